@@ -1,0 +1,342 @@
+// Batch-norm statistics / finalize / apply (+ReLU|ReLU6, residual add, Dropout2d channel scale) and
+// their backward, over NHWC pixel rows.  All HBM-bound streaming kernels: 16 B per lane, a 16-lane
+// group covers 64 consecutive channels of one pixel row (256 B), f32 accumulation, f64 finalize.
+// Reference sites: every batchnorm(...) + ReLU pair in models/{aspp,decoder}.py and
+// models/backbone/{resnet,mobilenet}.py (F.batch_norm training=True/False semantics of torch).
+#include "dass_common.h"
+
+namespace {
+
+constexpr int SLAB = 128;  // pixel rows per partial-statistics row
+
+// partial[slab][0][k] = sum f0, partial[slab][1][k] = sum f1 over the slab's rows.
+// MODE 0: f0 = x, f1 = x*x ; MODE 1: f0 = dact, f1 = dact*xhat
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void colstat_kernel(const T *__restrict__ x, long ldx, const T *__restrict__ dout,
+                                                      long lddo, const T *__restrict__ out, long ldo,
+                                                      const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                      const float *__restrict__ nc_scale, long M, int K,
+                                                      long rows_per_image, int act, float *__restrict__ partial) {
+    __shared__ float red[2][16][64 + 1];
+    const int tid = threadIdx.x;
+    const int cx = tid & 15, ry = tid >> 4;
+    const int k = blockIdx.y * 64 + cx * 4;
+    const long r0 = (long)blockIdx.x * SLAB;
+    long r1 = r0 + SLAB;
+    if (r1 > M) r1 = M;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    if (k < K) {
+        f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f};
+        if (MODE == 1) {
+            mu = *reinterpret_cast<const f32x4 *>(mean + k);
+            is = *reinterpret_cast<const f32x4 *>(invstd + k);
+        }
+        for (long r = r0 + ry; r < r1; r += 16) {
+            const f32x4 xv = ld4<T>(x + r * ldx + k);
+            if (MODE == 0) {
+                s0 += xv;
+                s1 += xv * xv;
+            } else {
+                f32x4 g = ld4<T>(dout + r * lddo + k);
+                const f32x4 o = ld4<T>(out + r * ldo + k);
+                if (nc_scale) g *= *reinterpret_cast<const f32x4 *>(nc_scale + (r / rows_per_image) * K + k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] *= act_grad_from_out(o[e], act);
+                s0 += g;
+                s1 += g * ((xv - mu) * is);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[0][ry][cx * 4 + e] = s0[e];
+        red[1][ry][cx * 4 + e] = s1[e];
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int which = tid >> 6, c = tid & 63;
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a += red[which][i][c];
+        const int kk = blockIdx.y * 64 + c;
+        if (kk < K) partial[((long)blockIdx.x * 2 + which) * K + kk] = a;
+    }
+}
+
+// one block per 64 channels; 4 row lanes; f64 accumulation of the partial rows
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ partial, int rows, int K,
+                                                          double count, double rep, const float *gamma,
+                                                          const float *beta, float *running_mean, float *running_var,
+                                                          float momentum, float eps, float *mean, float *invstd,
+                                                          float *scale, float *shift) {
+    __shared__ double red[2][4][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + c;
+    double s = 0.0, ss = 0.0;
+    if (k < K)
+        for (int r = rl; r < rows; r += 4) {
+            s += (double)partial[((long)r * 2 + 0) * K + k];
+            ss += (double)partial[((long)r * 2 + 1) * K + k];
+        }
+    red[0][rl][c] = s;
+    red[1][rl][c] = ss;
+    __syncthreads();
+    if (rl == 0 && k < K) {
+        s = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+        ss = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        const double mu = s * rep / count;
+        double var = ss * rep / count - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const double is = 1.0 / sqrt(var + (double)eps);
+        const float g = gamma ? gamma[k] : 1.f, b = beta ? beta[k] : 0.f;
+        mean[k] = (float)mu;
+        invstd[k] = (float)is;
+        const float sc = (float)((double)g * is);
+        scale[k] = sc;
+        shift[k] = (float)((double)b - mu * (double)g * is);
+        if (momentum >= 0.f && running_mean && running_var) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[k] = (1.f - momentum) * running_mean[k] + momentum * (float)mu;
+            running_var[k] = (1.f - momentum) * running_var[k] + momentum * (float)unb;
+        }
+    }
+}
+
+__global__ void bn_eval_kernel(const float *gamma, const float *beta, const float *rm, const float *rv, float eps,
+                               int K, float *mean, float *invstd, float *scale, float *shift) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const float is = 1.f / sqrtf(rv[k] + eps);
+    const float g = gamma ? gamma[k] : 1.f, b = beta ? beta[k] : 0.f;
+    mean[k] = rm[k];
+    invstd[k] = is;
+    scale[k] = g * is;
+    shift[k] = b - rm[k] * g * is;
+}
+
+__global__ __launch_bounds__(256) void bwd_finalize_kernel(const float *__restrict__ partial, int rows, int K,
+                                                           float *dbeta, float *dgamma) {
+    __shared__ double red[2][4][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + c;
+    double s = 0.0, ss = 0.0;
+    if (k < K)
+        for (int r = rl; r < rows; r += 4) {
+            s += (double)partial[((long)r * 2 + 0) * K + k];
+            ss += (double)partial[((long)r * 2 + 1) * K + k];
+        }
+    red[0][rl][c] = s;
+    red[1][rl][c] = ss;
+    __syncthreads();
+    if (rl == 0 && k < K) {
+        if (dbeta) dbeta[k] = (float)(red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        if (dgamma) dgamma[k] = (float)(red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_shift_act_kernel(const T *__restrict__ x, long ldx, T *__restrict__ out,
+                                                              long ldo, const float *__restrict__ scale,
+                                                              const float *__restrict__ shift,
+                                                              const T *__restrict__ res, long ldr,
+                                                              const float *__restrict__ nc_scale, long M, int K,
+                                                              long rows_per_image, int act) {
+    const int kv = K >> 2;
+    const long total = M * kv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / kv;
+        const int k = (int)(i - m * kv) << 2;
+        f32x4 v = ld4<T>(x + m * ldx + k);
+        if (scale) v *= *reinterpret_cast<const f32x4 *>(scale + k);
+        if (shift) v += *reinterpret_cast<const f32x4 *>(shift + k);
+        if (res) v += ld4<T>(res + m * ldr + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
+        if (nc_scale) v *= *reinterpret_cast<const f32x4 *>(nc_scale + (m / rows_per_image) * K + k);
+        st4<T>(out + m * ldo + k, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__ dout, long lddo,
+                                                           const T *__restrict__ out, long ldo,
+                                                           const T *__restrict__ x, long ldx,
+                                                           const float *__restrict__ mean,
+                                                           const float *__restrict__ invstd,
+                                                           const float *__restrict__ gamma,
+                                                           const float *__restrict__ dbeta,
+                                                           const float *__restrict__ dgamma,
+                                                           const float *__restrict__ nc_scale, T *__restrict__ dx,
+                                                           long lddx, T *__restrict__ dres, long lddr, long M, int K,
+                                                           long rows_per_image, float inv_count, int train, int act) {
+    const int kv = K >> 2;
+    const long total = M * kv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / kv;
+        const int k = (int)(i - m * kv) << 2;
+        f32x4 g = ld4<T>(dout + m * lddo + k);
+        const f32x4 o = ld4<T>(out + m * ldo + k);
+        if (nc_scale) g *= *reinterpret_cast<const f32x4 *>(nc_scale + (m / rows_per_image) * K + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] *= act_grad_from_out(o[e], act);
+        if (dres) st4<T>(dres + m * lddr + k, g);
+        if (dx) {
+            const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + k);
+            f32x4 ga = {1.f, 1.f, 1.f, 1.f};
+            if (gamma) ga = *reinterpret_cast<const f32x4 *>(gamma + k);
+            f32x4 r = g;
+            if (train) {
+                const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + k);
+                const f32x4 xh = (ld4<T>(x + m * ldx + k) - mu) * is;
+                const f32x4 db = *reinterpret_cast<const f32x4 *>(dbeta + k);
+                const f32x4 dg = *reinterpret_cast<const f32x4 *>(dgamma + k);
+                r = g - (db + xh * dg) * inv_count;
+            }
+            st4<T>(dx + m * lddx + k, r * (ga * is));
+        }
+    }
+}
+
+__global__ void colsum_finalize_kernel(const float *__restrict__ partial, int rows, int K, float *out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    double s = 0.0;
+    for (int r = 0; r < rows; ++r) s += (double)partial[((long)r * 2) * K + k];
+    out[k] = (float)s;
+}
+
+bool ok4(int K, int64_t a, int64_t b = 4, int64_t c = 4, int64_t d = 4) {
+    return K > 0 && K % 4 == 0 && a % 4 == 0 && b % 4 == 0 && c % 4 == 0 && d % 4 == 0;
+}
+
+}  // namespace
+
+extern "C" int dass_stat_rows(int64_t M) { return (int)((M + SLAB - 1) / SLAB); }
+
+extern "C" int dass_channel_stats(const void *x, int64_t ldx, int64_t M, int K, float *partial, int dtype,
+                                  void *stream) {
+    if (!x || !partial || M <= 0 || !ok4(K, ldx)) return DASS_ERR_ARG;
+    dim3 grid((unsigned)dass_stat_rows(M), (unsigned)((K + 63) / 64));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DASS_F32)
+        hipLaunchKernelGGL((colstat_kernel<float, 0>), grid, dim3(256), 0, st, (const float *)x, ldx, nullptr, 0,
+                           nullptr, 0, nullptr, nullptr, nullptr, M, K, 1, 0, partial);
+    else if (dtype == DASS_BF16)
+        hipLaunchKernelGGL((colstat_kernel<bf16_t, 0>), grid, dim3(256), 0, st, (const bf16_t *)x, ldx, nullptr, 0,
+                           nullptr, 0, nullptr, nullptr, nullptr, M, K, 1, 0, partial);
+    else
+        return DASS_ERR_UNSUPPORTED;
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_bn_finalize(const float *partial, int rows, int K, double count, double rep, const float *gamma,
+                                const float *beta, float *running_mean, float *running_var, float momentum,
+                                float eps, float *mean, float *invstd, float *scale, float *shift, void *stream) {
+    if (!partial || rows <= 0 || K <= 0 || count <= 0 || !mean || !invstd || !scale || !shift) return DASS_ERR_ARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((K + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial, rows, K,
+                       count, rep, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_bn_eval_scale_shift(const float *gamma, const float *beta, const float *running_mean,
+                                        const float *running_var, float eps, int K, float *mean, float *invstd,
+                                        float *scale, float *shift, void *stream) {
+    if (!running_mean || !running_var || K <= 0 || !mean || !invstd || !scale || !shift) return DASS_ERR_ARG;
+    hipLaunchKernelGGL(bn_eval_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                       running_mean, running_var, eps, K, mean, invstd, scale, shift);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_scale_shift_act(const void *x, int64_t ldx, void *out, int64_t ldo, const float *scale,
+                                    const float *shift, const void *residual, int64_t ldr, const float *nc_scale,
+                                    int64_t M, int K, int64_t rows_per_image, int act, int dtype, void *stream) {
+    if (!x || !out || M <= 0 || !ok4(K, ldx, ldo, residual ? ldr : 4) || rows_per_image <= 0) return DASS_ERR_ARG;
+    const int grid = dass_grid_1d(M * (K / 4), 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DASS_F32)
+        hipLaunchKernelGGL(scale_shift_act_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, ldx,
+                           (float *)out, ldo, scale, shift, (const float *)residual, ldr, nc_scale, M, K,
+                           rows_per_image, act);
+    else if (dtype == DASS_BF16)
+        hipLaunchKernelGGL(scale_shift_act_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)x, ldx,
+                           (bf16_t *)out, ldo, scale, shift, (const bf16_t *)residual, ldr, nc_scale, M, K,
+                           rows_per_image, act);
+    else
+        return DASS_ERR_UNSUPPORTED;
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_bn_bwd_reduce(const void *dout, int64_t lddo, const void *out, int64_t ldo, const void *x,
+                                  int64_t ldx, const float *mean, const float *invstd, const float *nc_scale,
+                                  int64_t M, int K, int64_t rows_per_image, int act, float *partial, int dtype,
+                                  void *stream) {
+    if (!dout || !out || !x || !mean || !invstd || !partial || M <= 0 || !ok4(K, lddo, ldo, ldx) ||
+        rows_per_image <= 0)
+        return DASS_ERR_ARG;
+    dim3 grid((unsigned)dass_stat_rows(M), (unsigned)((K + 63) / 64));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DASS_F32)
+        hipLaunchKernelGGL((colstat_kernel<float, 1>), grid, dim3(256), 0, st, (const float *)x, ldx,
+                           (const float *)dout, lddo, (const float *)out, ldo, mean, invstd, nc_scale, M, K,
+                           rows_per_image, act, partial);
+    else if (dtype == DASS_BF16)
+        hipLaunchKernelGGL((colstat_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t *)x, ldx,
+                           (const bf16_t *)dout, lddo, (const bf16_t *)out, ldo, mean, invstd, nc_scale, M, K,
+                           rows_per_image, act, partial);
+    else
+        return DASS_ERR_UNSUPPORTED;
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_bn_bwd_finalize(const float *partial, int rows, int K, float *dbeta, float *dgamma,
+                                    void *stream) {
+    if (!partial || rows <= 0 || K <= 0) return DASS_ERR_ARG;
+    hipLaunchKernelGGL(bwd_finalize_kernel, dim3((K + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial, rows, K,
+                       dbeta, dgamma);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_bn_bwd_apply(const void *dout, int64_t lddo, const void *out, int64_t ldo, const void *x,
+                                 int64_t ldx, const float *mean, const float *invstd, const float *gamma,
+                                 const float *dbeta, const float *dgamma, const float *nc_scale, void *dx,
+                                 int64_t lddx, void *dres, int64_t lddr, int64_t M, int K, int64_t rows_per_image,
+                                 double count, int train, int act, int dtype, void *stream) {
+    if (!dout || !out || M <= 0 || !ok4(K, lddo, ldo) || rows_per_image <= 0) return DASS_ERR_ARG;
+    if (dx && (!invstd || lddx % 4)) return DASS_ERR_ARG;
+    if (dx && train && (!x || !mean || !dbeta || !dgamma || ldx % 4 || count <= 0)) return DASS_ERR_ARG;
+    if (dres && lddr % 4) return DASS_ERR_ARG;
+    const int grid = dass_grid_1d(M * (K / 4), 256);
+    const float inv_count = train ? (float)(1.0 / count) : 0.f;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DASS_F32)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)dout, lddo,
+                           (const float *)out, ldo, (const float *)x, ldx, mean, invstd, gamma, dbeta, dgamma,
+                           nc_scale, (float *)dx, lddx, (float *)dres, lddr, M, K, rows_per_image, inv_count, train,
+                           act);
+    else if (dtype == DASS_BF16)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)dout, lddo,
+                           (const bf16_t *)out, ldo, (const bf16_t *)x, ldx, mean, invstd, gamma, dbeta, dgamma,
+                           nc_scale, (bf16_t *)dx, lddx, (bf16_t *)dres, lddr, M, K, rows_per_image, inv_count, train,
+                           act);
+    else
+        return DASS_ERR_UNSUPPORTED;
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_colsum(const void *x, int64_t ldx, int64_t M, int K, float *partial, float *out, int dtype,
+                           void *stream) {
+    if (!out) return DASS_ERR_ARG;
+    const int rc = dass_channel_stats(x, ldx, M, K, partial, dtype, stream);
+    if (rc != DASS_OK) return rc;
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial,
+                       dass_stat_rows(M), K, out);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}

@@ -1,0 +1,524 @@
+// Implicit-GEMM NHWC convolution for gfx950 (CDNA4) on MFMA.
+//
+// GEMM view:  Y[M = N*OH*OW pixels][K out-ch] = A[M][R*S*C] x B[R*S*C][K]
+//   A rows are gathered on the fly: for tap (r,s) the row of pixel m is the contiguous C-vector of
+//   the shifted input pixel (NHWC), zero where the tap falls in the padding.
+//   B is the KRSC weight tensor: row k is contiguous along the reduction (r,s,c).
+//
+// One 256-thread workgroup (4 waves) owns a BM x BN output tile.  Each reduction step stages a
+// 128-byte-wide slab (32 f32 / 64 bf16 channels of ONE tap) of A and B through LDS:
+//   global (16 B per lane, 8 lanes = one pixel's 128 B)  ->  registers  ->  LDS rows of 144 B
+// (128 + 16 pad: ds_read_b128 of 16 different rows then hits 16 different 16-B bank slots), and the
+// next slab's global loads are in flight while the current one is multiplied.
+//   f32 : v_mfma_f32_32x32x2_f32, exact f32 (parity mode).  A lane reads 16 B = 4 k-values and issues
+//         4 MFMAs; the k order inside the slab is permuted identically for A and B.
+//   bf16: v_mfma_f32_32x32x16_bf16, one MFMA per 16-B fragment.
+// Taps that are out of range for the whole tile (dilation 6/12/18 on a 33x33 map) are skipped.
+// The same kernel computes input gradients: dgrad of a stride-s conv is this kernel with
+// ustride = s over weights transformed by dass_weight_transform(mode=1).
+//
+// Reference sites replaced: every groups=1 nn.Conv2d on the DeepLab path (see include/dass_hip.h).
+#include "dass_common.h"
+
+namespace {
+
+struct ConvP {
+    const char *x;
+    const char *w;
+    char *y;
+    const float *scale;
+    const float *shift;
+    const char *res;
+    const float *in_scale;
+    long ldx, ldy, ldr;
+    long wk_stride;  // R*S*C
+    int N, H, W, C, OH, OW, K, R, S, stride, pad, dil, ustride, act;
+    int M, cchunks, mtiles, ntiles;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<float> {
+    static __device__ __forceinline__ void run(const uint4 &a, const uint4 &b, f32x16 &acc) {
+        const float *af = reinterpret_cast<const float *>(&a);
+        const float *bf = reinterpret_cast<const float *>(&b);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<bf16_t> {
+    static __device__ __forceinline__ void run(const uint4 &a, const uint4 &b, f32x16 &acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&a),
+                                                      *reinterpret_cast<const bf16x8 *>(&b), acc, 0, 0, 0);
+    }
+};
+
+template <typename T> __device__ __forceinline__ uint4 scale_vec(uint4 v, const float *s);
+template <> __device__ __forceinline__ uint4 scale_vec<float>(uint4 v, const float *s) {
+    float *f = reinterpret_cast<float *>(&v);
+    const f32x4 sv = *reinterpret_cast<const f32x4 *>(s);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] *= sv[e];
+    return v;
+}
+template <> __device__ __forceinline__ uint4 scale_vec<bf16_t>(uint4 v, const float *s) {
+    bf16_t *h = reinterpret_cast<bf16_t *>(&v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = f32_to_bf16(bf16_to_f32(h[e]) * s[e]);
+    return v;
+}
+
+constexpr int ROWB = 144;  // LDS bytes per staged row (128 data + 16 pad)
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
+    constexpr int ES = sizeof(T);
+    constexpr int EPV = 16 / ES;  // elements per 16-byte vector
+    constexpr int BK = 8 * EPV;   // reduction elements per staged slab (128 B)
+    constexpr int AR = BM / 32, BR = BN / 32;
+    constexpr int TMW = BM / WM, TNW = BN / WN, MT = TMW / 32, NT = TNW / 32;
+    static_assert(WM * WN == 4, "4 waves");
+    static_assert(MT >= 1 && NT >= 1, "wave tile");
+
+    __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * ROWB];
+    char *As = smem;
+    char *Bs = smem + BM * ROWB;
+
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt_i = wg / p.ntiles, nt_i = wg - mt_i * p.ntiles;
+    const int m0 = mt_i * BM, n0 = nt_i * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = tid >> 3, lchunk = tid & 7;
+    const int wm = wave / WN, wn = wave - wm * WN;
+
+    // ---- per-thread description of the A rows it stages
+    int a_iy0[AR], a_ix0[AR], a_n[AR];
+    long a_nb[AR];
+    bool a_ok[AR];
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int j = 0; j < AR; ++j) {
+        const int m = m0 + lrow + 32 * j;
+        a_ok[j] = m < p.M;
+        const int mm = a_ok[j] ? m : 0;
+        const int n = mm / ohw;
+        const int rem = mm - n * ohw;
+        const int oh = rem / p.OW;
+        const int ow = rem - oh * p.OW;
+        a_iy0[j] = oh * p.stride - p.pad;
+        a_ix0[j] = ow * p.stride - p.pad;
+        a_n[j] = n;
+        a_nb[j] = (long)n * p.H * p.W;
+    }
+
+    auto tap_pixel = [&](int j, int r, int s, long &pix) -> bool {
+        int iy = a_iy0[j] + r * p.dil, ix = a_ix0[j] + s * p.dil;
+        bool ok = a_ok[j] && iy >= 0 && ix >= 0;
+        if (p.ustride > 1) {
+            ok = ok && (iy % p.ustride == 0) && (ix % p.ustride == 0);
+            iy /= p.ustride;
+            ix /= p.ustride;
+        }
+        ok = ok && iy < p.H && ix < p.W;
+        pix = a_nb[j] + (long)iy * p.W + ix;
+        return ok;
+    };
+
+    // ---- which taps touch this tile at all
+    const int ntaps = p.R * p.S;
+    unsigned long long tapmask = 0ull;
+    for (int t = 0; t < ntaps; ++t) {
+        const int r = t / p.S, s = t - r * p.S;
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < AR; ++j) {
+            long pix;
+            any = any || tap_pixel(j, r, s, pix);
+        }
+        if (__syncthreads_or((int)any)) tapmask |= (1ull << t);
+    }
+
+    uint4 ra[AR], rb[BR];
+    auto load_stage = [&](int t, int cc) {
+        const int r = t / p.S, s = t - r * p.S;
+        const int c = cc * BK + lchunk * EPV;
+        const bool okc = c < p.C;
+#pragma unroll
+        for (int j = 0; j < AR; ++j) {
+            long pix;
+            const bool ok = tap_pixel(j, r, s, pix) && okc;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (ok) {
+                v = *reinterpret_cast<const uint4 *>(p.x + (pix * p.ldx + c) * ES);
+                if (p.in_scale) v = scale_vec<T>(v, p.in_scale + (long)a_n[j] * p.C + c);
+            }
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < BR; ++j) {
+            const int k = n0 + lrow + 32 * j;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (k < p.K && okc) v = *reinterpret_cast<const uint4 *>(p.w + ((long)k * p.wk_stride + (long)t * p.C + c) * ES);
+            rb[j] = v;
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // ---- reduction loop over (active tap, channel slab)
+    unsigned long long rem_mask = tapmask;
+    int cur_t = -1, cur_cc = 0;
+    bool have = false;
+    if (rem_mask) {
+        cur_t = __builtin_ctzll(rem_mask);
+        rem_mask &= rem_mask - 1;
+        cur_cc = 0;
+        have = true;
+        load_stage(cur_t, cur_cc);
+    }
+    while (have) {
+        __syncthreads();  // everyone finished reading the previous slab
+#pragma unroll
+        for (int j = 0; j < AR; ++j) *reinterpret_cast<uint4 *>(As + (lrow + 32 * j) * ROWB + lchunk * 16) = ra[j];
+#pragma unroll
+        for (int j = 0; j < BR; ++j) *reinterpret_cast<uint4 *>(Bs + (lrow + 32 * j) * ROWB + lchunk * 16) = rb[j];
+        __syncthreads();
+
+        // advance and prefetch the next slab (loads stay in flight under the MFMAs)
+        ++cur_cc;
+        if (cur_cc >= p.cchunks) {
+            cur_cc = 0;
+            if (rem_mask) {
+                cur_t = __builtin_ctzll(rem_mask);
+                rem_mask &= rem_mask - 1;
+            } else {
+                have = false;
+            }
+        }
+        if (have) load_stage(cur_t, cur_cc);
+
+        const char *ap = As + (wm * TMW + (lane & 31)) * ROWB + (lane >> 5) * 16;
+        const char *bp = Bs + (wn * TNW + (lane & 31)) * ROWB + (lane >> 5) * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint4 a[MT], b[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const uint4 *>(ap + mt * 32 * ROWB + i * 32);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const uint4 *>(bp + nt * 32 * ROWB + i * 32);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) Mma<T>::run(a[mt], b[nt], acc[mt][nt]);
+        }
+    }
+
+    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    T *y = reinterpret_cast<T *>(p.y);
+    const T *res = reinterpret_cast<const T *>(p.res);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int k = n0 + wn * TNW + nt * 32 + (lane & 31);
+        if (k >= p.K) continue;
+        const float sc = p.scale ? p.scale[k] : 1.f;
+        const float sh = p.shift ? p.shift[k] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                const int m = m0 + wm * TMW + mt * 32 + row;
+                if (m < p.M) {
+                    float v = acc[mt][nt][reg] * sc + sh;
+                    if (res) v += Elem<T>::ld(res + (long)m * p.ldr + k);
+                    v = apply_act(v, p.act);
+                    Elem<T>::st(y + (long)m * p.ldy + k, v);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ wgrad
+// dW[k][tap][c] = sum_pixels dY[pix][k] * X[pix @ tap][c].  GEMM with the PIXEL axis as reduction:
+// both operands sit in memory as [pixel][channel], which is exactly what the f32 MFMA wants when the
+// LDS tile is kept [pixel][channel]: lane (i = lane&31, h = lane>>5) reads element [2*kk+h][i], i.e.
+// 32 consecutive floats per half-wave -> conflict-free ds_read_b32.  One workgroup = one
+// (K-tile, C-tile, tap, pixel-split); partial tiles are accumulated into dW with f32 atomics
+// (256 contiguous bytes per wave-instruction, the shape that runs at the full atomic rate).
+struct WgradP {
+    const char *x;
+    const char *dy;
+    float *dw;
+    long ldx, lddy;
+    int N, H, W, C, OH, OW, K, R, S, stride, pad, dil;
+    int M, ktiles, ctiles, psplit, pix_per_split;
+};
+
+template <typename T, int BMK, int BNC>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
+    constexpr int BP = 32;          // pixels per staged slab
+    constexpr int LDA = BMK + 4;    // floats per LDS row (pad keeps 16-B alignment, staggers rows)
+    constexpr int LDB = BNC + 4;
+    constexpr int TMW = BMK / 2, TNW = BNC / 2, MT = TMW / 32, NT = TNW / 32;
+    constexpr int CPR_A = BMK / 4, RPP_A = 256 / CPR_A, PASS_A = BP / RPP_A;  // 16-B chunks of 4 f32 in LDS
+    constexpr int CPR_B = BNC / 4, RPP_B = 256 / CPR_B, PASS_B = BP / RPP_B;
+    static_assert(MT >= 1 && NT >= 1, "tile");
+    static_assert(PASS_A >= 1 && PASS_B >= 1, "passes");
+
+    __shared__ __attribute__((aligned(16))) float As[BP * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[BP * LDB];
+
+    int wg = blockIdx.x;
+    const int ps = wg % p.psplit;
+    wg /= p.psplit;
+    const int tap = wg % (p.R * p.S);
+    wg /= (p.R * p.S);
+    const int ct = wg % p.ctiles;
+    const int kt = wg / p.ctiles;
+    const int k0 = kt * BMK, c0 = ct * BNC;
+    const int r = tap / p.S, s = tap - r * p.S;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ohw = p.OH * p.OW;
+
+    const long pbeg = (long)ps * p.pix_per_split;
+    long pend = pbeg + p.pix_per_split;
+    if (pend > p.M) pend = p.M;
+
+    const int arow = tid / CPR_A, achunk = tid % CPR_A;
+    const int brow = tid / CPR_B, bchunk = tid % CPR_B;
+    const T *xg = reinterpret_cast<const T *>(p.x);
+    const T *dyg = reinterpret_cast<const T *>(p.dy);
+
+    f32x4 ra[PASS_A], rb[PASS_B];
+    auto load_stage = [&](long pb) {
+#pragma unroll
+        for (int j = 0; j < PASS_A; ++j) {
+            const long pix = pb + arow + j * RPP_A;
+            const int k = k0 + achunk * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (pix < pend && k < p.K) v = ld4<T>(dyg + pix * p.lddy + k);
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < PASS_B; ++j) {
+            const long pix = pb + brow + j * RPP_B;
+            const int c = c0 + bchunk * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (pix < pend && c < p.C) {
+                const int n = (int)(pix / ohw);
+                const int rem = (int)(pix - (long)n * ohw);
+                const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                const int iy = oh * p.stride - p.pad + r * p.dil;
+                const int ix = ow * p.stride - p.pad + s * p.dil;
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                    v = ld4<T>(xg + (((long)n * p.H + iy) * p.W + ix) * p.ldx + c);
+            }
+            rb[j] = v;
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    long pb = pbeg;
+    if (pb < pend) load_stage(pb);
+    while (pb < pend) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PASS_A; ++j) *reinterpret_cast<f32x4 *>(&As[(arow + j * RPP_A) * LDA + achunk * 4]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < PASS_B; ++j) *reinterpret_cast<f32x4 *>(&Bs[(brow + j * RPP_B) * LDB + bchunk * 4]) = rb[j];
+        __syncthreads();
+        pb += BP;
+        if (pb < pend) load_stage(pb);
+
+        const float *ap = As + (lane >> 5) * LDA + wm * TMW + (lane & 31);
+        const float *bp = Bs + (lane >> 5) * LDB + wn * TNW + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < BP / 2; ++kk) {
+            float a[MT], b[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = ap[kk * 2 * LDA + mt * 32];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = bp[kk * 2 * LDB + nt * 32];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+
+    const long rs = (long)p.R * p.S;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int c = c0 + wn * TNW + nt * 32 + (lane & 31);
+        if (c >= p.C) continue;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                const int k = k0 + wm * TMW + mt * 32 + row;
+                if (k < p.K) atomicAdd(p.dw + ((long)k * rs + tap) * p.C + c, acc[mt][nt][reg]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ weights
+template <typename T>
+__global__ void weight_transform_kernel(const float *__restrict__ src, T *__restrict__ dst, int K, int R, int S,
+                                        int Csrc, int Cdst, int mode) {
+    const long total = (long)K * R * S * Cdst;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        if (mode == 0) {
+            // dst [K][R][S][Cdst]
+            const int c = (int)(i % Cdst);
+            const long krs = i / Cdst;
+            const float v = c < Csrc ? src[krs * Csrc + c] : 0.f;
+            Elem<T>::st(dst + i, v);
+        } else {
+            // dst [C=Cdst][R][S][K] with taps flipped; src [K][R][S][Csrc]; Cdst == Csrc here
+            const int k = (int)(i % K);
+            long t = i / K;
+            const int s = (int)(t % S);
+            t /= S;
+            const int r = (int)(t % R);
+            const int c = (int)(t / R);
+            const float v = src[(((long)k * R + (R - 1 - r)) * S + (S - 1 - s)) * Csrc + c];
+            Elem<T>::st(dst + i, v);
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN> int launch_conv(ConvP &p, hipStream_t st) {
+    p.mtiles = (p.M + BM - 1) / BM;
+    p.ntiles = (p.K + BN - 1) / BN;
+    const int grid = p.mtiles * p.ntiles;
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN>), dim3(grid), dim3(256), 0, st, p);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+template <typename T> int dispatch_conv(ConvP &p, hipStream_t st) {
+    constexpr int EPV = 16 / sizeof(T);
+    p.cchunks = (p.C + 8 * EPV - 1) / (8 * EPV);
+    const long target = 512;  // >= 2 workgroups per CU
+    auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.K + bn - 1) / bn); };
+    if (p.K <= 32) return launch_conv<T, 128, 32, 4, 1>(p, st);
+    if (p.K > 64 && tiles(128, 128) >= target) return launch_conv<T, 128, 128, 2, 2>(p, st);
+    if (tiles(128, 64) >= target) return launch_conv<T, 128, 64, 2, 2>(p, st);
+    return launch_conv<T, 64, 64, 2, 2>(p, st);
+}
+
+template <typename T, int BMK, int BNC> int launch_wgrad(WgradP &p, hipStream_t st) {
+    p.ktiles = (p.K + BMK - 1) / BMK;
+    p.ctiles = (p.C + BNC - 1) / BNC;
+    const long base = (long)p.ktiles * p.ctiles * p.R * p.S;
+    long want = (1024 + base - 1) / base;  // aim at ~4 workgroups per CU
+    long maxsplit = (p.M + 255) / 256;     // at least 8 slabs of 32 pixels per workgroup
+    if (want > maxsplit) want = maxsplit;
+    if (want < 1) want = 1;
+    long pps = (p.M + want - 1) / want;
+    pps = (pps + 31) / 32 * 32;
+    p.pix_per_split = (int)pps;
+    p.psplit = (int)((p.M + pps - 1) / pps);
+    const long grid = base * p.psplit;
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, BMK, BNC>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+template <typename T> int dispatch_wgrad(WgradP &p, hipStream_t st) {
+    const bool kbig = p.K > 64, cbig = p.C > 64;
+    if (kbig && cbig) return launch_wgrad<T, 128, 128>(p, st);
+    if (kbig) return launch_wgrad<T, 128, 64>(p, st);
+    if (cbig) return launch_wgrad<T, 64, 128>(p, st);
+    return launch_wgrad<T, 64, 64>(p, st);
+}
+
+}  // namespace
+
+extern "C" int dass_conv2d_igemm(const void *x, int64_t ldx, const void *w, void *y, int64_t ldy, const float *scale,
+                                 const float *shift, const void *residual, int64_t ldr, const float *in_scale, int N,
+                                 int H, int W, int C, int OH, int OW, int K, int R, int S, int stride, int pad,
+                                 int dil, int ustride, int act, int dtype, void *stream) {
+    if (!x || !w || !y) return DASS_ERR_ARG;
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || K <= 0 || R <= 0 || S <= 0) return DASS_ERR_ARG;
+    if (R * S > 64 || stride < 1 || dil < 1 || ustride < 1) return DASS_ERR_ARG;
+    const int epv = dtype == DASS_F32 ? 4 : 8;
+    if (dtype != DASS_F32 && dtype != DASS_BF16) return DASS_ERR_UNSUPPORTED;
+    if (C % epv != 0 || ldx % epv != 0 || ((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return DASS_ERR_ARG;
+    if ((long)N * OH * OW >= (1l << 31)) return DASS_ERR_ARG;
+    ConvP p;
+    p.x = (const char *)x;
+    p.w = (const char *)w;
+    p.y = (char *)y;
+    p.scale = scale;
+    p.shift = shift;
+    p.res = (const char *)residual;
+    p.in_scale = in_scale;
+    p.ldx = ldx;
+    p.ldy = ldy;
+    p.ldr = ldr;
+    p.wk_stride = (long)R * S * C;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K; p.R = R; p.S = S;
+    p.stride = stride; p.pad = pad; p.dil = dil; p.ustride = ustride; p.act = act;
+    p.M = N * OH * OW;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == DASS_F32 ? dispatch_conv<float>(p, st) : dispatch_conv<bf16_t>(p, st);
+}
+
+extern "C" int dass_conv2d_wgrad(const void *x, int64_t ldx, const void *dy, int64_t lddy, float *dw, int N, int H, int W, int C, int OH, int OW, int K, int R,
+                                 int S, int stride, int pad, int dil, int dtype, void *stream) {
+    if (!x || !dy || !dw) return DASS_ERR_ARG;
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || K <= 0 || R <= 0 || S <= 0) return DASS_ERR_ARG;
+    if (dtype != DASS_F32 && dtype != DASS_BF16) return DASS_ERR_UNSUPPORTED;
+    if (C % 4 != 0 || K % 4 != 0 || ldx % 4 != 0 || lddy % 4 != 0) return DASS_ERR_ARG;
+    if ((long)N * OH * OW >= (1l << 31)) return DASS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * R * S * C, st) != hipSuccess) return DASS_ERR_LAUNCH;
+    WgradP p;
+    p.x = (const char *)x;
+    p.dy = (const char *)dy;
+    p.dw = dw;
+    p.ldx = ldx;
+    p.lddy = lddy;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K; p.R = R; p.S = S;
+    p.stride = stride; p.pad = pad; p.dil = dil;
+    p.M = N * OH * OW;
+    return dtype == DASS_F32 ? dispatch_wgrad<float>(p, st) : dispatch_wgrad<bf16_t>(p, st);
+}
+
+extern "C" int dass_weight_transform(const float *src, void *dst, int K, int R, int S, int Csrc, int Cdst, int mode,
+                                     int dtype, void *stream) {
+    if (!src || !dst || K <= 0 || R <= 0 || S <= 0 || Csrc <= 0 || Cdst <= 0) return DASS_ERR_ARG;
+    if (mode == 1 && Csrc != Cdst) return DASS_ERR_ARG;
+    if (mode != 0 && mode != 1) return DASS_ERR_ARG;
+    const long total = (long)K * R * S * Cdst;
+    const int grid = dass_grid_1d(total, 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DASS_F32)
+        hipLaunchKernelGGL(weight_transform_kernel<float>, dim3(grid), dim3(256), 0, st, src, (float *)dst, K, R, S, Csrc, Cdst, mode);
+    else if (dtype == DASS_BF16)
+        hipLaunchKernelGGL(weight_transform_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, src, (bf16_t *)dst, K, R, S, Csrc, Cdst, mode);
+    else
+        return DASS_ERR_UNSUPPORTED;
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}

@@ -1,0 +1,86 @@
+// Shared device helpers for libdass_hip (gfx950 only: 64-lane waves, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dass_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short bf16_t;  // raw storage
+
+#define DASS_LAUNCH_CHECK()                               \
+    do {                                                  \
+        if (hipGetLastError() != hipSuccess) return DASS_ERR_LAUNCH; \
+    } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    // round-to-nearest-even via the hardware convert (keeps NaN a NaN, see MI355X_MICROARCH hazards table)
+    __bf16 b = (__bf16)f;
+    return *reinterpret_cast<bf16_t *>(&b);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static __device__ __forceinline__ float ld(const float *p) { return *p; }
+    static __device__ __forceinline__ void st(float *p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static __device__ __forceinline__ float ld(const bf16_t *p) { return bf16_to_f32(*p); }
+    static __device__ __forceinline__ void st(bf16_t *p, float v) { *p = f32_to_bf16(v); }
+};
+
+// 4-element vector access (16 B f32 / 8 B bf16); pointers must be aligned accordingly.
+template <typename T> __device__ __forceinline__ f32x4 ld4(const T *p);
+template <> __device__ __forceinline__ f32x4 ld4<float>(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+template <> __device__ __forceinline__ f32x4 ld4<bf16_t>(const bf16_t *p) {
+    uint2 u = *reinterpret_cast<const uint2 *>(p);
+    f32x4 r;
+    r[0] = __uint_as_float(u.x << 16);
+    r[1] = __uint_as_float(u.x & 0xffff0000u);
+    r[2] = __uint_as_float(u.y << 16);
+    r[3] = __uint_as_float(u.y & 0xffff0000u);
+    return r;
+}
+template <typename T> __device__ __forceinline__ void st4(T *p, f32x4 v);
+template <> __device__ __forceinline__ void st4<float>(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t *p, f32x4 v) {
+    uint2 u;
+    u.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+    u.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+    *reinterpret_cast<uint2 *>(p) = u;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == DASS_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == DASS_ACT_RELU6) return v < 0.f ? 0.f : (v > 6.f ? 6.f : v);
+    return v;
+}
+// derivative of the activation expressed on its OUTPUT (out>0 <=> pre-activation>0, etc.)
+__device__ __forceinline__ float act_grad_from_out(float out, int act) {
+    if (act == DASS_ACT_RELU) return out > 0.f ? 1.f : 0.f;
+    if (act == DASS_ACT_RELU6) return (out > 0.f && out < 6.f) ? 1.f : 0.f;
+    return 1.f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of logical tiles so
+// tiles that share an operand panel hit the same L2 (cdna_hip_programming.md T1, bijective form).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+static inline int dass_grid_1d(int64_t work_items, int block) {
+    int64_t g = (work_items + block - 1) / block;
+    const int64_t cap = 256 * 8;  // 256 CUs x 8 blocks: grid-stride the rest
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}

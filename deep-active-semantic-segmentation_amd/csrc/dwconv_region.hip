@@ -1,0 +1,481 @@
+// Depthwise 3x3 convolution (MobileNetV2 InvertedResidual, models/backbone/mobilenet.py:49,59)
+// forward / input-gradient / weight-gradient, and the region-selection helpers of
+// active_selection/mc_dropout.py:82-155 (box-filter score maps, global min-max normalise, greedy
+// square NMS).  Depthwise conv is bandwidth-bound: one lane owns 4 channels of one pixel, taps are
+// 16-B loads that hit L1/L2 for the 9x re-read; the weight gradient reduces per-block partials in
+// LDS and finishes with contiguous f32 atomics.
+#include "dass_common.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void dw_fwd_kernel(const T *__restrict__ x, long ldx, const float *__restrict__ w,
+                                                     T *__restrict__ y, long ldy, int N, int H, int W, int C, int OH,
+                                                     int OW, int stride, int pad, int dil) {
+    const int cv = C >> 2;
+    const long total = (long)N * OH * OW * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) << 2;
+        long t = i / cv;
+        const int ow = (int)(t % OW);
+        t /= OW;
+        const int oh = (int)(t % OH);
+        const long n = t / OH;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int iy = oh * stride - pad + r * dil;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int ix = ow * stride - pad + s * dil;
+                if (ix < 0 || ix >= W) continue;
+                const f32x4 v = ld4<T>(x + ((n * H + iy) * W + ix) * ldx + c);
+                const int tap = r * 3 + s;
+                a[0] += v[0] * w[(c + 0) * 9 + tap];
+                a[1] += v[1] * w[(c + 1) * 9 + tap];
+                a[2] += v[2] * w[(c + 2) * 9 + tap];
+                a[3] += v[3] * w[(c + 3) * 9 + tap];
+            }
+        }
+        st4<T>(y + ((n * OH + oh) * OW + ow) * ldy + c, a);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dw_bwd_data_kernel(const T *__restrict__ dy, long lddy,
+                                                          const float *__restrict__ w, T *__restrict__ dx, long lddx,
+                                                          int N, int H, int W, int C, int OH, int OW, int stride,
+                                                          int pad, int dil) {
+    const int cv = C >> 2;
+    const long total = (long)N * H * W * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) << 2;
+        long t = i / cv;
+        const int ix = (int)(t % W);
+        t /= W;
+        const int iy = (int)(t % H);
+        const long n = t / H;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int ty = iy + pad - r * dil;
+            if (ty < 0 || ty % stride) continue;
+            const int oh = ty / stride;
+            if (oh >= OH) continue;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int tx = ix + pad - s * dil;
+                if (tx < 0 || tx % stride) continue;
+                const int ow = tx / stride;
+                if (ow >= OW) continue;
+                const f32x4 g = ld4<T>(dy + ((n * OH + oh) * OW + ow) * lddy + c);
+                const int tap = r * 3 + s;
+                a[0] += g[0] * w[(c + 0) * 9 + tap];
+                a[1] += g[1] * w[(c + 1) * 9 + tap];
+                a[2] += g[2] * w[(c + 2) * 9 + tap];
+                a[3] += g[3] * w[(c + 3) * 9 + tap];
+            }
+        }
+        st4<T>(dx + ((n * H + iy) * W + ix) * lddx + c, a);
+    }
+}
+
+// grid (C/64, pixel slabs); thread = (channel c of 64, pixel lane of 4); 9 accumulators per thread
+template <typename T>
+__global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const T *__restrict__ x, long ldx,
+                                                            const T *__restrict__ dy, long lddy,
+                                                            float *__restrict__ dw, int N, int H, int W, int C,
+                                                            int OH, int OW, int stride, int pad, int dil,
+                                                            long pix_per_block) {
+    __shared__ float red[4][9][64];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const long M = (long)N * OH * OW;
+    const long p0 = (long)blockIdx.y * pix_per_block;
+    long p1 = p0 + pix_per_block;
+    if (p1 > M) p1 = M;
+    float a[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) a[t] = 0.f;
+    if (c < C) {
+        const long ohw = (long)OH * OW;
+        for (long p = p0 + pl; p < p1; p += 4) {
+            const long n = p / ohw;
+            const long rem = p - n * ohw;
+            const int oh = (int)(rem / OW), ow = (int)(rem - (long)oh * OW);
+            const float g = Elem<T>::ld(dy + p * lddy + c);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int iy = oh * stride - pad + r * dil;
+                if (iy < 0 || iy >= H) continue;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const int ix = ow * stride - pad + s * dil;
+                    if (ix < 0 || ix >= W) continue;
+                    a[r * 3 + s] += g * Elem<T>::ld(x + ((n * H + iy) * W + ix) * ldx + c);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) red[pl][t][cl] = a[t];
+    __syncthreads();
+    if (pl == 0 && c < C) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) atomicAdd(dw + (long)c * 9 + t, red[0][t][cl] + red[1][t][cl] + red[2][t][cl] + red[3][t][cl]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- regions
+// horizontal then vertical running box sums (valid), f64 accumulators -> f32
+__global__ void box_rows_kernel(const float *__restrict__ in, float *__restrict__ tmp, int N, int H, int W, int r) {
+    const int OWd = W - r + 1;
+    const long total = (long)N * H * OWd;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % OWd);
+        const long row = i / OWd;
+        const float *p = in + row * W + ox;
+        double s = 0.0;
+        for (int j = 0; j < r; ++j) s += (double)p[j];
+        tmp[i] = (float)s;
+    }
+}
+__global__ void box_cols_kernel(const float *__restrict__ tmp, float *__restrict__ out, int N, int H, int W, int r) {
+    const int OWd = W - r + 1, OHd = H - r + 1;
+    const long total = (long)N * OHd * OWd;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % OWd);
+        long t = i / OWd;
+        const int oy = (int)(t % OHd);
+        const long n = t / OHd;
+        const float *p = tmp + (n * H + oy) * OWd + ox;
+        double s = 0.0;
+        for (int j = 0; j < r; ++j) s += (double)p[(long)j * OWd];
+        out[i] = (float)s;
+    }
+}
+
+__global__ void zero_rect_kernel(float *__restrict__ maps, long base, int W, int r0, int r1, int c0, int c1) {
+    const int h = r1 - r0, w = c1 - c0;
+    const long total = (long)h * w;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / w), x = (int)(i - (long)y * w);
+        maps[base + (long)(r0 + y) * W + c0 + x] = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void minmax_stage1_kernel(const float *__restrict__ v, long n,
+                                                            float *__restrict__ partial) {
+    __shared__ float smin[256], smax[256];
+    float lo = INFINITY, hi = -INFINITY;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float x = v[i];
+        lo = fminf(lo, x);
+        hi = fmaxf(hi, x);
+    }
+    smin[threadIdx.x] = lo;
+    smax[threadIdx.x] = hi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            smin[threadIdx.x] = fminf(smin[threadIdx.x], smin[threadIdx.x + o]);
+            smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + o]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x * 2] = smin[0];
+        partial[blockIdx.x * 2 + 1] = smax[0];
+    }
+}
+__global__ __launch_bounds__(256) void minmax_stage2_kernel(const float *__restrict__ partial, int blocks,
+                                                            float *__restrict__ out) {
+    __shared__ float smin[256], smax[256];
+    float lo = INFINITY, hi = -INFINITY;
+    for (int i = threadIdx.x; i < blocks; i += 256) {
+        lo = fminf(lo, partial[i * 2]);
+        hi = fmaxf(hi, partial[i * 2 + 1]);
+    }
+    smin[threadIdx.x] = lo;
+    smax[threadIdx.x] = hi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            smin[threadIdx.x] = fminf(smin[threadIdx.x], smin[threadIdx.x + o]);
+            smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + o]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = smin[0];
+        out[1] = smax[0];
+    }
+}
+// x.add_(-min).mul_(1/(max-min)) exactly as mc_dropout.py:154
+__global__ void affine_kernel(float *__restrict__ v, long n, const float *__restrict__ mm) {
+    const float lo = mm[0];
+    const float inv = 1.0f / (mm[1] - mm[0]);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        v[i] = (v[i] + (-lo)) * inv;
+}
+
+// per-image (max, first index) of [N][HW] maps: grid N
+__global__ __launch_bounds__(256) void image_argmax_kernel(const float *__restrict__ maps, long HW,
+                                                           float *__restrict__ imax, int *__restrict__ iarg) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const long n = blockIdx.x;
+    const float *m = maps + n * HW;
+    float best = -INFINITY;
+    int bi = -1;
+    for (long i = threadIdx.x; i < HW; i += 256) {
+        const float x = m[i];
+        if (bi < 0 || x > best) {
+            best = x;
+            bi = (int)i;
+        }
+    }
+    sv[threadIdx.x] = best;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            const float x = sv[threadIdx.x + o];
+            const int j = si[threadIdx.x + o], cur = si[threadIdx.x];
+            if (j >= 0 && (cur < 0 || x > sv[threadIdx.x] || (x == sv[threadIdx.x] && j < cur))) {
+                sv[threadIdx.x] = x;
+                si[threadIdx.x] = j;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        imax[n] = sv[0];
+        iarg[n] = si[0];
+    }
+}
+
+// Greedy square NMS (mc_dropout.py:82-108) as ONE single-workgroup kernel over the per-image
+// (max, argmax) cache: pick the global first-max, record (image,row,col), zero the clipped
+// (2*region)^2 box anchored at (row-region, col-region), refresh that image's cache, stop when the
+// global max < 0.01 or after max_picks.  Sequential by definition; 1024 lanes do each step's scans.
+__global__ __launch_bounds__(1024) void square_nms_kernel(float *__restrict__ maps, int N, int H, int W, int region,
+                                                          int max_picks, float *__restrict__ imax,
+                                                          int *__restrict__ iarg, int *__restrict__ picks,
+                                                          int *__restrict__ count) {
+    __shared__ float sv[1024];
+    __shared__ long si[1024];
+    __shared__ int s_img, s_pos, s_stop;
+    const int tid = threadIdx.x;
+    const long HW = (long)H * W;
+    int npicks = 0;
+    for (int it = 0; it < max_picks; ++it) {
+        // global first-max over images: flat index = n*HW + iarg[n]
+        float best = -INFINITY;
+        long bi = -1;
+        for (int n = tid; n < N; n += 1024) {
+            const float x = imax[n];
+            const long f = (long)n * HW + iarg[n];
+            if (bi < 0 || x > best || (x == best && f < bi)) {
+                best = x;
+                bi = f;
+            }
+        }
+        sv[tid] = best;
+        si[tid] = bi;
+        __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) {
+            if (tid < o) {
+                const float x = sv[tid + o];
+                const long j = si[tid + o], cur = si[tid];
+                if (j >= 0 && (cur < 0 || x > sv[tid] || (x == sv[tid] && j < cur))) {
+                    sv[tid] = x;
+                    si[tid] = j;
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const long f = si[0];
+            s_img = (int)(f / HW);
+            s_pos = (int)(f - (long)s_img * HW);
+            picks[npicks * 3 + 0] = s_img;
+            picks[npicks * 3 + 1] = s_pos / W;
+            picks[npicks * 3 + 2] = s_pos % W;
+        }
+        __syncthreads();
+        ++npicks;
+        const int img = s_img, r = s_pos / W, c = s_pos % W;
+        const int r0 = max(0, r - region), c0 = max(0, c - region);
+        const int r1 = min(H, r + region), c1 = min(W, c + region);
+        float *m = maps + (long)img * HW;
+        const int bw = c1 - c0, bh = r1 - r0;
+        for (int i = tid; i < bw * bh; i += 1024) m[(long)(r0 + i / bw) * W + c0 + i % bw] = 0.f;
+        __syncthreads();
+        // refresh this image's cache
+        best = -INFINITY;
+        bi = -1;
+        for (long i = tid; i < HW; i += 1024) {
+            const float x = m[i];
+            if (bi < 0 || x > best) {
+                best = x;
+                bi = i;
+            }
+        }
+        sv[tid] = best;
+        si[tid] = bi;
+        __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) {
+            if (tid < o) {
+                const float x = sv[tid + o];
+                const long j = si[tid + o], cur = si[tid];
+                if (j >= 0 && (cur < 0 || x > sv[tid] || (x == sv[tid] && j < cur))) {
+                    sv[tid] = x;
+                    si[tid] = j;
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            imax[img] = sv[0];
+            iarg[img] = (int)si[0];
+        }
+        __syncthreads();
+        // stop test: score_maps.max() < 0.01
+        float gm = -INFINITY;
+        for (int n = tid; n < N; n += 1024) gm = fmaxf(gm, imax[n]);
+        sv[tid] = gm;
+        __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) {
+            if (tid < o) sv[tid] = fmaxf(sv[tid], sv[tid + o]);
+            __syncthreads();
+        }
+        if (tid == 0) s_stop = sv[0] < 0.01f ? 1 : 0;
+        __syncthreads();
+        if (s_stop) break;
+    }
+    if (tid == 0) count[0] = npicks;
+}
+
+}  // namespace
+
+#define DW_ARGS_OK (x_ && y_ && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && OH > 0 && OW > 0 && stride >= 1 && dil >= 1)
+
+extern "C" int dass_dwconv3x3_fwd(const void *x, int64_t ldx, const float *w, void *y, int64_t ldy, int N, int H,
+                                  int W, int C, int OH, int OW, int stride, int pad, int dil, int dtype, void *stream) {
+    const void *x_ = x;
+    const void *y_ = y;
+    if (!DW_ARGS_OK || !w || ldx % 4 || ldy % 4) return DASS_ERR_ARG;
+    const int grid = dass_grid_1d((long)N * OH * OW * (C / 4), 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DASS_F32)
+        hipLaunchKernelGGL(dw_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, ldx, w, (float *)y, ldy, N, H, W, C, OH, OW, stride, pad, dil);
+    else if (dtype == DASS_BF16)
+        hipLaunchKernelGGL(dw_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)x, ldx, w, (bf16_t *)y, ldy, N, H, W, C, OH, OW, stride, pad, dil);
+    else
+        return DASS_ERR_UNSUPPORTED;
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_dwconv3x3_bwd_data(const void *dy, int64_t lddy, const float *w, void *dx, int64_t lddx, int N,
+                                       int H, int W, int C, int OH, int OW, int stride, int pad, int dil, int dtype,
+                                       void *stream) {
+    const void *x_ = dy;
+    const void *y_ = dx;
+    if (!DW_ARGS_OK || !w || lddx % 4 || lddy % 4) return DASS_ERR_ARG;
+    const int grid = dass_grid_1d((long)N * H * W * (C / 4), 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DASS_F32)
+        hipLaunchKernelGGL(dw_bwd_data_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)dy, lddy, w, (float *)dx, lddx, N, H, W, C, OH, OW, stride, pad, dil);
+    else if (dtype == DASS_BF16)
+        hipLaunchKernelGGL(dw_bwd_data_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)dy, lddy, w, (bf16_t *)dx, lddx, N, H, W, C, OH, OW, stride, pad, dil);
+    else
+        return DASS_ERR_UNSUPPORTED;
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_dwconv3x3_bwd_weight(const void *x, int64_t ldx, const void *dy, int64_t lddy, float *dw, int N,
+                                         int H, int W, int C, int OH, int OW, int stride, int pad, int dil, int dtype,
+                                         void *stream) {
+    const void *x_ = x;
+    const void *y_ = dy;
+    if (!DW_ARGS_OK || !dw) return DASS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)C * 9, st) != hipSuccess) return DASS_ERR_LAUNCH;
+    const long M = (long)N * OH * OW;
+    const int cblocks = (C + 63) / 64;
+    long slabs = (1024 + cblocks - 1) / cblocks;
+    const long maxslabs = (M + 255) / 256;
+    if (slabs > maxslabs) slabs = maxslabs;
+    if (slabs < 1) slabs = 1;
+    const long ppb = (M + slabs - 1) / slabs;
+    slabs = (M + ppb - 1) / ppb;
+    dim3 grid(cblocks, (unsigned)slabs);
+    if (dtype == DASS_F32)
+        hipLaunchKernelGGL(dw_bwd_weight_kernel<float>, grid, dim3(256), 0, st, (const float *)x, ldx, (const float *)dy, lddy, dw, N, H, W, C, OH, OW, stride, pad, dil, ppb);
+    else if (dtype == DASS_BF16)
+        hipLaunchKernelGGL(dw_bwd_weight_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)x, ldx, (const bf16_t *)dy, lddy, dw, N, H, W, C, OH, OW, stride, pad, dil, ppb);
+    else
+        return DASS_ERR_UNSUPPORTED;
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_box_sum(const float *maps, float *out, float *tmp, int N, int H, int W, int r, void *stream) {
+    if (!maps || !out || !tmp || N <= 0 || r <= 0 || r > H || r > W) return DASS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(box_rows_kernel, dim3(dass_grid_1d((long)N * H * (W - r + 1), 256)), dim3(256), 0, st, maps, tmp, N, H, W, r);
+    DASS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(box_cols_kernel, dim3(dass_grid_1d((long)N * (H - r + 1) * (W - r + 1), 256)), dim3(256), 0, st, tmp, out, N, H, W, r);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_zero_rect(float *maps, int n, int H, int W, int r0, int r1, int c0, int c1, void *stream) {
+    if (!maps || n < 0 || r0 < 0 || c0 < 0 || r1 > H || c1 > W) return DASS_ERR_ARG;
+    if (r1 <= r0 || c1 <= c0) return DASS_OK;
+    hipLaunchKernelGGL(zero_rect_kernel, dim3(dass_grid_1d((long)(r1 - r0) * (c1 - c0), 256)), dim3(256), 0,
+                       (hipStream_t)stream, maps, (long)n * H * W, W, r0, r1, c0, c1);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_minmax_blocks(int64_t n) {
+    int64_t g = (n + 255) / 256;
+    if (g > 1024) g = 1024;
+    return (int)(g < 1 ? 1 : g);
+}
+
+extern "C" int dass_minmax(const float *v, int64_t n, float *partial, float *out_min_max, void *stream) {
+    if (!v || !partial || !out_min_max || n <= 0) return DASS_ERR_ARG;
+    const int blocks = dass_minmax_blocks(n);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(minmax_stage1_kernel, dim3(blocks), dim3(256), 0, st, v, (long)n, partial);
+    DASS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(minmax_stage2_kernel, dim3(1), dim3(256), 0, st, partial, blocks, out_min_max);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_affine_inplace(float *v, int64_t n, const float *min_max, void *stream) {
+    if (!v || !min_max || n <= 0) return DASS_ERR_ARG;
+    hipLaunchKernelGGL(affine_kernel, dim3(dass_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, v, (long)n, min_max);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_square_nms(float *maps, int N, int H, int W, int region, int max_picks, float *imax, int *iarg,
+                               int *picks, int *count, void *stream) {
+    if (!maps || !imax || !iarg || !picks || !count || N <= 0 || H <= 0 || W <= 0 || region <= 0 || max_picks <= 0)
+        return DASS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(image_argmax_kernel, dim3(N), dim3(256), 0, st, maps, (long)H * W, imax, iarg);
+    DASS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(square_nms_kernel, dim3(1), dim3(1024), 0, st, maps, N, H, W, region, max_picks, imax, iarg,
+                       picks, count);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}

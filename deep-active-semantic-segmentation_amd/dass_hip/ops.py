@@ -1,0 +1,871 @@
+"""Host side of the HIP hot path: torch tensors in, libdass_hip launches on torch's current stream.
+
+PyTorch is plumbing here (device memory, streams, autograd bookkeeping); every arithmetic pass over an
+activation is a libdass_hip kernel.  Activations are 4-D torch tensors with NCHW *shape* and NHWC
+*memory* (channels_last), in the compute dtype selected by set_compute_dtype().
+
+The autograd Functions mirror what F.conv2d / F.batch_norm / F.relu / F.interpolate / F.max_pool2d /
+F.cross_entropy do at the reference's call sites (cited on each class).
+"""
+import ctypes
+import math
+
+import torch
+
+from ._lib import check, lib
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
+
+_state = {"dtype": torch.float32}
+
+
+def set_compute_dtype(dtype):
+    """torch.float32 = parity mode (exact f32 MFMA); torch.bfloat16 = bf16 storage, f32 accumulate."""
+    assert dtype in (torch.float32, torch.bfloat16)
+    _state["dtype"] = dtype
+
+
+def compute_dtype():
+    return _state["dtype"]
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError("dass_hip: unsupported dtype %s" % t.dtype)
+
+
+def _epv(dtype):
+    return 4 if dtype == torch.float32 else 8
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_cuda(t):
+    if not t.is_cuda:
+        raise RuntimeError("dass_hip ops run on the GPU only (tensor is on %s); there is no CPU fallback" % t.device)
+
+
+# ----------------------------------------------------------------------------- layout helpers
+def new_act(n, c, h, w, dtype, device):
+    """NCHW-shaped tensor backed by NHWC memory."""
+    return torch.empty((n, h, w, c), dtype=dtype, device=device).permute(0, 3, 1, 2)
+
+
+def zeros_act(n, c, h, w, dtype, device):
+    return torch.zeros((n, h, w, c), dtype=dtype, device=device).permute(0, 3, 1, 2)
+
+
+def rows(x):
+    """-> (tensor, ld): x as NHWC pixel rows with pixel stride ld (a channel slice of a wider
+    NHWC buffer is accepted as is); anything else is re-laid out once."""
+    n, c, h, w = x.shape
+    sn, sc, sh, sw = x.stride()
+    ld = sw if w > 1 else (sh // max(w, 1) if h > 1 else (sn // max(h * w, 1) if n > 1 else c))
+    ok = (sc == 1 or c == 1) and ld >= c
+    ok = ok and (w == 1 or sw == ld) and (h == 1 or sh == w * ld) and (n == 1 or sn == h * w * ld)
+    if not ok or ld % 4 != 0 and ld != c:
+        x = x.contiguous(memory_format=torch.channels_last)
+        if x.stride(1) != 1:  # degenerate shapes: force explicit NHWC storage
+            x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        ld = c
+    return x, ld
+
+
+def _cast_act(x):
+    """bring an incoming activation to the compute dtype (torch cast = boundary plumbing only)."""
+    dt = compute_dtype()
+    return x if x.dtype == dt else x.to(dt)
+
+
+# ----------------------------------------------------------------------------- raw launches
+def conv_launch(x, ldx, w_op, y, ldy, dims, scale=None, shift=None, residual=None, ldr=0, in_scale=None,
+                act=ACT_NONE, ustride=1):
+    n, h, w, c, oh, ow, k, r, s, stride, pad, dil = dims
+    check(lib.dass_conv2d_igemm(_p(x), ldx, _p(w_op), _p(y), ldy, _p(scale), _p(shift), _p(residual), ldr,
+                                _p(in_scale), n, h, w, c, oh, ow, k, r, s, stride, pad, dil, ustride, act,
+                                _dt(y), _stream()), "dass_conv2d_igemm")
+
+
+def channel_stats(x, ld, m, k):
+    nrows = lib.dass_stat_rows(m)
+    partial = torch.empty((nrows, 2, k), dtype=torch.float32, device=x.device)
+    check(lib.dass_channel_stats(_p(x), ld, m, k, _p(partial), _dt(x), _stream()), "dass_channel_stats")
+    return partial, nrows
+
+
+class BNState(object):
+    """mean / invstd / scale / shift vectors of one BN application (f32, device)."""
+
+    def __init__(self, k, device):
+        buf = torch.empty((4, k), dtype=torch.float32, device=device)
+        self.mean, self.invstd, self.scale, self.shift = buf[0], buf[1], buf[2], buf[3]
+
+
+def bn_train_state(x, ld, m, k, bn, rep=1.0):
+    partial, nrows = channel_stats(x, ld, m, k)
+    st = BNState(k, x.device)
+    mom = -1.0
+    rm = rv = None
+    if bn.track_running_stats and bn.running_mean is not None:
+        mom = 0.1 if bn.momentum is None else float(bn.momentum)
+        rm, rv = bn.running_mean, bn.running_var
+        bn.num_batches_tracked.add_(1)
+    check(lib.dass_bn_finalize(_p(partial), nrows, k, float(m) * rep, float(rep), _p(bn.weight), _p(bn.bias), _p(rm),
+                               _p(rv), mom, float(bn.eps), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
+                               _stream()), "dass_bn_finalize")
+    return st
+
+
+def bn_eval_state(bn, k, device):
+    st = BNState(k, device)
+    check(lib.dass_bn_eval_scale_shift(_p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var),
+                                       float(bn.eps), k, _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
+                                       _stream()), "dass_bn_eval_scale_shift")
+    return st
+
+
+def scale_shift_act(x, ldx, out, ldo, m, k, scale, shift, residual=None, ldr=0, nc_scale=None, rows_per_image=1,
+                    act=ACT_NONE):
+    check(lib.dass_scale_shift_act(_p(x), ldx, _p(out), ldo, _p(scale), _p(shift), _p(residual), ldr, _p(nc_scale),
+                                   m, k, rows_per_image, act, _dt(out), _stream()), "dass_scale_shift_act")
+
+
+def bn_use_batch_stats(bn):
+    return bn.training or (bn.running_mean is None)
+
+
+# ----------------------------------------------------------------------------- weight operands
+_wcache = {}
+
+
+def _krsc_master(weight):
+    """f32 KRSC view of an OIHW parameter (zero-copy when the parameter is channels_last)."""
+    w = weight.detach()
+    if w.dtype != torch.float32:
+        w = w.float()
+    wp = w.permute(0, 2, 3, 1)
+    if not wp.is_contiguous():
+        wp = wp.contiguous()
+    return wp
+
+
+def weight_operand(weight, mode, dtype, cpad=None):
+    """mode 0: [K][R][S][Cpad] forward operand; mode 1: [C][R][S][K] flipped dgrad operand.
+    Cached on (storage, version) so eval / MC passes transform once."""
+    k, c, r, s = weight.shape
+    cdst = c if cpad is None else cpad
+    key = (weight.data_ptr(), weight._version, mode, dtype, cdst, tuple(weight.shape))
+    hit = _wcache.get((id(weight), mode))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    master = _krsc_master(weight)
+    if mode == 0 and dtype == torch.float32 and cdst == c:
+        op = master
+    else:
+        if mode == 0:
+            op = torch.empty((k, r, s, cdst), dtype=dtype, device=weight.device)
+        else:
+            op = torch.empty((c, r, s, k), dtype=dtype, device=weight.device)
+        check(lib.dass_weight_transform(_p(master), _p(op), k, r, s, c, cdst, mode, F32 if dtype == torch.float32 else BF16,
+                                        _stream()), "dass_weight_transform")
+    _wcache[(id(weight), mode)] = (key, op, weight)
+    return op
+
+
+def _pad_to(v, m):
+    return (v + m - 1) // m * m
+
+
+def conv_out_size(h, k, stride, pad, dil):
+    return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+# ----------------------------------------------------------------------------- fused conv + BN + act
+class ConvSpec(object):
+    """static description of one conv (+BN +act) site."""
+
+    def __init__(self, conv, bn=None, act=ACT_NONE, extra_pad=0):
+        self.conv, self.bn, self.act = conv, bn, act
+        self.stride = conv.stride[0]
+        self.dil = conv.dilation[0]
+        self.pad = conv.padding[0] + extra_pad
+        self.depthwise = conv.groups > 1
+        if self.depthwise:
+            assert conv.groups == conv.in_channels == conv.out_channels and conv.kernel_size == (3, 3)
+        else:
+            assert conv.groups == 1
+
+
+def _dw_weight(weight):
+    w = weight.detach()
+    return w.reshape(w.shape[0], 9).contiguous().float()
+
+
+def _conv_forward_raw(spec, x, ldx, n, h, w, c, weight, y, ldy, oh, ow, **epi):
+    k = weight.shape[0]
+    if spec.depthwise:
+        assert not epi
+        check(lib.dass_dwconv3x3_fwd(_p(x), ldx, _p(_dw_weight(weight)), _p(y), ldy, n, h, w, c, oh, ow, spec.stride,
+                                     spec.pad, spec.dil, _dt(y), _stream()), "dass_dwconv3x3_fwd")
+    else:
+        r, s = weight.shape[2], weight.shape[3]
+        w_op = weight_operand(weight, 0, y.dtype, cpad=c)
+        conv_launch(x, ldx, w_op, y, ldy, (n, h, w, c, oh, ow, k, r, s, spec.stride, spec.pad, spec.dil), **epi)
+
+
+class _ConvBnAct(torch.autograd.Function):
+    """conv (groups=1 or depthwise 3x3) -> [BatchNorm2d] -> [ReLU|ReLU6] with optional bias, residual
+    add before the activation (resnet.py:42-43) and Dropout2d channel mask after it (aspp.py:89).
+    x may be the NCHW f32 network input (stem): it is re-laid out to NHWC (C padded) on the fly."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, bias, residual, nc_scale, spec, image_input):
+        _require_cuda(x)
+        dt = compute_dtype()
+        dev = x.device
+        n, c_in, h, w = x.shape
+        k = weight.shape[0]
+        r = weight.shape[2]
+        if image_input:
+            c = _pad_to(c_in, _epv(dt))
+            xr = torch.empty((n, h, w, c), dtype=dt, device=dev)
+            xin = x.contiguous().float()
+            check(lib.dass_nchw_to_nhwc(_p(xin), _p(xr), n, c_in, h, w, c, _dt(xr), _stream()), "dass_nchw_to_nhwc")
+            ldx = c
+            xs = xr
+        else:
+            xs, ldx = rows(_cast_act(x))
+            c = c_in
+        oh = conv_out_size(h, r, spec.stride, spec.pad, spec.dil)
+        ow = conv_out_size(w, weight.shape[3], spec.stride, spec.pad, spec.dil)
+        m = n * oh * ow
+        bn = spec.bn
+        need_grad = torch.is_grad_enabled() and any(
+            t is not None and t.requires_grad for t in (x, weight, gamma, beta, bias, residual))
+        res_t = ldr = None
+        if residual is not None:
+            res_t, ldr = rows(_cast_act(residual))
+        kpad = _pad_to(k, 4)
+        if kpad != k:  # e.g. the 19-class classifier: keep a zero pad column so rows stay 16-B aligned
+            out = zeros_act(n, kpad, oh, ow, dt, dev)[:, :k]
+        else:
+            out = new_act(n, k, oh, ow, dt, dev)
+        ldo = kpad
+        state = None
+        y_raw = None
+        batch_stats = bn is not None and bn_use_batch_stats(bn)
+        fuse = (not spec.depthwise) and (bn is None or (not batch_stats and not need_grad))
+        if fuse:
+            scale = shift = None
+            if bn is not None:
+                state = bn_eval_state(bn, k, dev)
+                scale, shift = state.scale, state.shift
+            elif bias is not None:
+                shift = bias.detach().float()
+            _conv_forward_raw(spec, xs, ldx, n, h, w, c, weight, out, ldo, oh, ow, scale=scale, shift=shift,
+                              residual=res_t, ldr=ldr or 0, act=spec.act)
+            if nc_scale is not None:
+                scale_shift_act(out, ldo, out, ldo, m, k, None, None, nc_scale=nc_scale, rows_per_image=oh * ow)
+        else:
+            assert k % 4 == 0, "BN epilogue needs K % 4 == 0"
+            y_raw = new_act(n, k, oh, ow, dt, dev)
+            _conv_forward_raw(spec, xs, ldx, n, h, w, c, weight, y_raw, k, oh, ow)
+            if bn is not None:
+                state = bn_train_state(y_raw, k, m, k, bn) if batch_stats else bn_eval_state(bn, k, dev)
+                scale, shift = state.scale, state.shift
+            else:
+                scale, shift = None, (bias.detach().float() if bias is not None else None)
+            scale_shift_act(y_raw, k, out, ldo, m, k, scale, shift, residual=res_t, ldr=ldr or 0,
+                            nc_scale=nc_scale, rows_per_image=oh * ow, act=spec.act)
+        if need_grad:
+            ctx.spec = spec
+            ctx.image_input = image_input
+            ctx.dims = (n, h, w, c, oh, ow, k, ldx, ldo, c_in)
+            ctx.train_stats = batch_stats
+            ctx.has_bn = bn is not None
+            ctx.has_bias = bias is not None
+            ctx.has_res = residual is not None
+            ctx.x_dtype = x.dtype
+            ctx.save_for_backward(xs, weight, gamma, y_raw, out, nc_scale,
+                                  state.mean if state is not None else None,
+                                  state.invstd if state is not None else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xs, weight, gamma, y_raw, out, nc_scale, mean, invstd = ctx.saved_tensors
+        spec = ctx.spec
+        n, h, w, c, oh, ow, k, ldx, ldo, c_in = ctx.dims
+        dt = out.dtype
+        dev = out.device
+        m = n * oh * ow
+        dout_r, lddo = rows(_cast_act(dout))
+        dgamma = dbeta = dbias = dres = None
+        simple = (not ctx.has_bn) and spec.act == ACT_NONE and nc_scale is None and not ctx.has_res
+        kp = _pad_to(k, 4)
+        if simple:
+            # conv (+bias): dy = dout.  (K may be unaligned: work on a zero-padded copy of width kp)
+            if lddo % 4 != 0 or kp != k:
+                dy = zeros_act(n, kp, oh, ow, dt, dev)
+                dy[:, :k].copy_(dout_r)
+                lddy = kp
+            else:
+                dy, lddy = dout_r, lddo
+            if ctx.has_bias:
+                partial = torch.empty((lib.dass_stat_rows(m), 2, kp), dtype=torch.float32, device=dev)
+                dbias_p = torch.empty((kp,), dtype=torch.float32, device=dev)
+                check(lib.dass_colsum(_p(dy), lddy, m, kp, _p(partial), _p(dbias_p), _dt(dy), _stream()), "dass_colsum")
+                dbias = dbias_p[:k]
+        else:
+            assert k % 4 == 0
+            dy = new_act(n, k, oh, ow, dt, dev)
+            lddy = k
+            if ctx.has_res:
+                dres = new_act(n, k, oh, ow, dt, dev)
+            src = y_raw if y_raw is not None else out
+            ones = None
+            if not ctx.has_bn:
+                ones = torch.ones((k,), dtype=torch.float32, device=dev)
+                mean_v, invstd_v, gamma_v = torch.zeros_like(ones), ones, None
+            else:
+                mean_v, invstd_v, gamma_v = mean, invstd, gamma
+            db = dg = None
+            need_red = ctx.has_bn or ctx.has_bias
+            if need_red:
+                nrows = lib.dass_stat_rows(m)
+                partial = torch.empty((nrows, 2, k), dtype=torch.float32, device=dev)
+                check(lib.dass_bn_bwd_reduce(_p(dout_r), lddo, _p(out), ldo, _p(src), k, _p(mean_v), _p(invstd_v),
+                                             _p(nc_scale), m, k, oh * ow, spec.act, _p(partial), _dt(out), _stream()),
+                      "dass_bn_bwd_reduce")
+                sums = torch.empty((2, k), dtype=torch.float32, device=dev)
+                db, dg = sums[0], sums[1]
+                check(lib.dass_bn_bwd_finalize(_p(partial), nrows, k, _p(db), _p(dg), _stream()), "dass_bn_bwd_finalize")
+                if ctx.has_bn:
+                    dbeta, dgamma = db, dg
+                else:
+                    dbias = db
+            check(lib.dass_bn_bwd_apply(_p(dout_r), lddo, _p(out), ldo, _p(src), k, _p(mean_v), _p(invstd_v),
+                                        _p(gamma_v.detach() if gamma_v is not None else None), _p(db), _p(dg),
+                                        _p(nc_scale), _p(dy), lddy, _p(dres), k, m, k, oh * ow, float(m),
+                                        1 if ctx.train_stats else 0, spec.act, _dt(out), _stream()), "dass_bn_bwd_apply")
+        # ---- conv backward
+        dx = dw = None
+        kk = kp if simple else k
+        if spec.depthwise:
+            wdw = _dw_weight(weight)
+            if ctx.needs_input_grad[0]:
+                dx = new_act(n, c, h, w, dt, dev)
+                check(lib.dass_dwconv3x3_bwd_data(_p(dy), lddy, _p(wdw), _p(dx), c, n, h, w, c, oh, ow, spec.stride,
+                                                  spec.pad, spec.dil, _dt(dx), _stream()), "dass_dwconv3x3_bwd_data")
+            if ctx.needs_input_grad[1]:
+                dwf = torch.empty((c, 9), dtype=torch.float32, device=dev)
+                check(lib.dass_dwconv3x3_bwd_weight(_p(xs), ldx, _p(dy), lddy, _p(dwf), n, h, w, c, oh, ow,
+                                                    spec.stride, spec.pad, spec.dil, _dt(dy), _stream()),
+                      "dass_dwconv3x3_bwd_weight")
+                dw = dwf.view(c, 1, 3, 3)
+        else:
+            r, s = weight.shape[2], weight.shape[3]
+            wsrc = weight
+            if kk != k:  # zero-pad the out-channel axis of the master weight (classifier: 19 -> 20)
+                wsrc = torch.zeros((kk, weight.shape[1], r, s), dtype=torch.float32, device=dev)
+                wsrc[:k].copy_(weight.detach())
+            if ctx.needs_input_grad[0] and not ctx.image_input:
+                w_t = weight_operand(wsrc, 1, dt) if wsrc is weight else _dgrad_operand_uncached(wsrc, dt)
+                dx = new_act(n, c, h, w, dt, dev)
+                pad_t = spec.dil * (r - 1) - spec.pad
+                # dgrad = stride-1 conv over dy with flipped/transposed taps; ustride re-inserts the stride
+                check(lib.dass_conv2d_igemm(_p(dy), lddy, _p(w_t), _p(dx), c, None, None, None, 0, None, n, oh, ow,
+                                            kk, h, w, c, r, s, 1, pad_t, spec.dil, spec.stride, ACT_NONE, _dt(dx),
+                                            _stream()), "dass_conv2d_igemm(dgrad)")
+            if ctx.needs_input_grad[1]:
+                dwk = torch.empty((kk, r, s, c), dtype=torch.float32, device=dev)
+                check(lib.dass_conv2d_wgrad(_p(xs), ldx, _p(dy), lddy, _p(dwk), n, h, w, c, oh, ow, kk, r, s,
+                                            spec.stride, spec.pad, spec.dil, _dt(dy), _stream()), "dass_conv2d_wgrad")
+                dw = dwk[:k, :, :, :c_in].permute(0, 3, 1, 2)
+                if kk != k or c != c_in:
+                    dw = dw.contiguous(memory_format=torch.channels_last)
+        if dx is not None and ctx.x_dtype != dx.dtype:
+            dx = dx.to(ctx.x_dtype)
+        return dx, dw, dgamma, dbeta, dbias, dres, None, None, None
+
+
+def _dgrad_operand_uncached(wsrc, dtype):
+    k, c, r, s = wsrc.shape
+    master = _krsc_master(wsrc)
+    op = torch.empty((c, r, s, k), dtype=dtype, device=wsrc.device)
+    check(lib.dass_weight_transform(_p(master), _p(op), k, r, s, c, c, 1, F32 if dtype == torch.float32 else BF16,
+                                    _stream()), "dass_weight_transform")
+    return op
+
+
+def conv_bn_act(x, conv, bn=None, act=ACT_NONE, residual=None, nc_scale=None, extra_pad=0, image_input=False):
+    spec = ConvSpec(conv, bn, act, extra_pad)
+    gamma = bn.weight if bn is not None else None
+    beta = bn.bias if bn is not None else None
+    return _ConvBnAct.apply(x, conv.weight, gamma, beta, conv.bias, residual, nc_scale, spec, image_input)
+
+
+# ----------------------------------------------------------------------------- max pool (resnet.py:68)
+class _MaxPool3x3s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        xs, ld = rows(_cast_act(x))
+        n, c, h, w = xs.shape
+        if ld != c:
+            xs = xs.contiguous(memory_format=torch.channels_last)
+        oh, ow = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+        y = new_act(n, c, oh, ow, xs.dtype, xs.device)
+        need = torch.is_grad_enabled() and x.requires_grad
+        idx = torch.empty((n, oh, ow, c), dtype=torch.uint8, device=xs.device) if need else None
+        check(lib.dass_maxpool3x3s2_fwd(_p(xs), _p(y), _p(idx), n, h, w, c, oh, ow, _dt(y), _stream()),
+              "dass_maxpool3x3s2_fwd")
+        if need:
+            ctx.save_for_backward(idx)
+            ctx.dims = (n, c, h, w, oh, ow)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        n, c, h, w, oh, ow = ctx.dims
+        dyr, ld = rows(_cast_act(dy))
+        if ld != c:
+            dyr = dyr.contiguous(memory_format=torch.channels_last)
+        dx = new_act(n, c, h, w, dyr.dtype, dyr.device)
+        check(lib.dass_maxpool3x3s2_bwd(_p(dyr), _p(idx), _p(dx), n, h, w, c, oh, ow, _dt(dx), _stream()),
+              "dass_maxpool3x3s2_bwd")
+        return dx
+
+
+def maxpool3x3s2(x):
+    return _MaxPool3x3s2.apply(x)
+
+
+# ----------------------------------------------------------------------------- residual add without BN (mobilenet.py:74)
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ar, lda = rows(_cast_act(a))
+        br, ldb = rows(_cast_act(b))
+        n, c, h, w = ar.shape
+        out = new_act(n, c, h, w, ar.dtype, ar.device)
+        m = n * h * w
+        check(lib.dass_copy_channels(_p(ar), lda, _p(out), c, m, c, _dt(out), _stream()), "dass_copy_channels")
+        check(lib.dass_add_channels(_p(br), ldb, _p(out), c, m, c, _dt(out), _stream()), "dass_add_channels")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+# ----------------------------------------------------------------------------- concat (aspp.py:83)
+class _Concat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [rows(_cast_act(x)) for x in xs]
+        n, _, h, w = xs[0][0].shape
+        cs = [x.shape[1] for x, _ in xs]
+        ct = sum(cs)
+        out = new_act(n, ct, h, w, xs[0][0].dtype, xs[0][0].device)
+        m = n * h * w
+        off = 0
+        for (x, ld), c in zip(xs, cs):
+            dst = out[:, off:off + c]
+            check(lib.dass_copy_channels(_p(x), ld, _p(dst), ct, m, c, _dt(out), _stream()), "dass_copy_channels")
+            off += c
+        ctx.cs = cs
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs = []
+        off = 0
+        for c in ctx.cs:
+            outs.append(g[:, off:off + c])  # channel-slice views; consumers read them with ld = C_total
+            off += c
+        return tuple(outs)
+
+
+def concat(*xs):
+    return _Concat.apply(*xs)
+
+
+# ----------------------------------------------------------------------------- ASPP image-pool branch (aspp.py:62-65,79-81)
+class _GlobalAvgPool(torch.autograd.Function):
+    """AdaptiveAvgPool2d((1,1)) -> [N,C,1,1]"""
+
+    @staticmethod
+    def forward(ctx, x):
+        xs, ld = rows(_cast_act(x))
+        n, c, h, w = xs.shape
+        y = new_act(n, c, 1, 1, xs.dtype, xs.device)
+        check(lib.dass_global_avgpool_fwd(_p(xs), ld, _p(y), n, h * w, c, _dt(y), _stream()), "dass_global_avgpool_fwd")
+        ctx.dims = (n, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, c, h, w = ctx.dims
+        gr, _ = rows(_cast_act(g))
+        gr = gr.reshape(n, c).contiguous()
+        dx = new_act(n, c, h, w, gr.dtype, gr.device)
+        check(lib.dass_broadcast_rows(_p(gr), _p(dx), c, n, h * w, c, 1.0 / (h * w), _dt(dx), _stream()),
+              "dass_broadcast_rows")
+        return dx
+
+
+def global_avgpool(x):
+    return _GlobalAvgPool.apply(x)
+
+
+class _BroadcastBN(torch.autograd.Function):
+    """bilinear 1x1 -> HxW (a broadcast) followed by BatchNorm2d over the broadcast map.
+    Batch statistics over N*H*W copies equal statistics over N rows with count N*H*W (only the
+    unbiased running_var correction sees H*W), so BN runs on the [N,C] vector and is broadcast."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, h, w):
+        xs, _ = rows(_cast_act(x))
+        n, c = xs.shape[0], xs.shape[1]
+        xv = xs.reshape(n, c).contiguous()
+        if bn_use_batch_stats(bn):
+            st = bn_train_state(xv, c, n, c, bn, rep=float(h * w))
+        else:
+            st = bn_eval_state(bn, c, xv.device)
+        yv = torch.empty_like(xv)
+        scale_shift_act(xv, c, yv, c, n, c, st.scale, st.shift)
+        out = new_act(n, c, h, w, xv.dtype, xv.device)
+        check(lib.dass_broadcast_rows(_p(yv), _p(out), c, n, h * w, c, 1.0, _dt(out), _stream()), "dass_broadcast_rows")
+        ctx.save_for_backward(xv, yv, gamma, st.mean, st.invstd)
+        ctx.dims = (n, c, h, w)
+        ctx.train_stats = bn_use_batch_stats(bn)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xv, yv, gamma, mean, invstd = ctx.saved_tensors
+        n, c, h, w = ctx.dims
+        gr, ldg = rows(_cast_act(g))
+        gs = torch.empty((n, c), dtype=gr.dtype, device=gr.device)
+        check(lib.dass_reduce_rows(_p(gr), ldg, _p(gs), n, h * w, c, _dt(gs), _stream()), "dass_reduce_rows")
+        nrows = lib.dass_stat_rows(n)
+        partial = torch.empty((nrows, 2, c), dtype=torch.float32, device=gr.device)
+        check(lib.dass_bn_bwd_reduce(_p(gs), c, _p(yv), c, _p(xv), c, _p(mean), _p(invstd), None, n, c, 1, ACT_NONE,
+                                     _p(partial), _dt(gs), _stream()), "dass_bn_bwd_reduce")
+        sums = torch.empty((2, c), dtype=torch.float32, device=gr.device)
+        check(lib.dass_bn_bwd_finalize(_p(partial), nrows, c, _p(sums[0]), _p(sums[1]), _stream()), "dass_bn_bwd_finalize")
+        dx = torch.empty((n, c), dtype=gs.dtype, device=gs.device)
+        check(lib.dass_bn_bwd_apply(_p(gs), c, _p(yv), c, _p(xv), c, _p(mean), _p(invstd), _p(gamma.detach()),
+                                    _p(sums[0]), _p(sums[1]), None, _p(dx), c, None, 0, n, c, 1, float(n),
+                                    1 if ctx.train_stats else 0, ACT_NONE, _dt(dx), _stream()), "dass_bn_bwd_apply")
+        return dx.view(n, 1, 1, c).permute(0, 3, 1, 2), sums[1], sums[0], None, None, None
+
+
+def broadcast_bn(x, bn, h, w):
+    return _BroadcastBN.apply(x, bn.weight, bn.bias, bn, h, w)
+
+
+# ----------------------------------------------------------------------------- bilinear (align_corners=True)
+class _UpsampleCat(torch.autograd.Function):
+    """F.interpolate(x, low.size()[2:], bilinear, align_corners=True); torch.cat((x, low), 1)
+    (decoder.py:45-46): the resampled rows are written straight into the 304-channel buffer."""
+
+    @staticmethod
+    def forward(ctx, x, low):
+        xs, ldx = rows(_cast_act(x))
+        ls, ldl = rows(_cast_act(low))
+        n, c, ih, iw = xs.shape
+        _, cl, oh, ow = ls.shape
+        ct = c + cl
+        out = new_act(n, ct, oh, ow, xs.dtype, xs.device)
+        check(lib.dass_bilinear_fwd(_p(xs), ldx, _p(out), ct, n, ih, iw, c, oh, ow, 0, _dt(out), _stream()),
+              "dass_bilinear_fwd")
+        check(lib.dass_copy_channels(_p(ls), ldl, _p(out[:, c:]), ct, n * oh * ow, cl, _dt(out), _stream()),
+              "dass_copy_channels")
+        ctx.dims = (n, c, ih, iw, cl, oh, ow)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n, c, ih, iw, cl, oh, ow = ctx.dims
+        gr, ldg = rows(_cast_act(g))
+        dx = new_act(n, c, ih, iw, gr.dtype, gr.device)
+        check(lib.dass_bilinear_bwd(_p(gr), ldg, _p(dx), c, n, ih, iw, c, oh, ow, 0, _dt(dx), _stream()),
+              "dass_bilinear_bwd")
+        return dx, gr[:, c:]
+
+
+def upsample_cat(x, low):
+    return _UpsampleCat.apply(x, low)
+
+
+class _UpsampleToNCHW(torch.autograd.Function):
+    """final F.interpolate(low_res_logits, size=input HW, bilinear, align_corners=True) (deeplab.py:59):
+    NHWC low-res logits in, NCHW f32 logits out (what the reference returns)."""
+
+    @staticmethod
+    def forward(ctx, x, oh, ow):
+        xs, ldx = rows(_cast_act(x))
+        n, c, ih, iw = xs.shape
+        y = torch.empty((n, c, oh, ow), dtype=torch.float32, device=xs.device)
+        check(lib.dass_bilinear_fwd(_p(xs), ldx, _p(y), 0, n, ih, iw, c, oh, ow, 1, _dt(xs), _stream()),
+              "dass_bilinear_fwd")
+        ctx.dims = (n, c, ih, iw, oh, ow)
+        ctx.dt = xs.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, c, ih, iw, oh, ow = ctx.dims
+        g = g.contiguous().float()
+        cp = _pad_to(c, 4)
+        dx = zeros_act(n, cp, ih, iw, ctx.dt, g.device) if cp != c else new_act(n, c, ih, iw, ctx.dt, g.device)
+        check(lib.dass_bilinear_bwd(_p(g), 0, _p(dx), cp, n, ih, iw, c, oh, ow, 1, _dt(dx), _stream()),
+              "dass_bilinear_bwd")
+        return dx[:, :c], None, None
+
+
+def upsample_to_nchw(x, oh, ow):
+    return _UpsampleToNCHW.apply(x, oh, ow)
+
+
+class _Upsample(torch.autograd.Function):
+    """generic NHWC -> NHWC bilinear align_corners resample"""
+
+    @staticmethod
+    def forward(ctx, x, oh, ow):
+        xs, ldx = rows(_cast_act(x))
+        n, c, ih, iw = xs.shape
+        y = new_act(n, c, oh, ow, xs.dtype, xs.device)
+        check(lib.dass_bilinear_fwd(_p(xs), ldx, _p(y), c, n, ih, iw, c, oh, ow, 0, _dt(y), _stream()), "dass_bilinear_fwd")
+        ctx.dims = (n, c, ih, iw, oh, ow)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, c, ih, iw, oh, ow = ctx.dims
+        gr, ldg = rows(_cast_act(g))
+        dx = new_act(n, c, ih, iw, gr.dtype, gr.device)
+        check(lib.dass_bilinear_bwd(_p(gr), ldg, _p(dx), c, n, ih, iw, c, oh, ow, 0, _dt(dx), _stream()), "dass_bilinear_bwd")
+        return dx, None, None
+
+
+def upsample(x, oh, ow):
+    return _Upsample.apply(x, oh, ow)
+
+
+# ----------------------------------------------------------------------------- Dropout2d as a channel mask
+def dropout2d_mask(n, c, p, device, generator=None):
+    """[N,C] f32 multipliers {0, 1/(1-p)} -- the exact values nn.Dropout2d applies per (n,c) plane."""
+    keep = torch.rand((n, c), device=device, generator=generator) >= p
+    return keep.to(torch.float32) * (1.0 / (1.0 - p))
+
+
+class _ChannelScale(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask):
+        xs, ld = rows(_cast_act(x))
+        n, c, h, w = xs.shape
+        out = new_act(n, c, h, w, xs.dtype, xs.device)
+        scale_shift_act(xs, ld, out, c, n * h * w, c, None, None, nc_scale=mask, rows_per_image=h * w)
+        ctx.save_for_backward(mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        gr, ld = rows(_cast_act(g))
+        n, c, h, w = gr.shape
+        dx = new_act(n, c, h, w, gr.dtype, gr.device)
+        scale_shift_act(gr, ld, dx, c, n * h * w, c, None, None, nc_scale=mask, rows_per_image=h * w)
+        return dx, None
+
+
+def channel_scale(x, mask):
+    return _ChannelScale.apply(x, mask)
+
+
+# ----------------------------------------------------------------------------- cross entropy (utils/loss.py:39-51)
+class _CrossEntropy(torch.autograd.Function):
+    """nn.CrossEntropyLoss(weight, ignore_index, reduction='mean')(logit, target.long())"""
+
+    @staticmethod
+    def forward(ctx, logit, target, weight, ignore_index):
+        _require_cuda(logit)
+        lg = logit.contiguous().float()
+        n, c, h, w = lg.shape
+        tgt = target.contiguous()
+        is_float = 1 if tgt.dtype == torch.float32 else 0
+        if not is_float and tgt.dtype != torch.int64:
+            tgt = tgt.long()
+        wt = weight.contiguous().float() if weight is not None else None
+        hw = h * w
+        blocks = lib.dass_ce_blocks(n * hw)
+        partial = torch.empty((blocks, 2), dtype=torch.float32, device=lg.device)
+        acc = torch.empty((2,), dtype=torch.float32, device=lg.device)
+        check(lib.dass_ce_fwd(_p(lg), _p(tgt), is_float, _p(wt), n, c, hw, int(ignore_index), _p(partial), _stream()),
+              "dass_ce_fwd")
+        check(lib.dass_ce_finalize(_p(partial), blocks, _p(acc), _stream()), "dass_ce_finalize")
+        ctx.save_for_backward(lg, tgt, wt, acc)
+        ctx.meta = (n, c, hw, is_float, int(ignore_index))
+        return acc[0] / acc[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        lg, tgt, wt, acc = ctx.saved_tensors
+        n, c, hw, is_float, ignore = ctx.meta
+        gs = g.detach().float().reshape(1).contiguous()
+        d = torch.empty_like(lg)
+        check(lib.dass_ce_bwd(_p(lg), _p(tgt), is_float, _p(wt), n, c, hw, ignore, _p(acc), _p(gs), _p(d), _stream()),
+              "dass_ce_bwd")
+        return d, None, None, None
+
+
+def cross_entropy(logit, target, weight=None, ignore_index=255):
+    return _CrossEntropy.apply(logit, target, weight, ignore_index)
+
+
+# ----------------------------------------------------------------------------- scoring launches (no autograd)
+def upsample_argmax(low, oh, ow, votes, t):
+    """votes[:, t] = argmax_c bilinear(low)[.., c]  (votes: uint8 [N,T,OH,OW])"""
+    xs, ldx = rows(low)
+    n, c, ih, iw = xs.shape
+    tt = votes.shape[1]
+    dst = votes[:, t]
+    check(lib.dass_upsample_argmax(_p(xs), ldx, _p(dst), tt * oh * ow, n, ih, iw, c, oh, ow, _dt(xs), _stream()),
+          "dass_upsample_argmax")
+
+
+def argmax_nchw(logits, votes, t):
+    lg = logits.contiguous().float()
+    n, c, h, w = lg.shape
+    tt = votes.shape[1]
+    check(lib.dass_argmax_nchw(_p(lg), _p(votes[:, t]), tt * h * w, n, c, h * w, _stream()), "dass_argmax_nchw")
+
+
+def vote_entropy(votes, label, num_classes, want_map=True):
+    """-> (entropy_map [N,H,W] f32 or None, image_mean [N] f32) ; mc_dropout.py:43-49,189"""
+    n, t, h, w = votes.shape
+    dev = votes.device
+    lab = label.contiguous().float() if label is not None else None
+    emap = torch.empty((n, h, w), dtype=torch.float32, device=dev) if want_map else None
+    partial = torch.empty((n, lib.dass_score_blocks()), dtype=torch.float32, device=dev)
+    sums = torch.empty((n,), dtype=torch.float32, device=dev)
+    check(lib.dass_vote_entropy(_p(votes), _p(lab), n, t, h * w, num_classes, _p(emap), _p(partial), _p(sums), _stream()),
+          "dass_vote_entropy")
+    return emap, sums / float(h * w)
+
+
+def softmax_scores(logits, label, num_classes, mode, want_map=False):
+    lg = logits.contiguous().float()
+    n, c, h, w = lg.shape
+    dev = lg.device
+    lab = label.contiguous().float() if label is not None else None
+    smap = torch.empty((n, h, w), dtype=torch.float32, device=dev) if want_map else None
+    partial = torch.empty((n, lib.dass_score_blocks()), dtype=torch.float32, device=dev)
+    sums = torch.empty((n,), dtype=torch.float32, device=dev)
+    check(lib.dass_softmax_scores(_p(lg), _p(lab), n, c, h * w, num_classes, mode, _p(smap), _p(partial), _p(sums),
+                                  _stream()), "dass_softmax_scores")
+    return smap, sums / float(h * w)
+
+
+def weak_labels(logits, label, num_classes):
+    lg = logits.contiguous().float()
+    n, c, h, w = lg.shape
+    out = torch.empty((n, h, w), dtype=torch.uint8, device=lg.device)
+    check(lib.dass_weak_labels(_p(lg), _p(label.contiguous().float()), n, c, h * w, num_classes, _p(out), _stream()),
+          "dass_weak_labels")
+    return out
+
+
+def avgpool_features(feat, k, s):
+    """F.avg_pool2d(feat, k, s).flatten(1) with the reference's channel-major order (core_set.py:61-63)"""
+    xs, ld = rows(feat)
+    n, c, h, w = xs.shape
+    ph, pw = (h - k) // s + 1, (w - k) // s + 1
+    out = torch.empty((n, c * ph * pw), dtype=torch.float32, device=xs.device)
+    check(lib.dass_avgpool_features(_p(xs), ld, _p(out), n, h, w, c, k, s, ph, pw, _dt(xs), _stream()),
+          "dass_avgpool_features")
+    return out
+
+
+def kcenter_greedy(features, selected, count):
+    """k-center greedy (core_set.py:17-38) fully enqueued on the device: returns int64 [count] picks."""
+    feats = features.contiguous().float()
+    n, d = feats.shape
+    dev = feats.device
+    min_dist = torch.empty((n,), dtype=torch.float64, device=dev)
+    nb = lib.dass_argmax_blocks(n)
+    pval = torch.empty((nb,), dtype=torch.float64, device=dev)
+    pidx = torch.empty((nb,), dtype=torch.int64, device=dev)
+    picks = torch.empty((max(count, 1),), dtype=torch.int64, device=dev)
+    centers = torch.as_tensor(list(selected), dtype=torch.int64, device=dev)
+    for i in range(centers.numel()):
+        check(lib.dass_kcenter_update(_p(feats), n, d, _p(centers[i:i + 1]), _p(min_dist), 1 if i == 0 else 0,
+                                      _stream()), "dass_kcenter_update")
+    if centers.numel() == 0:
+        min_dist.fill_(float("inf"))
+    for j in range(count):
+        check(lib.dass_argmax_f64(_p(min_dist), n, _p(pval), _p(pidx), _p(picks[j:j + 1]), None, _stream()),
+              "dass_argmax_f64")
+        check(lib.dass_kcenter_update(_p(feats), n, d, _p(picks[j:j + 1]), _p(min_dist), 0, _stream()),
+              "dass_kcenter_update")
+    return picks[:count], min_dist
+
+
+def box_sum(maps, r):
+    n, h, w = maps.shape
+    out = torch.empty((n, h - r + 1, w - r + 1), dtype=torch.float32, device=maps.device)
+    tmp = torch.empty((n, h, w - r + 1), dtype=torch.float32, device=maps.device)
+    check(lib.dass_box_sum(_p(maps.contiguous()), _p(out), _p(tmp), n, h, w, r, _stream()), "dass_box_sum")
+    return out
+
+
+def zero_rect(maps, i, r0, r1, c0, c1):
+    n, h, w = maps.shape
+    r0, c0, r1, c1 = max(r0, 0), max(c0, 0), min(r1, h), min(c1, w)
+    check(lib.dass_zero_rect(_p(maps), i, h, w, r0, r1, c0, c1, _stream()), "dass_zero_rect")
+
+
+def minmax_normalize_(maps):
+    """x.add_(-min).mul_(1/(max-min)) over ALL maps (mc_dropout.py:152-155)"""
+    nel = maps.numel()
+    partial = torch.empty((lib.dass_minmax_blocks(nel), 2), dtype=torch.float32, device=maps.device)
+    mm = torch.empty((2,), dtype=torch.float32, device=maps.device)
+    check(lib.dass_minmax(_p(maps), nel, _p(partial), _p(mm), _stream()), "dass_minmax")
+    check(lib.dass_affine_inplace(_p(maps), nel, _p(mm), _stream()), "dass_affine_inplace")
+    return mm
+
+
+def square_nms(score_maps, region_size, max_selection_count):
+    """mc_dropout.py:82-108 on the device; returns (selected_regions per image, selection_count)"""
+    n, h, w = score_maps.shape
+    dev = score_maps.device
+    max_picks = int(math.ceil(max_selection_count))
+    imax = torch.empty((n,), dtype=torch.float32, device=dev)
+    iarg = torch.empty((n,), dtype=torch.int32, device=dev)
+    picks = torch.zeros((max(max_picks, 1), 3), dtype=torch.int32, device=dev)
+    count = torch.zeros((1,), dtype=torch.int32, device=dev)
+    if max_picks > 0:
+        check(lib.dass_square_nms(_p(score_maps), n, h, w, int(region_size), max_picks, _p(imax), _p(iarg), _p(picks),
+                                  _p(count), _stream()), "dass_square_nms")
+    cnt = int(count.item())
+    regions = [[] for _ in range(n)]
+    for i, r, c in picks[:cnt].tolist():
+        regions[i].append((r, c, region_size, region_size))
+    return regions, cnt

@@ -1,0 +1,226 @@
+/*
+ * dass_hip.h -- C-ABI of libdass_hip.so, the MI355X (gfx950) device library under the
+ * DeepLab-v3+ training / active-selection scoring hot path.
+ *
+ * The reference (nihalsid/deep-active-semantic-segmentation) has no FFI of its own: its
+ * device work is whatever ATen dispatches for the Python call sites cited on each entry
+ * point below.  These entry points are what the host-side mirror of the reference
+ * surface (models.deeplab.DeepLab, utils.loss.SegmentationLosses, active_selection.*)
+ * binds through ctypes -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a DASS_ERR_* code otherwise; nothing here
+ *     allocates, synchronises or touches the host: callers own every buffer.
+ *   - `stream` is a hipStream_t passed as void*.
+ *   - activations are NHWC ("pixel rows"): element (n,h,w,c) of a tensor lives at
+ *     ptr + ((n*H + h)*W + w)*ld + c, where ld >= C is the pixel stride in ELEMENTS.
+ *     A channel slice of a wider buffer is (ptr + c_off, ld = C_total).
+ *   - dtype: DASS_F32 (parity mode, exact f32 MFMA) or DASS_BF16 (storage bf16, f32 accumulate).
+ *   - conv weights are "KRSC": w[k][r][s][c], i.e. an OIHW tensor in channels_last memory.
+ *   - logits at the module boundary are NCHW f32, as the reference returns them.
+ */
+#ifndef DASS_HIP_H
+#define DASS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DASS_OK 0
+#define DASS_ERR_ARG 1      /* bad shape / alignment / null pointer */
+#define DASS_ERR_LAUNCH 2   /* hipGetLastError() after a launch      */
+#define DASS_ERR_UNSUPPORTED 3
+
+#define DASS_F32 0
+#define DASS_BF16 1
+
+#define DASS_ACT_NONE 0
+#define DASS_ACT_RELU 1
+#define DASS_ACT_RELU6 2
+
+/* library / build identification */
+int dass_version(void);
+const char *dass_arch(void);
+
+/* ---------------------------------------------------------------- convolution
+ * Implicit-GEMM NHWC convolution on MFMA; replaces every nn.Conv2d(groups=1) forward on the
+ * path (models/backbone/resnet.py:11-15,65,101-104; mobilenet.py:14,51-66; aspp.py:13,63,67;
+ * decoder.py:25,29-36) and, with ustride>1 / flipped weights, their input gradients.
+ *
+ *   y[n,oh,ow,k] = act( scale[k]*( sum_{r,s,c} x[n,iy,ix,c]*in_scale[n,c]*w[k,r,s,c] ) + shift[k]
+ *                       + residual[n,oh,ow,k] )
+ *   iy = oh*stride - pad + r*dil ; when ustride>1 the tap contributes only if iy%ustride==0
+ *   and then iy/=ustride (transposed-conv / dgrad addressing).  Same for ix.
+ * scale, shift, residual, in_scale may be NULL.  C and ldx, K-offsets must keep 16-byte alignment
+ * (C % 4 == 0 for f32, C % 8 == 0 for bf16).
+ */
+int dass_conv2d_igemm(const void *x, int64_t ldx, const void *w, void *y, int64_t ldy,
+                      const float *scale, const float *shift,
+                      const void *residual, int64_t ldr, const float *in_scale,
+                      int N, int H, int W, int C, int OH, int OW, int K,
+                      int R, int S, int stride, int pad, int dil, int ustride,
+                      int act, int dtype, void *stream);
+
+/* dw[k][r][s][c] (f32, KRSC, ld = C) = sum_pixels dy[n,oh,ow,k] * x[n,iy,ix,c]*in_scale[n,c];
+ * dw is zeroed inside (hipMemsetAsync on `stream`) then accumulated with f32 atomics.
+ * Replaces the weight gradient of the same nn.Conv2d sites. */
+int dass_conv2d_wgrad(const void *x, int64_t ldx, const void *dy, int64_t lddy, float *dw,
+                      int N, int H, int W, int C, int OH, int OW, int K,
+                      int R, int S, int stride, int pad, int dil, int dtype, void *stream);
+
+/* KRSC f32 master weights -> device operand.  mode 0: cast/copy [K][R][S][Csrc] -> [K][R][S][Cdst]
+ * (zero pad or truncate channels); mode 1: dgrad operand [C][R][S][K] with taps flipped. */
+int dass_weight_transform(const float *src, void *dst, int K, int R, int S, int Csrc, int Cdst,
+                          int mode, int dtype, void *stream);
+
+/* depthwise 3x3 (MobileNetV2 InvertedResidual, mobilenet.py:49,59): w[c][3][3] f32 */
+int dass_dwconv3x3_fwd(const void *x, int64_t ldx, const float *w, void *y, int64_t ldy,
+                       int N, int H, int W, int C, int OH, int OW,
+                       int stride, int pad, int dil, int dtype, void *stream);
+int dass_dwconv3x3_bwd_data(const void *dy, int64_t lddy, const float *w, void *dx, int64_t lddx,
+                            int N, int H, int W, int C, int OH, int OW,
+                            int stride, int pad, int dil, int dtype, void *stream);
+int dass_dwconv3x3_bwd_weight(const void *x, int64_t ldx, const void *dy, int64_t lddy, float *dw,
+                              int N, int H, int W, int C, int OH, int OW,
+                              int stride, int pad, int dil, int dtype, void *stream);
+
+/* ---------------------------------------------------------------- batch norm (+ReLU/ReLU6, residual, Dropout2d scale)
+ * Replaces F.batch_norm at every batchnorm(...) site + the ReLU that follows it. */
+
+/* number of partial rows dass_channel_stats / dass_bn_bwd_reduce write for M pixel rows */
+int dass_stat_rows(int64_t M);
+/* partial[row][0][k] = sum_m x[m,k], partial[row][1][k] = sum_m x[m,k]^2 over a slab of rows */
+int dass_channel_stats(const void *x, int64_t ldx, int64_t M, int K, float *partial, int dtype, void *stream);
+/* reduce partials in f64; count = M*rep ("rep" = how often each of the M rows is logically repeated,
+ * used by the ASPP image-pool branch whose BN sits after a 1x1 -> HxW broadcast, aspp.py:79-81).
+ * Writes mean, invstd, scale=gamma*invstd, shift=beta-mean*scale; updates running stats when
+ * momentum >= 0 (running_var uses the unbiased variance, as torch). */
+int dass_bn_finalize(const float *partial, int rows, int K, double count, double rep,
+                     const float *gamma, const float *beta, float *running_mean, float *running_var,
+                     float momentum, float eps, float *mean, float *invstd, float *scale, float *shift,
+                     void *stream);
+/* eval-mode BN folded to scale/shift from running stats */
+int dass_bn_eval_scale_shift(const float *gamma, const float *beta, const float *running_mean,
+                             const float *running_var, float eps, int K,
+                             float *mean, float *invstd, float *scale, float *shift, void *stream);
+/* out = act(x*scale[k] + shift[k] + residual) * nc_scale[n][k] ; n = m / rows_per_image */
+int dass_scale_shift_act(const void *x, int64_t ldx, void *out, int64_t ldo,
+                         const float *scale, const float *shift, const void *residual, int64_t ldr,
+                         const float *nc_scale, int64_t M, int K, int64_t rows_per_image,
+                         int act, int dtype, void *stream);
+/* backward of the above.  pass 1: partial[row][0][k]=sum dact, [1][k]=sum dact*xhat with
+ * dact = dout*nc_scale*act'(out) and xhat=(x-mean)*invstd. */
+int dass_bn_bwd_reduce(const void *dout, int64_t lddo, const void *out, int64_t ldo,
+                       const void *x, int64_t ldx, const float *mean, const float *invstd,
+                       const float *nc_scale, int64_t M, int K, int64_t rows_per_image,
+                       int act, float *partial, int dtype, void *stream);
+/* sums[0][k] = dbeta, sums[1][k] = dgamma (f64 reduction of the partial rows) */
+int dass_bn_bwd_finalize(const float *partial, int rows, int K, float *dbeta, float *dgamma, void *stream);
+/* pass 2: dx = gamma*invstd*(dact - train*(dbeta + xhat*dgamma)/count); dres = dact (may be NULL) */
+int dass_bn_bwd_apply(const void *dout, int64_t lddo, const void *out, int64_t ldo,
+                      const void *x, int64_t ldx, const float *mean, const float *invstd,
+                      const float *gamma, const float *dbeta, const float *dgamma,
+                      const float *nc_scale, void *dx, int64_t lddx, void *dres, int64_t lddr,
+                      int64_t M, int K, int64_t rows_per_image, double count, int train,
+                      int act, int dtype, void *stream);
+/* column sums only: out[k] = sum_m x[m,k] (bias gradient of decoder.last_conv.7) */
+int dass_colsum(const void *x, int64_t ldx, int64_t M, int K, float *partial, float *out, int dtype, void *stream);
+
+/* ---------------------------------------------------------------- layout / pooling / interpolation */
+/* NCHW f32 image -> NHWC (dtype), channels zero-padded to Cpad (stem input, resnet.py:83 / mobilenet.py:140) */
+int dass_nchw_to_nhwc(const float *x, void *y, int N, int C, int H, int W, int Cpad, int dtype, void *stream);
+int dass_nhwc_to_nchw(const void *x, int64_t ldx, float *y, int N, int C, int H, int W, int dtype, void *stream);
+/* dst[m, 0:C] = src[m, 0:C] with independent pixel strides (concat / split, torch.cat at aspp.py:83, decoder.py:46) */
+int dass_copy_channels(const void *src, int64_t lds, void *dst, int64_t ldd, int64_t M, int C, int dtype, void *stream);
+/* dst[m,c] += src[m,c] */
+int dass_add_channels(const void *src, int64_t lds, void *dst, int64_t ldd, int64_t M, int C, int dtype, void *stream);
+/* nn.MaxPool2d(3, 2, 1) (resnet.py:68): idx = winning tap 0..8 (uint8), first max wins */
+int dass_maxpool3x3s2_fwd(const void *x, void *y, uint8_t *idx, int N, int H, int W, int C, int OH, int OW, int dtype, void *stream);
+int dass_maxpool3x3s2_bwd(const void *dy, const uint8_t *idx, void *dx, int N, int H, int W, int C, int OH, int OW, int dtype, void *stream);
+/* nn.AdaptiveAvgPool2d((1,1)) (aspp.py:62): y[n][c] f32-accumulated mean */
+int dass_global_avgpool_fwd(const void *x, int64_t ldx, void *y, int N, int64_t HW, int C, int dtype, void *stream);
+/* dx[n,hw,c] = dy[n,c]*mult  (broadcast; also the 1x1 -> HxW bilinear of aspp.py:80) */
+int dass_broadcast_rows(const void *src, void *dst, int64_t ldd, int N, int64_t HW, int C, float mult, int dtype, void *stream);
+/* dst[n][c] = sum_hw src[n,hw,c] (backward of the broadcast) */
+int dass_reduce_rows(const void *src, int64_t lds, void *dst, int N, int64_t HW, int C, int dtype, void *stream);
+/* F.interpolate(mode='bilinear', align_corners=True) (aspp.py:80, decoder.py:45, deeplab.py:59).
+ * NHWC in; out NHWC (out_nchw=0, pixel stride ldy) or NCHW f32 (out_nchw=1). */
+int dass_bilinear_fwd(const void *x, int64_t ldx, void *y, int64_t ldy, int N, int IH, int IW, int C,
+                      int OH, int OW, int out_nchw, int dtype, void *stream);
+/* gather-form backward (deterministic): dy NHWC (ld) or NCHW f32 */
+int dass_bilinear_bwd(const void *dy, int64_t lddy, void *dx, int64_t lddx, int N, int IH, int IW, int C,
+                      int OH, int OW, int dy_nchw, int dtype, void *stream);
+
+/* ---------------------------------------------------------------- loss (utils/loss.py:39-51)
+ * logits NCHW f32; target float32 (target_is_float=1, as the reference's dataloader yields) or int64.
+ * ce_fwd writes per-block partial {sum w*nll, sum w}; ce_finalize reduces them (f64) into acc[2].
+ * ce_bwd: dlogits = gscale * w[t]*(softmax - onehot) / acc[1]  (gscale read from device memory). */
+int dass_ce_blocks(int64_t npix);
+int dass_ce_fwd(const float *logits, const void *target, int target_is_float, const float *weight,
+                int N, int C, int64_t HW, int ignore_index, float *partial, void *stream);
+int dass_ce_finalize(const float *partial, int blocks, float *acc, void *stream);
+int dass_ce_bwd(const float *logits, const void *target, int target_is_float, const float *weight,
+                int N, int C, int64_t HW, int ignore_index, const float *acc, const float *gscale,
+                float *dlogits, void *stream);
+
+/* ---------------------------------------------------------------- acquisition scoring
+ * (active_selection/mc_dropout.py:30-49,148-155,82-108; ceal.py:34-39,82-95,111-123,158-164;
+ *  core_set.py:17-38,61-63) */
+/* bilinear(align_corners) upsample of low-res NHWC logits fused with argmax over classes;
+ * votes[n*vote_nstride + oy*OW + ox] (uint8) -- never materialises the full-size logits. */
+int dass_upsample_argmax(const void *x, int64_t ldx, uint8_t *votes, int64_t vote_nstride,
+                         int N, int IH, int IW, int C, int OH, int OW, int dtype, void *stream);
+/* argmax over dim 1 of NCHW f32 logits (generic models; first max wins as torch.argmax) */
+int dass_argmax_nchw(const float *logits, uint8_t *votes, int64_t vote_nstride, int N, int C, int64_t HW, void *stream);
+/* per-image sums below go through fixed-order partials: partial must hold N*dass_score_blocks() floats */
+int dass_score_blocks(void);
+/* vote entropy: votes [N][T][HW] u8; label f32 [N][HW] or NULL; p_c = count_c/T;
+ * e = -sum_c p_c*log2(p_c+1e-12); 0 where label<0 or >=num_classes.
+ * entropy_map (nullable) [N][HW]; image_sum[n] = sum of the map (f64 finalize). */
+int dass_vote_entropy(const uint8_t *votes, const float *label, int N, int T, int64_t HW, int num_classes,
+                      float *entropy_map, float *partial, float *image_sum, void *stream);
+/* softmax scores from NCHW f32 logits. mode 0: max prob (masked->1), 1: top1-top2 margin (masked->1),
+ * 2: entropy log2 (masked->0).  map nullable; image_sum[n] = sum over pixels. */
+int dass_softmax_scores(const float *logits, const float *label, int N, int C, int64_t HW, int num_classes,
+                        int mode, float *map, float *partial, float *image_sum, void *stream);
+/* weak labels: argmax u8 with 255 where label is outside [0,num_classes) (ceal.py:158-164) */
+int dass_weak_labels(const float *logits, const float *label, int N, int C, int64_t HW, int num_classes,
+                     uint8_t *out, void *stream);
+/* F.avg_pool2d(feat, k, s) of NHWC features flattened channel-major: out[n][c*PH*PW + ph*PW + pw] f32 */
+int dass_avgpool_features(const void *x, int64_t ldx, float *out, int N, int H, int W, int C,
+                          int k, int s, int PH, int PW, int dtype, void *stream);
+/* k-center (core_set.py:32-38): min_dist[i] = min(min_dist[i], ||f_i - f_center||_2), f64 distances;
+ * the centre index is read from device memory so a whole greedy selection enqueues without a host sync.
+ * first=1 overwrites min_dist. */
+int dass_kcenter_update(const float *feat, int64_t n, int d, const int64_t *center, double *min_dist,
+                        int first, void *stream);
+/* first-max argmax (np.argmax, core_set.py:22): partial_val/partial_idx hold dass_argmax_blocks(n) entries */
+int dass_argmax_blocks(int64_t n);
+int dass_argmax_f64(const double *v, int64_t n, double *partial_val, int64_t *partial_idx,
+                    int64_t *out_idx, double *out_val, void *stream);
+/* valid r x r box sum of [N][H][W] maps -> [N][H-r+1][W-r+1] (conv2d with ones, mc_dropout.py:148);
+ * tmp holds N*H*(W-r+1) floats */
+int dass_box_sum(const float *maps, float *out, float *tmp, int N, int H, int W, int r, void *stream);
+/* zero the rectangle [r0,r1)x[c0,c1) of map n (suppress_labeled_entropy, mc_dropout.py:110-121) */
+int dass_zero_rect(float *maps, int n, int H, int W, int r0, int r1, int c0, int c1, void *stream);
+/* global min/max then x = (x - min) * (1/(max-min)) in place (mc_dropout.py:152-155);
+ * partial holds 2*dass_minmax_blocks(n) floats, out_min_max 2 floats (device) */
+int dass_minmax_blocks(int64_t n);
+int dass_minmax(const float *v, int64_t n, float *partial, float *out_min_max, void *stream);
+int dass_affine_inplace(float *v, int64_t n, const float *min_max, void *stream);
+/* greedy square NMS (mc_dropout.py:82-108) over [N][H][W] normalised score maps, entirely on device:
+ * picks[i] = (image, row, col), count[0] = number of picks; imax/iarg are N-entry scratch. */
+int dass_square_nms(float *maps, int N, int H, int W, int region, int max_picks, float *imax, int *iarg,
+                    int *picks, int *count, void *stream);
+
+/* fused SGD(momentum, weight decay, nesterov=False) step over one flat f32 tensor
+ * (torch.optim.SGD as built at active_train.py:60): g += wd*p; buf = mom*buf + g; p -= lr*buf */
+int dass_sgd_step(float *p, const float *g, float *buf, int64_t n, float lr, float momentum,
+                  float weight_decay, int first_step, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

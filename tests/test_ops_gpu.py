@@ -1,0 +1,430 @@
+"""Op-level parity of the HIP kernels (through the C-ABI) against plain PyTorch fp32 on the CPU.
+
+Each case runs the torch op the reference calls at that site (F.conv2d, F.batch_norm, F.relu,
+F.max_pool2d, F.interpolate, F.cross_entropy ...) on the CPU and the libdass_hip path on cuda:0 with the
+same seeded inputs.  Tolerances: forward 2e-4 relative to the tensor's max magnitude (f32 MFMA is an
+exact f32 fma chain; only summation order differs), gradients 5e-4.
+"""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from dass_hip import ops
+
+    ops.set_compute_dtype(torch.float32)
+    return ops
+
+
+def _close(a, b, tol, what=""):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(b.abs().max().item(), 1e-6)
+    err = (a - b).abs().max().item() / scale
+    assert err <= tol, "%s: rel err %.3e > %.1e (max |ref| %.3e)" % (what, err, tol, scale)
+
+
+def _cl(t):
+    return t.cuda().contiguous(memory_format=torch.channels_last)
+
+
+CONV_CASES = [
+    # (N, C, H, W, K, ksize, stride, pad, dil)
+    (2, 64, 17, 17, 64, 1, 1, 0, 1),
+    (2, 32, 19, 23, 96, 3, 1, 1, 1),
+    (1, 128, 33, 33, 256, 3, 1, 6, 6),
+    (2, 64, 33, 33, 64, 3, 1, 12, 12),
+    (1, 64, 33, 33, 32, 3, 1, 18, 18),
+    (2, 48, 21, 21, 128, 3, 2, 1, 1),
+    (2, 256, 9, 9, 512, 1, 2, 0, 1),
+    (2, 24, 13, 13, 144, 1, 1, 0, 1),
+    (1, 304, 17, 17, 256, 3, 1, 1, 1),
+    (2, 512, 9, 9, 512, 3, 1, 2, 2),
+    (3, 64, 9, 9, 48, 1, 1, 2, 1),  # 1x1 over a zero-padded input (MobileNet fixed_padding before expand)
+    (1, 2048, 5, 5, 256, 1, 1, 0, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward_backward(case):
+    ops = _ops()
+    n, c, h, w, k, ks, stride, pad, dil = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(n, c, h, w, generator=g)
+    conv = nn.Conv2d(c, k, ks, stride, pad, dil, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (c * ks * ks)) ** 0.5)
+    xr = x.clone().requires_grad_(True)
+    yr = conv(xr)
+    go = torch.randn(yr.shape, generator=g)
+    yr.backward(go)
+
+    conv_d = nn.Conv2d(c, k, ks, stride, pad, dil, bias=False).cuda()
+    with torch.no_grad():
+        conv_d.weight.copy_(conv.weight)
+    conv_d.weight.data = conv_d.weight.data.contiguous(memory_format=torch.channels_last)
+    xd = _cl(x).requires_grad_(True)
+    yd = ops.conv_bn_act(xd, conv_d)
+    _close(yd, yr, 2e-4, "conv fwd %s" % (case,))
+    yd.backward(_cl(go))
+    _close(xd.grad, xr.grad, 5e-4, "conv dgrad %s" % (case,))
+    _close(conv_d.weight.grad, conv.weight.grad, 5e-4, "conv wgrad %s" % (case,))
+
+
+def test_conv_stem_image_input():
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 65, 65, generator=g)
+    conv = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+    bn = nn.BatchNorm2d(64)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(64, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(64, generator=g) * 0.1)
+    ref = F.relu(bn(conv(x)))
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    import copy
+
+    conv_d, bn_d = copy.deepcopy(conv).cuda(), copy.deepcopy(bn).cuda()
+    conv_d.weight.grad = None
+    bn_d.weight.grad = bn_d.bias.grad = None
+    bn_d.running_mean.zero_()
+    bn_d.running_var.fill_(1)
+    bn_d.num_batches_tracked.zero_()
+    out = ops.conv_bn_act(x.cuda(), conv_d, bn_d, ops.ACT_RELU, image_input=True)
+    _close(out, ref, 2e-4, "stem fwd")
+    out.backward(_cl(go))
+    _close(conv_d.weight.grad, conv.weight.grad, 5e-4, "stem wgrad")
+    _close(bn_d.weight.grad, bn.weight.grad, 5e-4, "stem dgamma")
+    _close(bn_d.bias.grad, bn.bias.grad, 5e-4, "stem dbeta")
+    _close(bn_d.running_mean, bn.running_mean, 1e-4, "running_mean")
+    _close(bn_d.running_var, bn.running_var, 1e-4, "running_var")
+
+
+@pytest.mark.parametrize("act", ["relu", "relu6"])
+@pytest.mark.parametrize("train", [True, False])
+def test_conv_bn_act_residual(act, train):
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    n, c, h, w, k = 2, 64, 15, 15, 128
+    x = torch.randn(n, c, h, w, generator=g)
+    res = torch.randn(n, k, h, w, generator=g)
+    conv = nn.Conv2d(c, k, 3, 1, 2, 2, bias=False)
+    bn = nn.BatchNorm2d(k)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(k, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(k, generator=g) * 0.2)
+        bn.running_mean.copy_(torch.randn(k, generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(k, generator=g) + 0.5)
+    import copy
+
+    conv_d, bn_d = copy.deepcopy(conv).cuda(), copy.deepcopy(bn).cuda()
+    bn.train(train)
+    bn_d.train(train)
+    actf = F.relu if act == "relu" else F.relu6
+    xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    ref = actf(bn(conv(xr)) + rr)
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    xd, rd = _cl(x).requires_grad_(True), _cl(res).requires_grad_(True)
+    out = ops.conv_bn_act(xd, conv_d, bn_d, ops.ACT_RELU if act == "relu" else ops.ACT_RELU6, residual=rd)
+    _close(out, ref, 2e-4, "fwd")
+    out.backward(_cl(go))
+    _close(xd.grad, xr.grad, 5e-4, "dx")
+    _close(rd.grad, rr.grad, 5e-4, "dres")
+    _close(conv_d.weight.grad, conv.weight.grad, 5e-4, "dw")
+    _close(bn_d.weight.grad, bn.weight.grad, 5e-4, "dgamma")
+    _close(bn_d.bias.grad, bn.bias.grad, 5e-4, "dbeta")
+    if train:
+        _close(bn_d.running_var, bn.running_var, 1e-4, "running_var")
+    # inference (no grad) takes the fully fused epilogue
+    bn.eval()
+    bn_d.eval()
+    with torch.no_grad():
+        ref2 = actf(bn(conv(x)) + res)
+        out2 = ops.conv_bn_act(_cl(x), conv_d, bn_d, ops.ACT_RELU if act == "relu" else ops.ACT_RELU6, residual=_cl(res))
+    _close(out2, ref2, 2e-4, "fused eval fwd")
+
+
+def test_classifier_bias_19():
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 256, 11, 11, generator=g)
+    conv = nn.Conv2d(256, 19, 1)
+    xr = x.clone().requires_grad_(True)
+    ref = conv(xr)
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    import copy
+
+    conv_d = copy.deepcopy(conv).cuda()
+    conv_d.weight.grad = conv_d.bias.grad = None
+    xd = _cl(x).requires_grad_(True)
+    out = ops.conv_bn_act(xd, conv_d)
+    _close(out, ref, 2e-4, "cls fwd")
+    up_ref = F.interpolate(ref, size=(41, 41), mode="bilinear", align_corners=True)
+    up = ops.upsample_to_nchw(out, 41, 41)
+    _close(up, up_ref, 2e-4, "final upsample")
+    out.backward(go.cuda())
+    _close(xd.grad, xr.grad, 5e-4, "cls dx")
+    _close(conv_d.weight.grad, conv.weight.grad, 5e-4, "cls dw")
+    _close(conv_d.bias.grad, conv.bias.grad, 5e-4, "cls dbias")
+
+
+@pytest.mark.parametrize("cfg", [(32, 1, 1), (96, 2, 1), (144, 1, 2), (576, 1, 4)])
+def test_depthwise(cfg):
+    ops = _ops()
+    c, stride, dil = cfg
+    g = torch.Generator().manual_seed(c)
+    x = torch.randn(2, c, 17, 19, generator=g)
+    conv = nn.Conv2d(c, c, 3, stride, 0, dil, groups=c, bias=False)
+    bn = nn.BatchNorm2d(c)
+    xr = x.clone().requires_grad_(True)
+    ref = F.relu6(bn(conv(F.pad(xr, (dil, dil, dil, dil)))))
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    import copy
+
+    conv_d, bn_d = copy.deepcopy(conv).cuda(), copy.deepcopy(bn).cuda()
+    conv_d.weight.grad = None
+    bn_d.weight.grad = bn_d.bias.grad = None
+    bn_d.running_mean.zero_()
+    bn_d.running_var.fill_(1)
+    xd = _cl(x).requires_grad_(True)
+    out = ops.conv_bn_act(xd, conv_d, bn_d, ops.ACT_RELU6, extra_pad=dil)
+    _close(out, ref, 2e-4, "dw fwd")
+    out.backward(_cl(go))
+    _close(xd.grad, xr.grad, 5e-4, "dw dx")
+    _close(conv_d.weight.grad, conv.weight.grad, 5e-4, "dw dw")
+    _close(bn_d.weight.grad, bn.weight.grad, 5e-4, "dw dgamma")
+
+
+def test_maxpool_and_add():
+    ops = _ops()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 64, 33, 31, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = F.max_pool2d(xr, 3, 2, 1)
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    xd = _cl(x).requires_grad_(True)
+    out = ops.maxpool3x3s2(xd)
+    _close(out, ref, 0, "maxpool fwd")
+    out.backward(_cl(go))
+    _close(xd.grad, xr.grad, 1e-6, "maxpool bwd")
+    a, b = torch.randn(2, 32, 5, 5, generator=g), torch.randn(2, 32, 5, 5, generator=g)
+    _close(ops.add(_cl(a), _cl(b)), a + b, 1e-6, "add")
+
+
+def test_upsample_cat_and_concat():
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 256, 9, 9, generator=g)
+    low = torch.randn(2, 48, 33, 33, generator=g)
+    xr, lr = x.clone().requires_grad_(True), low.clone().requires_grad_(True)
+    ref = torch.cat((F.interpolate(xr, size=(33, 33), mode="bilinear", align_corners=True), lr), 1)
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    xd, ld = _cl(x).requires_grad_(True), _cl(low).requires_grad_(True)
+    out = ops.upsample_cat(xd, ld)
+    _close(out, ref, 1e-5, "upsample_cat fwd")
+    out.backward(_cl(go))
+    _close(xd.grad, xr.grad, 1e-4, "upsample bwd")
+    _close(ld.grad, lr.grad, 1e-6, "cat bwd")
+    parts = [torch.randn(2, 256, 7, 7, generator=g) for _ in range(5)]
+    pd = [_cl(p).requires_grad_(True) for p in parts]
+    cat = ops.concat(*pd)
+    _close(cat, torch.cat(parts, 1), 0, "concat")
+    go2 = torch.randn(cat.shape, generator=g)
+    cat.backward(_cl(go2))
+    _close(pd[3].grad, go2[:, 768:1024], 0, "concat bwd")
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_aspp_pool_branch(train):
+    ops = _ops()
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(3, 320, 9, 9, generator=g)
+    conv = nn.Conv2d(320, 256, 1, bias=False)
+    bn = nn.BatchNorm2d(256)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(256, generator=g) + 0.5)
+        bn.running_var.copy_(torch.rand(256, generator=g) + 0.5)
+    import copy
+
+    conv_d, bn_d = copy.deepcopy(conv).cuda(), copy.deepcopy(bn).cuda()
+    bn.train(train)
+    bn_d.train(train)
+    xr = x.clone().requires_grad_(True)
+    ref = bn(F.interpolate(F.relu(conv(F.adaptive_avg_pool2d(xr, 1))), size=(9, 9), mode="bilinear", align_corners=True))
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    xd = _cl(x).requires_grad_(True)
+    out = ops.broadcast_bn(ops.conv_bn_act(ops.global_avgpool(xd), conv_d, None, ops.ACT_RELU), bn_d, 9, 9)
+    _close(out, ref, 2e-4, "pool branch fwd")
+    out.backward(_cl(go))
+    _close(xd.grad, xr.grad, 1e-3, "pool branch dx")
+    _close(conv_d.weight.grad, conv.weight.grad, 1e-3, "pool branch dw")
+    _close(bn_d.weight.grad, bn.weight.grad, 1e-3, "pool branch dgamma")
+    if train:
+        _close(bn_d.running_var, bn.running_var, 1e-4, "pool branch running_var")
+
+
+def test_dropout_channel_scale():
+    ops = _ops()
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 256, 7, 7, generator=g)
+    mask = (torch.rand(2, 256, generator=g) > 0.5).float() * 2.0
+    conv = nn.Conv2d(256, 256, 1, bias=False)
+    bn = nn.BatchNorm2d(256)
+    import copy
+
+    conv_d, bn_d = copy.deepcopy(conv).cuda(), copy.deepcopy(bn).cuda()
+    xr = x.clone().requires_grad_(True)
+    ref = F.relu(bn(conv(xr))) * mask[:, :, None, None]
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    xd = _cl(x).requires_grad_(True)
+    out = ops.conv_bn_act(xd, conv_d, bn_d, ops.ACT_RELU, nc_scale=mask.cuda())
+    _close(out, ref, 2e-4, "dropout fwd")
+    out.backward(_cl(go))
+    _close(xd.grad, xr.grad, 5e-4, "dropout dx")
+    _close(bn_d.weight.grad, bn.weight.grad, 5e-4, "dropout dgamma")
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_cross_entropy(weighted):
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    logit = torch.randn(2, 19, 33, 29, generator=g) * 3
+    target = torch.randint(0, 19, (2, 33, 29), generator=g).float()
+    target[:, :4] = 255
+    wt = (torch.rand(19, generator=g) + 0.5) if weighted else None
+    lr = logit.clone().requires_grad_(True)
+    ref = F.cross_entropy(lr, target.long(), weight=wt, ignore_index=255) / 2
+    ref.backward()
+    ld = logit.cuda().requires_grad_(True)
+    out = ops.cross_entropy(ld, target.cuda(), wt.cuda() if weighted else None, 255) / 2
+    assert abs(out.item() - ref.item()) <= 1e-5 * max(1.0, abs(ref.item()))
+    out.backward()
+    _close(ld.grad, lr.grad, 1e-4, "ce grad")
+    # int64 targets too
+    out2 = ops.cross_entropy(logit.cuda(), target.long().cuda(), wt.cuda() if weighted else None, 255) / 2
+    assert abs(out2.item() - ref.item()) <= 1e-5 * max(1.0, abs(ref.item()))
+
+
+def test_scoring_kernels():
+    ops = _ops()
+    g = torch.Generator().manual_seed(10)
+    n, t, h, w, c = 2, 10, 37, 41, 19
+    votes = torch.randint(0, c, (n, t, h, w), generator=g).to(torch.uint8)
+    votes[:, :, :10] = votes[:, :1, :10]  # unanimous rows -> zero entropy
+    label = torch.randint(0, c, (n, h, w), generator=g).float()
+    label[:, :3] = 255
+    label[:, 3:4] = -1
+    ent = torch.zeros(n, h, w)
+    vf = votes.float()
+    for i in range(n):
+        e = torch.zeros(h, w)
+        for cc in range(c):
+            p = torch.sum(vf[i] == cc, dim=0, dtype=torch.float32) / t
+            e = e - p * torch.log2(p + 1e-12)
+        e[(label[i] < 0) | (label[i] >= c)] = 0
+        ent[i] = e
+    emap, mean = ops.vote_entropy(votes.cuda(), label.cuda(), c)
+    _close(emap, ent, 1e-5, "vote entropy map")
+    _close(mean, ent.mean(dim=(1, 2)), 1e-5, "vote entropy mean")
+    logits = torch.randn(n, c, h, w, generator=g) * 2
+    sm = torch.softmax(logits, 1)
+    mask = (label < 0) | (label >= c)
+    conf = sm.max(1)[0].clone()
+    conf[mask] = 1
+    top2 = sm.topk(2, dim=1)[0]
+    margin = (top2[:, 0] - top2[:, 1]).clone()
+    margin[mask] = 1
+    sent = -(sm * torch.log2(sm + 1e-12)).sum(1)
+    sent[mask] = 0
+    for mode, ref in ((0, conf), (1, margin), (2, sent)):
+        smap, smean = ops.softmax_scores(logits.cuda(), label.cuda(), c, mode, want_map=True)
+        _close(smap, ref, 1e-5, "softmax score map mode %d" % mode)
+        _close(smean, ref.mean(dim=(1, 2)), 1e-5, "softmax score mean mode %d" % mode)
+    wl = ops.weak_labels(logits.cuda(), label.cuda(), c).cpu()
+    ref_wl = logits.argmax(1).to(torch.uint8)
+    ref_wl[mask] = 255
+    assert torch.equal(wl, ref_wl)
+    # fused upsample + argmax vs interpolate + argmax (exact wherever the top-2 margin is not tiny)
+    low = torch.randn(n, c, 10, 11, generator=g)
+    up = F.interpolate(low, size=(h, w), mode="bilinear", align_corners=True)
+    top = up.topk(2, dim=1)[0]
+    safe = (top[:, 0] - top[:, 1]) > 1e-4
+    lowd = torch.zeros(n, 10, 11, 20).cuda()
+    lowd[..., :c] = low.permute(0, 2, 3, 1).cuda()
+    lowd = lowd.permute(0, 3, 1, 2)[:, :c]
+    vt = torch.zeros(n, 1, h, w, dtype=torch.uint8).cuda()
+    ops.upsample_argmax(lowd, h, w, vt, 0)
+    got = vt[:, 0].cpu().long()
+    assert torch.equal(got[safe], up.argmax(1)[safe])
+    assert safe.float().mean() > 0.99
+
+
+def test_coreset_kernels():
+    ops = _ops()
+    g = torch.Generator().manual_seed(12)
+    feat = torch.randn(2, 304, 129, 129, generator=g)
+    ref = F.avg_pool2d(feat, (64, 64), 32).flatten(1)
+    got = ops.avgpool_features(_cl(feat), 64, 32)
+    _close(got, ref, 1e-5, "avgpool features")
+    assert got.shape[1] == 2736
+    import numpy as np
+
+    pts = np.array([[0, 0], [0, 1], [1, 1], [1, 0], [10, 10], [11, 10], [10, 11], [20, 20], [21, 20]], dtype=np.float32)
+    # brute-force greedy reference (core_set.py:17-38 semantics)
+    def greedy(f, sel, k):
+        d = np.min(np.linalg.norm(f[:, None, :].astype(np.float64) - f[sel][None].astype(np.float64), axis=2), axis=1)
+        out = []
+        for _ in range(k):
+            i = int(np.argmax(d))
+            out.append(i)
+            d = np.minimum(d, np.linalg.norm(f.astype(np.float64) - f[i].astype(np.float64), axis=1))
+        return out
+
+    picks, _ = ops.kcenter_greedy(torch.from_numpy(pts).cuda(), [6], 5)
+    assert picks.cpu().tolist() == greedy(pts, [6], 5)
+    f = torch.randn(300, 2736, generator=g).numpy()
+    picks, _ = ops.kcenter_greedy(torch.from_numpy(f).cuda(), list(range(10)), 20)
+    assert picks.cpu().tolist() == greedy(f, list(range(10)), 20)
+
+
+def test_region_kernels():
+    ops = _ops()
+    g = torch.Generator().manual_seed(13)
+    maps = torch.rand(3, 65, 65, generator=g)
+    r = 17
+    ref = F.conv2d(maps[:, None], torch.ones(1, 1, r, r))[:, 0]
+    got = ops.box_sum(maps.cuda(), r)
+    _close(got, ref, 1e-5, "box sum")
+    lo, hi = ref.min(), ref.max()
+    refn = ref.clone().add_(-lo).mul_(1.0 / (hi - lo))
+    ops.minmax_normalize_(got)
+    _close(got, refn, 1e-5, "minmax")
+    # NMS vs a line-by-line CPU loop of mc_dropout.py:82-108
+    sm = refn.clone()
+    regions = [[] for _ in range(sm.shape[0])]
+    cnt = 0
+    for _ in range(12):
+        am = sm.view(-1).argmax()
+        i, rr, cc = am // (sm.shape[1] * sm.shape[2]), (am // sm.shape[2]) % sm.shape[1], am % sm.shape[2]
+        regions[i.item()].append((rr.item(), cc.item(), r, r))
+        cnt += 1
+        r0, c0 = max(0, rr - r), max(0, cc - r)
+        r1, c1 = min(sm.shape[1], rr + r), min(sm.shape[2], cc + r)
+        sm[i, r0:r1, c0:c1] = 0
+        if sm.max() < 0.01:
+            break
+    got_regions, got_cnt = ops.square_nms(refn.clone().cuda(), r, 12)
+    assert got_cnt == cnt and got_regions == regions
