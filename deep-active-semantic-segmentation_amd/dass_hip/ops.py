@@ -250,8 +250,7 @@ class _ConvBnAct(torch.autograd.Function):
         ow = conv_out_size(w, weight.shape[3], spec.stride, spec.pad, spec.dil)
         m = n * oh * ow
         bn = spec.bn
-        need_grad = torch.is_grad_enabled() and any(
-            t is not None and t.requires_grad for t in (x, weight, gamma, beta, bias, residual))
+        need_grad = any(ctx.needs_input_grad)  # (grad mode is off inside forward; this is the real signal)
         res_t = ldr = None
         if residual is not None:
             res_t, ldr = rows(_cast_act(residual))
@@ -425,7 +424,7 @@ class _MaxPool3x3s2(torch.autograd.Function):
             xs = xs.contiguous(memory_format=torch.channels_last)
         oh, ow = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
         y = new_act(n, c, oh, ow, xs.dtype, xs.device)
-        need = torch.is_grad_enabled() and x.requires_grad
+        need = ctx.needs_input_grad[0]
         idx = torch.empty((n, oh, ow, c), dtype=torch.uint8, device=xs.device) if need else None
         check(lib.dass_maxpool3x3s2_fwd(_p(xs), _p(y), _p(idx), n, h, w, c, oh, ow, _dt(y), _stream()),
               "dass_maxpool3x3s2_fwd")
