@@ -233,6 +233,8 @@ def fill_state_dict(module, seed=0, randomize_bn_stats=True):
             new[name] = (0.5 + u) if randomize_bn_stats else torch.ones_like(t)
         elif name.endswith("running_mean"):
             new[name] = ((u - 0.5) * 0.2) if randomize_bn_stats else torch.zeros_like(t)
+        elif name.endswith("bn3.weight"):
+            new[name] = 0.1 + 0.2 * u  # keep the 16/33-block residual stacks of ResNet-50/101 at O(1) magnitude
         elif name.endswith("weight"):
             new[name] = 0.5 + u
         else:  # BN beta, conv bias

@@ -1,0 +1,334 @@
+"""Pins the CPU oracle against the reference and writes the fixtures under tests/golden/.
+
+TEST INFRASTRUCTURE.  Run ONLY in the authoring container (needs /root/reference, read-only):
+    python oracle/make_goldens.py
+What it does
+  1. imports the reference's own modules from /root/reference (stubbing the absent torchvision / lmdb /
+     tensorboardX / scipy.misc.imresize, none of which are on the arithmetic path, and aliasing
+     torch.cuda.FloatTensor to the CPU type so mc_dropout.py's reductions run here -- SURVEY.md 8c),
+  2. drives reference and oracle with the same closed-form weights and asserts they agree,
+  3. stores the REFERENCE's outputs as small .npz fixtures (inputs are regenerated from seeds by the
+     tests, so only outputs are stored).  Fixtures are data; no reference source is copied.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from oracle import deeplab_cpu as O  # noqa: E402
+from oracle import selection_cpu as S  # noqa: E402
+
+
+def import_reference():
+    for name in ("torchvision", "torchvision.transforms", "torchvision.utils", "lmdb", "tensorboardX"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision"].utils = sys.modules["torchvision.utils"]
+    sys.modules["torchvision.utils"].make_grid = None
+    sys.modules["tensorboardX"].SummaryWriter = object
+    import scipy.misc
+
+    if not hasattr(scipy.misc, "imresize"):
+        scipy.misc.imresize = None
+    torch.cuda.FloatTensor = torch.FloatTensor
+    sys.path.insert(0, REF)
+    import constants  # noqa: F401
+    from models.deeplab import DeepLab
+    from models.aspp import ASPP
+    from models.decoder import Decoder
+    from models.backbone.resnet import ResNet101, ResNet50
+    from utils.loss import SegmentationLosses
+    from active_selection.mc_dropout import ActiveSelectionMCDropout
+    from active_selection.core_set import ActiveSelectionCoreSet
+
+    return dict(DeepLab=DeepLab, ASPP=ASPP, Decoder=Decoder, ResNet101=ResNet101, ResNet50=ResNet50,
+                SegmentationLosses=SegmentationLosses, MCDropout=ActiveSelectionMCDropout,
+                CoreSet=ActiveSelectionCoreSet, constants=constants)
+
+
+class RefResNetDeepLab(nn.Module):
+    """the reference's ResNet DeepLab assembled from its own parts (build_backbone('resnet') would
+    download weights; deeplab.py:43-59 is this 4-line composition)."""
+
+    def __init__(self, ref, which, num_classes):
+        super().__init__()
+        self.backbone = ref[which](16, nn.BatchNorm2d, pretrained=False)
+        self.aspp = ref["ASPP"]("resnet", 16, nn.BatchNorm2d)
+        self.decoder = ref["Decoder"](num_classes, "resnet", nn.BatchNorm2d, False)
+
+    def forward(self, x):
+        hi, low = self.backbone(x)
+        low_res, feats = self.decoder(self.aspp(hi), low)
+        return F.interpolate(low_res, size=x.shape[2:], mode="bilinear", align_corners=True), feats
+
+
+class MaskDropout(nn.Module):
+    """stands in for nn.Dropout2d inside the REFERENCE model so both sides see identical masks"""
+
+    def __init__(self):
+        super().__init__()
+        self.mask = None
+
+    def forward(self, x):
+        return x if self.mask is None else x * self.mask[:, :, None, None]
+
+
+def maxdiff(a, b):
+    return float((a - b).abs().max())
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    ref = import_reference()
+    report = {}
+
+    # ---------------------------------------------------------------- G5: end-to-end logits, eval mode
+    for tag, backbone, ncls, n, hw in (("mobilenet", "mobilenet", 19, 2, 65), ("resnet50", "resnet", 19, 1, 65),
+                                        ("resnet101", "resnet101", 19, 1, 65), ("mobilenet_voc", "mobilenet", 21, 1, 97)):
+        if backbone == "mobilenet":
+            rm = ref["DeepLab"](backbone="mobilenet", output_stride=16, num_classes=ncls, sync_bn=False,
+                                freeze_bn=False, mc_dropout=False, pretrained=False)
+        else:
+            rm = RefResNetDeepLab(ref, "ResNet50" if backbone == "resnet" else "ResNet101", ncls)
+        om = O.ODeepLab(backbone, 16, ncls)
+        O.fill_state_dict(om, seed=1)
+        missing = rm.load_state_dict(om.state_dict(), strict=True)
+        assert set(rm.state_dict().keys()) == set(om.state_dict().keys()), "state_dict keys differ"
+        rm.eval()
+        om.eval()
+        x, lab = O.synthetic_batch(n, hw, hw, ncls)
+        with torch.no_grad():
+            if backbone == "mobilenet":
+                rm.set_return_features(True)
+                r_out, r_feat = rm(x)
+            else:
+                r_out, r_feat = rm(x)
+            om.return_features = True
+            o_out, o_feat = om(x)
+        d = maxdiff(r_out, o_out)
+        report["e2e_%s" % tag] = d
+        assert d < 1e-5 and maxdiff(r_feat, o_feat) < 1e-5, (tag, d)
+        top2 = r_out.topk(2, dim=1)[0]
+        np.savez_compressed(os.path.join(OUT, "e2e_%s.npz" % tag), logits=r_out.numpy(),
+                            argmax=r_out.argmax(1).numpy().astype(np.uint8),
+                            margin=(top2[:, 0] - top2[:, 1]).numpy().astype(np.float16),
+                            feat_pooled=F.avg_pool2d(r_feat, 8, 4).numpy(),
+                            meta=np.array([n, hw, ncls]))
+
+    # ---------------------------------------------------------------- MC-dropout votes with explicit masks (mobilenet 65^2)
+    ncls, n, hw, T = 19, 2, 65, 6
+    rm = ref["DeepLab"](backbone="mobilenet", output_stride=16, num_classes=ncls, sync_bn=False, pretrained=False)
+    om = O.ODeepLab("mobilenet", 16, ncls)
+    O.fill_state_dict(om, seed=2)
+    rm.load_state_dict(om.state_dict())
+    rm.eval()
+    om.eval()
+    rm.aspp.dropout = MaskDropout()
+    rm.decoder.last_conv[6] = MaskDropout()
+    x, lab = O.synthetic_batch(n, hw, hw, ncls, first_index=50)
+    m1, m2 = O.dropout_masks(n, T, seed=3)
+    votes_ref = []
+    with torch.no_grad():
+        for t in range(T):
+            rm.aspp.dropout.mask, rm.decoder.last_conv[6].mask = m1[t], m2[t]
+            votes_ref.append(torch.argmax(rm(x), dim=1))
+    votes_ref = torch.stack(votes_ref, 1)
+    votes_or = S.mc_votes(om, x, (m1, m2))
+    flips = int((votes_ref != votes_or).sum())
+    report["mc_vote_flips_oracle_vs_ref"] = flips
+    assert flips == 0
+    # the reference's own reduction (mc_dropout.py:43-49) driven by a scripted model replaying these votes
+    ref["constants"].MC_STEPS = T
+    sel = ref["MCDropout"](ncls, None, hw, n)
+    replay = {"t": 0}
+
+    def scripted(_img):
+        t = replay["t"]
+        replay["t"] += 1
+        return F.one_hot(votes_ref[:, t], ncls).permute(0, 3, 1, 2).float()
+
+    ent_ref = sel._get_vote_entropy_for_batch(scripted, x, lab)
+    ent_or = S.vote_entropy_maps(votes_ref, lab, ncls)
+    d = max(maxdiff(a, b) for a, b in zip(ent_ref, ent_or))
+    report["vote_entropy_oracle_vs_ref"] = d
+    assert d == 0.0
+    np.savez_compressed(os.path.join(OUT, "mc_dropout_mobilenet.npz"), votes=votes_ref.numpy().astype(np.uint8),
+                        entropy=torch.stack(ent_ref).numpy(), mean=np.array([float(torch.mean(e)) for e in ent_ref], dtype=np.float32),
+                        meta=np.array([n, hw, ncls, T]))
+
+    # ---------------------------------------------------------------- G7: scripted votes (T in {10,20}, C in {19,21})
+    for T, C in ((10, 19), (20, 21)):
+        g = torch.Generator().manual_seed(100 + T)
+        votes = torch.randint(0, C, (3, T, 24, 31), generator=g)
+        votes[:, :, :6] = votes[:, :1, :6]
+        votes[0, : T // 2, 6:12] = 3
+        votes[0, T // 2:, 6:12] = 7
+        lab = torch.randint(0, C, (3, 24, 31), generator=g).float()
+        lab[:, 20:] = 255
+        lab[1, 0] = -1
+        ref["constants"].MC_STEPS = T
+        sel = ref["MCDropout"](C, None, 24, 3)
+        replay = {"t": 0}
+
+        def scripted2(_img, votes=votes, C=C, replay=replay):
+            t = replay["t"]
+            replay["t"] += 1
+            return F.one_hot(votes[:, t], C).permute(0, 3, 1, 2).float()
+
+        ent_ref = sel._get_vote_entropy_for_batch(scripted2, torch.zeros(3, 3, 24, 31), lab)
+        ent_or = S.vote_entropy_maps(votes, lab, C)
+        assert max(maxdiff(a, b) for a, b in zip(ent_ref, ent_or)) == 0.0
+        np.savez_compressed(os.path.join(OUT, "vote_entropy_T%d_C%d.npz" % (T, C)), votes=votes.numpy().astype(np.uint8),
+                            label=lab.numpy(), entropy=torch.stack(ent_ref).numpy())
+
+    # ---------------------------------------------------------------- G6: losses (value + dlogits)
+    g = torch.Generator().manual_seed(7)
+    logit = (torch.randn(2, 19, 21, 23, generator=g) * 3)
+    target = torch.randint(0, 19, (2, 21, 23), generator=g).float()
+    target[:, :3] = 255
+    wt = torch.rand(19, generator=g) + 0.5
+    out = {}
+    for wname, w in (("plain", None), ("weighted", wt)):
+        crit = ref["SegmentationLosses"](weight=w, cuda=False)
+        for mode in ("ce", "focal"):
+            lg = logit.clone().requires_grad_(True)
+            loss = crit.build_loss(mode)(lg, target)
+            loss.backward()
+            lo = logit.clone().requires_grad_(True)
+            loss_o = (S.ce_loss if mode == "ce" else S.focal_loss)(lo, target, w)
+            loss_o.backward()
+            assert abs(float(loss) - float(loss_o)) < 1e-7 and maxdiff(lg.grad, lo.grad) < 1e-8
+            out["%s_%s_loss" % (mode, wname)] = np.float32(float(loss))
+            out["%s_%s_grad" % (mode, wname)] = lg.grad.numpy()
+    sw = torch.tensor([1.0, 0.25])
+    crit = ref["SegmentationLosses"](cuda=False)
+    crit.cuda = False
+    lg = logit.clone().requires_grad_(True)
+    # SampleWeightedCrossEntropyLoss touches `weights` only under self.cuda (loss.py:26-28): drive the same math
+    per = nn.CrossEntropyLoss(ignore_index=255, reduction="none")(lg, target.long()).mean(-1).mean(-1)
+    loss = torch.mean(per * sw) / 2
+    lo = logit.clone()
+    assert abs(float(loss) - float(S.sample_weighted_ce_loss(lo, target, sw))) < 1e-7
+    out["sample_weighted_loss"] = np.float32(float(loss))
+    np.savez_compressed(os.path.join(OUT, "loss.npz"), **out)
+
+    # ---------------------------------------------------------------- G8: softmax scores (torch/numpy ops of ceal.py)
+    g = torch.Generator().manual_seed(8)
+    logits = torch.randn(2, 19, 17, 19, generator=g) * 2
+    lab = torch.randint(0, 19, (2, 17, 19), generator=g).float()
+    lab[:, :2] = 255
+    conf, margin, ent = S.softmax_score_maps(logits, lab, 19)
+    # cross-check against the literal numpy argsort formulation of ceal.py:85-91 for one image
+    outn = torch.softmax(logits, 1)[0].numpy()
+    ndx = np.indices(outn.shape)
+    second = outn[outn.argsort(0), ndx[1], ndx[2]][-2]
+    m0 = torch.softmax(logits, 1)[0].max(0)[0].numpy() - second
+    m0[S.label_mask(lab[0], 19).numpy()] = 1
+    assert np.abs(m0 - margin[0].numpy()).max() == 0.0
+    np.savez_compressed(os.path.join(OUT, "softmax_scores.npz"), conf=conf.numpy(), margin=margin.numpy(), entropy=ent.numpy(),
+                        weak=S.weak_label_maps(logits, lab, 19))
+
+    # ---------------------------------------------------------------- G10: k-center (tests.py:557-562 inputs)
+    cs = ref["CoreSet"](None, None, None)
+    feats = np.array([[1, 1], [2, 2], [2, 4], [3, 3], [4, 2], [4, 5], [5, 4], [6, 2], [7, 6]])
+    picks_ref = [int(i) for i in cs._select_batch(feats, [6], 5)]
+    picks_or, _ = S.kcenter_greedy(feats.astype(np.float64), [6], 5)
+    assert picks_ref == picks_or == [0, 2, 8, 4, 7], (picks_ref, picks_or)
+    big = np.asarray(O._hash_uniform(300 * 2736, 99), dtype=np.float64).reshape(300, 2736)
+    picks_big = [int(i) for i in cs._select_batch(big, list(range(10)), 25)]
+    assert picks_big == S.kcenter_greedy(big, list(range(10)), 25)[0]
+    np.savez_compressed(os.path.join(OUT, "kcenter.npz"), small_feats=feats, small_picks=np.array(picks_ref),
+                        big_picks=np.array(picks_big))
+
+    # ---------------------------------------------------------------- G11: square NMS (tests.py:213-231 inputs, production normalisation)
+    from PIL import Image
+
+    imgs = [np.asarray(Image.open(os.path.join(REF, "resources/images/nms_%d.png" % i)), dtype=np.float32) / 256 for i in (0, 1)]
+    region = 127
+    maps = torch.stack([S.box_sum(torch.from_numpy(im), region) for im in imgs])
+    S.minmax_normalize(maps)
+    reg_ref, cnt_ref = ref["MCDropout"].square_nms(maps.clone(), region, (512 * 512) // (region * region))
+    reg_or, cnt_or = S.square_nms(maps, region, (512 * 512) // (region * region))
+    assert reg_ref == reg_or and cnt_ref == cnt_or
+    np.savez_compressed(os.path.join(OUT, "nms_png.npz"), img0=(imgs[0] * 256).astype(np.uint8), img1=(imgs[1] * 256).astype(np.uint8),
+                        regions0=np.array(reg_ref[0]), regions1=np.array(reg_ref[1]), count=np.array(cnt_ref))
+    report["nms_regions"] = reg_ref
+    # suppress_labeled_entropy (mc_dropout.py:110-121)
+    em = torch.rand(40, 40)
+    em_ref = em.clone()
+    ref["MCDropout"].suppress_labeled_entropy(em_ref, [(3, 4, 10, 12), (30, 30, 10, 10)])
+    assert maxdiff(em_ref, S.suppress_labeled(em.clone(), [(3, 4, 10, 12), (30, 30, 10, 10)])) == 0
+
+    # ---------------------------------------------------------------- G12: two SGD training steps (mobilenet, 65^2, train-mode BN, dropout off via p masks)
+    ncls, n, hw = 19, 2, 97
+    rm = ref["DeepLab"](backbone="mobilenet", output_stride=16, num_classes=ncls, sync_bn=False, pretrained=False)
+    om = O.ODeepLab("mobilenet", 16, ncls)
+    O.fill_state_dict(om, seed=4, randomize_bn_stats=False)
+    rm.load_state_dict(om.state_dict())
+    sd0 = {k: v.clone() for k, v in om.state_dict().items()}
+    rm.aspp.dropout = MaskDropout()
+    rm.decoder.last_conv[6] = MaskDropout()
+    rm.train()
+    om.train()
+    x, lab = O.synthetic_batch(n, hw, hw, ncls, first_index=200)
+    m1, m2 = O.dropout_masks(n, 2, seed=5)
+    crit = ref["SegmentationLosses"](cuda=False).build_loss("ce")
+    # reference parameter grouping (deeplab.py:71-89) and optimizer (active_train.py:49-60)
+    lr = 0.01
+    r_opt = torch.optim.SGD([{"params": rm.get_1x_lr_params(), "lr": lr}, {"params": rm.get_10x_lr_params(), "lr": lr * 10}],
+                            momentum=0.9, weight_decay=5e-4, nesterov=False)
+    o_opt = torch.optim.SGD([{"params": [p for p in om.backbone.parameters()], "lr": lr},
+                             {"params": [p for p in list(om.aspp.parameters()) + list(om.decoder.parameters())], "lr": lr * 10}],
+                            momentum=0.9, weight_decay=5e-4, nesterov=False)
+    losses = []
+    for step in range(2):
+        rm.aspp.dropout.mask, rm.decoder.last_conv[6].mask = m1[step], m2[step]
+        r_opt.zero_grad()
+        lr_ = crit(rm(x), lab)
+        lr_.backward()
+        r_opt.step()
+        o_opt.zero_grad()
+        lo_ = S.ce_loss(om(x, (m1[step], m2[step])), lab)
+        lo_.backward()
+        o_opt.step()
+        assert abs(float(lr_) - float(lo_)) < 1e-5, (step, float(lr_), float(lo_))
+        losses.append(float(lr_))
+    sd_r, sd_o = rm.state_dict(), om.state_dict()
+    diffs = sorted(((maxdiff(sd_r[k].float(), sd_o[k].float()) / max(float((sd_r[k].float() - sd0[k].float()).abs().max()), 1e-3), k)
+                    for k in sd_o), reverse=True)
+    print("train2 worst keys (diff relative to the 2-step update)", diffs[:3])
+    worst = diffs[0][0]
+    report["train2_state_maxdiff_oracle_vs_ref"] = worst
+    # Both sides are stock PyTorch running the same op sequence; what differs is thread partitioning in
+    # the backward reductions.  Train-mode BN over the deepest 7x7 maps (mostly fixed_padding zeros)
+    # has near-zero-variance channels whose invstd ~ 1/sqrt(eps) amplifies that f32 noise, so the
+    # bound is on the update-relative difference and is loose by necessity.
+    assert worst < 5e-2
+    keys = ["backbone.features.0.0.weight", "backbone.features.5.conv.3.weight", "aspp.aspp3.atrous_conv.weight",
+            "aspp.bn_global_average_pool.running_var", "decoder.last_conv.0.weight", "decoder.last_conv.7.bias",
+            "backbone.features.17.conv.7.running_mean", "decoder.bn1.weight"]
+    np.savez_compressed(os.path.join(OUT, "train2_mobilenet.npz"), losses=np.array(losses, dtype=np.float64),
+                        **{k.replace(".", "__"): sd_r[k].numpy().reshape(-1)[:4096] for k in keys},
+                        **{"init__" + k.replace(".", "__"): sd0[k].numpy().reshape(-1)[:4096] for k in keys})
+    report["train2_losses"] = losses
+
+    for k, v in report.items():
+        print(k, v)
+    print("goldens written to", OUT)
+
+
+if __name__ == "__main__":
+    main()
