@@ -1,0 +1,89 @@
+"""ActiveSelectionBase -- mirror of active_selection/base.py:1-6 plus the two pieces every selector
+shares in this build: how the pool is read and how it is sharded over ranks.
+
+Data layer.  The reference selectors build DataLoader(PathsDataset(self.env, keys, crop, labels),
+batch_size, shuffle=False, num_workers=0) themselves (mc_dropout.py:180-181).  The LMDB / transform
+stack is outside this build's scope, so the loader comes from `loader_factory(keys, include_labels)`
+when one is injected (tests, bench: synthetic pools), else from the caller's own
+`dataloaders.dataset.paths_dataset.PathsDataset` exactly as the reference does.
+
+Multi-GPU.  Pool scoring is image-independent (eval-mode BN), so with torch.distributed initialised
+(one process per GPU, RCCL) each rank scores a contiguous shard of the key list and the per-image
+scores are all-gathered (padded to equal length); every rank then runs the same stable sort and
+returns the same selection.  No other collective is on the scoring path.
+"""
+import torch
+
+
+def _dist():
+    import torch.distributed as dist
+
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
+def shard_bounds(n_items, rank, world_size):
+    """contiguous, balanced split: the first (n % world) ranks hold one extra item"""
+    base, extra = divmod(n_items, world_size)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def all_gather_rows(local, n_total, device=None):
+    """local: [n_local, ...] tensor of this rank's shard (shard_bounds order) -> [n_total, ...] on every rank.
+    One all_gather of equal-size padded buffers (RCCL over xGMI when the backend is nccl)."""
+    dist = _dist()
+    if dist is None or dist.get_world_size() == 1:
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    per = (n_total + world - 1) // world
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad)
+    parts = []
+    for r in range(world):
+        s, e = shard_bounds(n_total, r, world)
+        parts.append(out[r][: e - s])
+    return torch.cat(parts, dim=0)
+
+
+class ActiveSelectionBase:
+
+    def __init__(self, dataset_lmdb_env, crop_size, dataloader_batch_size, loader_factory=None, shard=True):
+        self.crop_size = crop_size
+        self.dataloader_batch_size = dataloader_batch_size
+        self.env = dataset_lmdb_env
+        self.loader_factory = loader_factory
+        self.shard = shard
+
+    # ---- pool access
+    def make_loader(self, images, include_labels):
+        if self.loader_factory is not None:
+            return self.loader_factory(images, include_labels)
+        from torch.utils.data import DataLoader
+        from dataloaders.dataset import paths_dataset  # the caller's data layer, as in the reference
+
+        return DataLoader(paths_dataset.PathsDataset(self.env, images, self.crop_size, include_labels=include_labels),
+                          batch_size=self.dataloader_batch_size, shuffle=False, num_workers=0)
+
+    # ---- sharding
+    def local_slice(self, images):
+        dist = _dist()
+        if not self.shard or dist is None or dist.get_world_size() == 1:
+            return list(images), 0
+        s, e = shard_bounds(len(images), dist.get_rank(), dist.get_world_size())
+        return list(images[s:e]), s
+
+    def gather(self, local_rows, n_total):
+        if not self.shard:
+            return local_rows
+        return all_gather_rows(local_rows, n_total)
+
+    @staticmethod
+    def unwrap(model):
+        """selectors receive the DataParallel/DDP-wrapped model (active_train.py:82-85, core_set.py:44)"""
+        return model.module if hasattr(model, "module") else model
+
+    @staticmethod
+    def label_mask(label, num_classes):
+        return (label < 0) | (label >= num_classes)

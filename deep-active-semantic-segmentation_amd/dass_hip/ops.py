@@ -271,8 +271,11 @@ class _ConvBnAct(torch.autograd.Function):
                 scale, shift = state.scale, state.shift
             elif bias is not None:
                 shift = bias.detach().float()
+            in_scale = getattr(spec, "in_scale", None)
+            if in_scale is not None:
+                assert not need_grad and tuple(in_scale.shape) == (n, c) and in_scale.dtype == torch.float32
             _conv_forward_raw(spec, xs, ldx, n, h, w, c, weight, out, ldo, oh, ow, scale=scale, shift=shift,
-                              residual=res_t, ldr=ldr or 0, act=spec.act)
+                              residual=res_t, ldr=ldr or 0, act=spec.act, in_scale=in_scale)
             if nc_scale is not None:
                 scale_shift_act(out, ldo, out, ldo, m, k, None, None, nc_scale=nc_scale, rows_per_image=oh * ow)
         else:
@@ -407,8 +410,14 @@ def _dgrad_operand_uncached(wsrc, dtype):
     return op
 
 
-def conv_bn_act(x, conv, bn=None, act=ACT_NONE, residual=None, nc_scale=None, extra_pad=0, image_input=False):
+def conv_bn_act(x, conv, bn=None, act=ACT_NONE, residual=None, nc_scale=None, extra_pad=0, image_input=False,
+                in_scale=None):
+    """in_scale: [N,C] f32 multipliers applied to the INPUT while it is staged (inference only): a
+    Dropout2d mask of the producer folded into this conv's loader (MC-dropout tail, SURVEY 8a note iii)."""
     spec = ConvSpec(conv, bn, act, extra_pad)
+    if in_scale is not None:
+        assert bn is None or not bn_use_batch_stats(bn), "in_scale needs eval-mode BN"
+        spec.in_scale = in_scale.contiguous()
     gamma = bn.weight if bn is not None else None
     beta = bn.bias if bn is not None else None
     return _ConvBnAct.apply(x, conv.weight, gamma, beta, conv.bias, residual, nc_scale, spec, image_input)
@@ -704,7 +713,7 @@ class _CrossEntropy(torch.autograd.Function):
     """nn.CrossEntropyLoss(weight, ignore_index, reduction='mean')(logit, target.long())"""
 
     @staticmethod
-    def forward(ctx, logit, target, weight, ignore_index):
+    def forward(ctx, logit, target, weight, ignore_index, mean):
         _require_cuda(logit)
         lg = logit.contiguous().float()
         n, c, h, w = lg.shape
@@ -720,9 +729,13 @@ class _CrossEntropy(torch.autograd.Function):
         check(lib.dass_ce_fwd(_p(lg), _p(tgt), is_float, _p(wt), n, c, hw, int(ignore_index), _p(partial), _stream()),
               "dass_ce_fwd")
         check(lib.dass_ce_finalize(_p(partial), blocks, _p(acc), _stream()), "dass_ce_finalize")
-        ctx.save_for_backward(lg, tgt, wt, acc)
         ctx.meta = (n, c, hw, is_float, int(ignore_index))
-        return acc[0] / acc[1]
+        if mean:
+            ctx.save_for_backward(lg, tgt, wt, acc)
+            return acc[0] / acc[1]
+        norm = torch.ones((2,), dtype=torch.float32, device=lg.device)  # backward divides by norm[1] = 1
+        ctx.save_for_backward(lg, tgt, wt, norm)
+        return acc[0].clone()
 
     @staticmethod
     def backward(ctx, g):
@@ -732,11 +745,16 @@ class _CrossEntropy(torch.autograd.Function):
         d = torch.empty_like(lg)
         check(lib.dass_ce_bwd(_p(lg), _p(tgt), is_float, _p(wt), n, c, hw, ignore, _p(acc), _p(gs), _p(d), _stream()),
               "dass_ce_bwd")
-        return d, None, None, None
+        return d, None, None, None, None
 
 
 def cross_entropy(logit, target, weight=None, ignore_index=255):
-    return _CrossEntropy.apply(logit, target, weight, ignore_index)
+    return _CrossEntropy.apply(logit, target, weight, ignore_index, True)
+
+
+def cross_entropy_sum(logit, target, weight=None, ignore_index=255):
+    """sum over valid pixels of w[t]*nll (reduction='none' summed), used by the sample-weighted loss"""
+    return _CrossEntropy.apply(logit, target, weight, ignore_index, False)
 
 
 # ----------------------------------------------------------------------------- scoring launches (no autograd)

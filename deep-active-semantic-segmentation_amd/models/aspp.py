@@ -1,0 +1,81 @@
+"""ASPP on the HIP path -- mirror of models/aspp.py:8-101 (same names, signatures, state_dict keys,
+error behaviour).  Four conv+BN+ReLU branches (1x1 and three dilated 3x3, each one implicit-GEMM
+launch that skips the taps falling entirely in the padding), the image-pool branch
+(avg-pool -> 1x1 -> ReLU -> broadcast -> BN, the reference's ReLU-before-BN / BN-after-upsample order),
+channel concat, 1x1 merge conv + BN + ReLU with the Dropout2d(0.5) mask fused into the BN-apply pass.
+"""
+import torch.nn as nn
+
+from dass_hip import ops
+from models._common import channels_last_weights, dropout_mask_for, init_weights
+
+
+class ASPPModule(nn.Module):
+
+    def __init__(self, inplanes, planes, kernel_size, padding, dilation, batchnorm):
+        super(ASPPModule, self).__init__()
+        self.atrous_conv = nn.Conv2d(inplanes, planes, kernel_size=kernel_size, stride=1, padding=padding, dilation=dilation, bias=False)
+        self.bn = batchnorm(planes)
+        self.relu = nn.ReLU()
+        self._init_weight()
+
+    def forward(self, x):
+        return ops.conv_bn_act(x, self.atrous_conv, self.bn, ops.ACT_RELU)
+
+    def _init_weight(self):
+        init_weights(self)
+        channels_last_weights(self)
+
+
+class ASPP(nn.Module):
+
+    def __init__(self, backbone, output_stride, batchnorm):
+        super(ASPP, self).__init__()
+        if backbone in ('resnet', 'resnet101'):
+            inplanes = 2048
+        elif backbone == 'mobilenet':
+            inplanes = 320
+        else:
+            raise Exception('Unknown backbone')
+
+        if output_stride == 16:
+            dilations = [1, 6, 12, 18]
+        elif output_stride == 8:
+            dilations = [1, 12, 24, 36]
+        else:
+            raise NotImplementedError
+
+        self.aspp1 = ASPPModule(inplanes, 256, 1, padding=0, dilation=dilations[0], batchnorm=batchnorm)
+        self.aspp2 = ASPPModule(inplanes, 256, 3, padding=dilations[1], dilation=dilations[1], batchnorm=batchnorm)
+        self.aspp3 = ASPPModule(inplanes, 256, 3, padding=dilations[2], dilation=dilations[2], batchnorm=batchnorm)
+        self.aspp4 = ASPPModule(inplanes, 256, 3, padding=dilations[3], dilation=dilations[3], batchnorm=batchnorm)
+        self.global_average_pool = nn.Sequential(nn.AdaptiveAvgPool2d((1, 1)),
+                                                 nn.Conv2d(inplanes, 256, 1, stride=1, bias=False),
+                                                 nn.ReLU())
+        self.bn_global_average_pool = batchnorm(256)
+        self.conv1 = nn.Conv2d(1280, 256, 1, bias=False)
+        self.bn1 = batchnorm(256)
+        self.relu = nn.ReLU()
+        self.dropout = nn.Dropout2d(0.5)
+        self._init_weight()
+
+    def forward(self, x, dropout_mask=None, apply_dropout=True):
+        """dropout_mask: optional explicit [N,256] multipliers (reproducible stochastic passes);
+        apply_dropout=False returns the pre-dropout activation (used by the hoisted MC-dropout tail)."""
+        h, w = x.shape[2], x.shape[3]
+        x1 = self.aspp1(x)
+        x2 = self.aspp2(x)
+        x3 = self.aspp3(x)
+        x4 = self.aspp4(x)
+        x5 = ops.global_avgpool(x)
+        x5 = ops.conv_bn_act(x5, self.global_average_pool[1], None, ops.ACT_RELU)
+        x5 = ops.broadcast_bn(x5, self.bn_global_average_pool, h, w)
+        cat = ops.concat(x1, x2, x3, x4, x5)
+        mask = None
+        if apply_dropout:
+            mask = dropout_mask if dropout_mask is not None else dropout_mask_for(self.dropout, x.shape[0], 256, x.device)
+        return ops.conv_bn_act(cat, self.conv1, self.bn1, ops.ACT_RELU, nc_scale=mask)
+
+    def _init_weight(self):
+        init_weights(self)
+        channels_last_weights(self)

@@ -1,0 +1,63 @@
+"""DeepLab-v3+ decoder on the HIP path -- mirror of models/decoder.py:9-60.
+
+forward(x, low_level_feat) -> (low-res logits [N,classes,h,w], concat features [N,304,h,w]) as the
+reference.  The bilinear(align_corners) upsample of the ASPP output is written straight into the
+304-channel concat buffer; Dropout2d(MC_DROPOUT_RATE) is a per-(n,c) scale fused into the BN-apply
+pass of the second 3x3; the classifier's bias rides in the conv epilogue.
+"""
+import torch.nn as nn
+
+import constants
+from dass_hip import ops
+from models._common import channels_last_weights, dropout_mask_for, init_weights
+
+
+class Decoder(nn.Module):
+
+    def __init__(self, num_classes, backbone, batchnorm, mc_dropout):
+        super(Decoder, self).__init__()
+        if backbone in ('resnet', 'resnet101'):
+            low_level_inplanes = 256
+        elif backbone == 'xception':
+            low_level_inplanes = 128
+        elif backbone == 'mobilenet':
+            low_level_inplanes = 24
+        else:
+            raise NotImplementedError
+
+        self.conv1 = nn.Conv2d(low_level_inplanes, 48, 1, bias=False)
+        self.bn1 = batchnorm(48)
+        self.relu = nn.ReLU()
+        # aspp always gives out 256 planes + 48 from conv1
+        self.last_conv = nn.Sequential(nn.Conv2d(304, 256, kernel_size=3, stride=1, padding=1, bias=False),
+                                       batchnorm(256),
+                                       nn.ReLU(),
+                                       nn.Conv2d(256, 256, kernel_size=3, stride=1, padding=1, bias=False),
+                                       batchnorm(256),
+                                       nn.ReLU(),
+                                       nn.Dropout2d(p=constants.MC_DROPOUT_RATE),
+                                       nn.Conv2d(256, num_classes, kernel_size=1, stride=1))
+        self._init_weight()
+
+    def features(self, x, low_level_feat):
+        """[upsampled ASPP output | 48-ch low-level] -- the core-set feature tensor (decoder.py:41-46)"""
+        low = ops.conv_bn_act(low_level_feat, self.conv1, self.bn1, ops.ACT_RELU)
+        return ops.upsample_cat(x, low)
+
+    def head(self, feats, dropout_mask=None, in_scale=None, mask_as_in_scale=None):
+        lc = self.last_conv
+        h = ops.conv_bn_act(feats, lc[0], lc[1], ops.ACT_RELU, in_scale=in_scale)
+        if mask_as_in_scale is not None:  # inference: fold the Dropout2d mask into the classifier's loader
+            h = ops.conv_bn_act(h, lc[3], lc[4], ops.ACT_RELU)
+            return ops.conv_bn_act(h, lc[7], in_scale=mask_as_in_scale)
+        mask = dropout_mask if dropout_mask is not None else dropout_mask_for(lc[6], feats.shape[0], 256, feats.device)
+        h = ops.conv_bn_act(h, lc[3], lc[4], ops.ACT_RELU, nc_scale=mask)
+        return ops.conv_bn_act(h, lc[7])
+
+    def forward(self, x, low_level_feat, dropout_mask=None):
+        second_to_last_features = self.features(x, low_level_feat)
+        return self.head(second_to_last_features, dropout_mask), second_to_last_features
+
+    def _init_weight(self):
+        init_weights(self)
+        channels_last_weights(self)

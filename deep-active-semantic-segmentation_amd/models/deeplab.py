@@ -1,0 +1,136 @@
+"""DeepLab-v3+ on the MI355X HIP path -- drop-in mirror of models/deeplab.py:11-89.
+
+Same constructor, attributes (backbone / aspp / decoder / return_features / noisy_features /
+model_name), methods (set_return_features, set_noisy_features, freeze_bn, get_1x_lr_params,
+get_10x_lr_params) and state_dict keys; forward(input[N,C,H,W] f32) -> logits[N,classes,H,W] f32
+(or (logits, feats[N,304,H/4,W/4])).  Everything between the NCHW input and the NCHW logits runs in
+NHWC through libdass_hip.
+
+Additions (do not change the reference surface):
+  * backbone='resnet101' (the benchmark config; 'resnet' stays ResNet-50 like the reference),
+  * forward(..., dropout_masks=(m_aspp[N,256], m_dec[N,256])) for reproducible stochastic passes,
+  * mc_dropout_votes(): the T-pass scoring tail with the deterministic prefix computed once
+    (SURVEY.md 8a notes i-iii), used by active_selection.mc_dropout.
+"""
+import torch
+import torch.nn as nn
+
+from dass_hip import ops
+from models.aspp import ASPP
+from models.backbone import build_backbone
+from models.decoder import Decoder
+from models.sync_batchnorm.batchnorm import SynchronizedBatchNorm2d
+
+
+class DeepLab(nn.Module):
+
+    def __init__(self, backbone='mobilenet', output_stride=16, num_classes=19, sync_bn=True, freeze_bn=False,
+                 mc_dropout=False, input_channels=3, pretrained=True):
+        super(DeepLab, self).__init__()
+        if sync_bn == True:  # noqa: E712  (reference idiom, deeplab.py:17)
+            batchnorm = SynchronizedBatchNorm2d
+        else:
+            batchnorm = nn.BatchNorm2d
+
+        self.backbone = build_backbone(backbone, output_stride, batchnorm, mc_dropout, input_channels, pretrained)
+        self.aspp = ASPP(backbone, output_stride, batchnorm)
+        self.decoder = Decoder(num_classes, backbone, batchnorm, mc_dropout)
+        self.return_features = False
+        self.noisy_features = False
+        self.model_name = 'deeplab'
+        self.num_classes = num_classes
+        if freeze_bn:
+            self.freeze_bn()
+
+    def set_return_features(self, return_features):
+        self.return_features = return_features
+
+    def set_noisy_features(self, noisy_features):
+        self.noisy_features = noisy_features
+
+    @staticmethod
+    def _noise_like(t, frac):
+        # deeplab.py:39-56 draws numpy gaussians on the host; same distribution drawn on the device here
+        return torch.randn_like(t.float()) * abs(float(t.float().mean()) * frac)
+
+    def forward(self, input, dropout_masks=None):
+        m_aspp, m_dec = dropout_masks if dropout_masks is not None else (None, None)
+        if self.noisy_features is True:
+            input = input + self._noise_like(input, 0.05)
+
+        x, low_level_feat = self.backbone(input)
+
+        if self.noisy_features is True:
+            x = x + self._noise_like(x, 0.5).to(x.dtype)
+            low_level_feat = low_level_feat + self._noise_like(low_level_feat, 0.5).to(low_level_feat.dtype)
+
+        x = self.aspp(x, dropout_mask=m_aspp)
+
+        if self.noisy_features is True:
+            x = x + self._noise_like(x, 0.5).to(x.dtype)
+
+        low_res_x, features = self.decoder(x, low_level_feat, dropout_mask=m_dec)
+        x = ops.upsample_to_nchw(low_res_x, input.shape[2], input.shape[3])
+        if self.return_features:
+            return x, features
+        return x
+
+    # ------------------------------------------------------------------ scoring fast paths (inference only)
+    def _bn_all_eval(self):
+        return not any(m.training for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm))
+
+    @torch.no_grad()
+    def encoder_features(self, input):
+        """the 304-channel decoder feature map without the dead last_conv / final upsample
+        (core_set.py:60-61 only consumes the features; SURVEY.md 8a note ii)"""
+        x, low = self.backbone(input)
+        x = self.aspp(x, apply_dropout=False)
+        return self.decoder.features(x, low)
+
+    @torch.no_grad()
+    def mc_dropout_votes(self, input, steps, masks=None, generator=None):
+        """uint8 votes [N, steps, H, W] = argmax of `steps` stochastic forwards (mc_dropout.py:37-40).
+
+        Only Dropout2d after aspp.bn1 (p=0.5) and decoder.last_conv.6 (p=MC_DROPOUT_RATE) are stochastic
+        for models built the way active_train.py:48 builds them, so backbone + ASPP + decoder.conv1 +
+        the upsample/concat run ONCE; each pass re-runs last_conv with its masks folded into the conv
+        loaders (upsample(m*x) == m*upsample(x)) and ends in the fused upsample+argmax kernel.
+        masks: optional ([T,N,256], [T,N,256]) multipliers; default: Bernoulli draws like nn.Dropout2d."""
+        assert self._bn_all_eval(), "mc_dropout_votes needs eval-mode BN (model.eval() + dropout switched on)"
+        n, _, hh, ww = input.shape
+        dev = input.device
+        feats = self.encoder_features(input)
+        p1, p2 = self.aspp.dropout.p, self.decoder.last_conv[6].p
+        votes = torch.empty((n, steps, hh, ww), dtype=torch.uint8, device=dev)
+        ones48 = torch.ones((n, 48), dtype=torch.float32, device=dev)
+        for t in range(steps):
+            if masks is not None:
+                m1, m2 = masks[0][t].to(dev).float(), masks[1][t].to(dev).float()
+            else:
+                m1 = ops.dropout2d_mask(n, 256, p1, dev, generator)
+                m2 = ops.dropout2d_mask(n, 256, p2, dev, generator)
+            low_res = self.decoder.head(feats, in_scale=torch.cat((m1, ones48), dim=1), mask_as_in_scale=m2)
+            ops.upsample_argmax(low_res, hh, ww, votes, t)
+        return votes
+
+    def freeze_bn(self):
+        for m in self.modules():
+            if isinstance(m, SynchronizedBatchNorm2d):
+                m.eval()
+            elif isinstance(m, nn.BatchNorm2d):
+                m.eval()
+
+    def _lr_params(self, modules):
+        for mod in modules:
+            for m in mod.named_modules():
+                if isinstance(m[1], nn.Conv2d) or isinstance(m[1], SynchronizedBatchNorm2d) \
+                        or isinstance(m[1], nn.BatchNorm2d):
+                    for p in m[1].parameters():
+                        if p.requires_grad:
+                            yield p
+
+    def get_1x_lr_params(self):
+        return self._lr_params([self.backbone])
+
+    def get_10x_lr_params(self):
+        return self._lr_params([self.aspp, self.decoder])

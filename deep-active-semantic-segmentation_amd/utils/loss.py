@@ -1,0 +1,65 @@
+"""utils.loss.SegmentationLosses on the HIP path -- mirror of utils/loss.py:5-70.
+
+Same constructor, build_loss(mode) -> bound callable (logit[N,C,H,W], target[N,H,W] float) -> 0-dim
+tensor with autograd, NotImplementedError for unknown modes.  The log-softmax + NLL + ignore-index mean
+(and its gradient) are the fused dass_ce_* kernels; the scalar focal transform stays scalar torch math,
+exactly as the reference composes it on top of the CE scalar.
+"""
+import torch
+
+from dass_hip import ops
+
+
+class SegmentationLosses(object):
+
+    def __init__(self, weight=None, batch_average=True, ignore_index=255, cuda=True):
+        self.ignore_index = ignore_index
+        self.weight = weight
+        self.batch_average = batch_average
+        self.cuda = cuda
+
+    def build_loss(self, mode='ce'):
+        if mode == 'ce':
+            return self.CrossEntropyLoss
+        elif mode == 'focal':
+            return self.FocalLoss
+        else:
+            raise NotImplementedError
+
+    def _weight_on(self, device):
+        if self.weight is None:
+            return None
+        w = self.weight if torch.is_tensor(self.weight) else torch.as_tensor(self.weight)
+        return w.to(device=device, dtype=torch.float32)
+
+    def _ce_mean(self, logit, target):
+        return ops.cross_entropy(logit, target, self._weight_on(logit.device), self.ignore_index)
+
+    def SampleWeightedCrossEntropyLoss(self, logit, target, sample_weights):
+        n, c, h, w = logit.size()
+        weights = sample_weights.to(logit.device)
+        # reduction='none' then .mean(-1).mean(-1): ignored pixels count as zeros in the H*W mean
+        per_image = torch.stack([ops.cross_entropy_sum(logit[i:i + 1], target[i:i + 1], self._weight_on(logit.device),
+                                                       self.ignore_index) for i in range(n)]) / float(h * w)
+        loss = torch.mean(torch.mul(per_image, weights))
+        if self.batch_average:
+            loss /= n
+        return loss
+
+    def CrossEntropyLoss(self, logit, target):
+        n, c, h, w = logit.size()
+        loss = self._ce_mean(logit, target)
+        if self.batch_average:
+            loss = loss / n
+        return loss
+
+    def FocalLoss(self, logit, target, gamma=2, alpha=0.5):
+        n, c, h, w = logit.size()
+        logpt = -self._ce_mean(logit, target)
+        pt = torch.exp(logpt)
+        if alpha is not None:
+            logpt = logpt * alpha
+        loss = -((1 - pt) ** gamma) * logpt
+        if self.batch_average:
+            loss = loss / n
+        return loss

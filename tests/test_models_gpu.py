@@ -1,0 +1,296 @@
+"""End-to-end parity of the HIP product path (through the reference's surface: models.deeplab.DeepLab,
+utils.loss.SegmentationLosses, active_selection.*) against
+  (a) the golden fixtures produced by the REFERENCE's own modules (tests/golden, oracle/make_goldens.py),
+  (b) the CPU oracle run on the same seeded inputs.
+Tolerances follow BASELINE.json's north_star: logits and entropy scores within 1e-3 (f32), argmax label
+maps bit-exact wherever the reference's own top-2 margin exceeds 1e-3 (nearer ties are reported).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _setup():
+    from dass_hip import ops
+
+    ops.set_compute_dtype(torch.float32)
+    from oracle import deeplab_cpu as O
+    from oracle import selection_cpu as S
+
+    return ops, O, S
+
+
+def _product(backbone, ncls, O, seed, randomize_bn_stats=True):
+    from models.deeplab import DeepLab
+
+    om = O.ODeepLab(backbone, 16, ncls)
+    O.fill_state_dict(om, seed=seed, randomize_bn_stats=randomize_bn_stats)
+    pm = DeepLab(backbone=backbone, output_stride=16, num_classes=ncls, sync_bn=False, freeze_bn=False, pretrained=False)
+    assert list(pm.state_dict().keys()) == list(om.state_dict().keys()), "state_dict keys must match the reference's"
+    pm.load_state_dict(om.state_dict())
+    return pm.cuda(), om
+
+
+@pytest.mark.parametrize("tag,backbone", [("mobilenet", "mobilenet"), ("resnet50", "resnet"), ("resnet101", "resnet101"),
+                                          ("mobilenet_voc", "mobilenet")])
+def test_e2e_logits_vs_reference_golden(tag, backbone):
+    ops, O, S = _setup()
+    g = np.load(os.path.join(GOLD, "e2e_%s.npz" % tag))
+    n, hw, ncls = [int(v) for v in g["meta"]]
+    pm, _ = _product(backbone, ncls, O, seed=1)
+    pm.eval()
+    x, _ = O.synthetic_batch(n, hw, hw, ncls)
+    pm.set_return_features(True)
+    with torch.no_grad():
+        out, feats = pm(x.cuda())
+    assert out.shape == (n, ncls, hw, hw) and out.dtype == torch.float32 and out.is_contiguous()
+    ref = torch.from_numpy(g["logits"])
+    err = (out.cpu() - ref).abs().max().item()
+    assert err <= 1e-3, "logits max abs err %.3e" % err
+    margin = torch.from_numpy(g["margin"].astype(np.float32))
+    safe = margin > 1e-3
+    am = out.argmax(1).cpu()
+    ref_am = torch.from_numpy(g["argmax"]).long()
+    assert torch.equal(am[safe], ref_am[safe]), "argmax differs outside near-ties"
+    flips = int((am != ref_am).sum())
+    print("%s: logits err %.2e, near-tie pixels %d, argmax flips %d" % (tag, err, int((~safe).sum()), flips))
+    assert flips <= int((~safe).sum())
+    pooled = torch.nn.functional.avg_pool2d(feats.float().cpu(), 8, 4)
+    assert (pooled - torch.from_numpy(g["feat_pooled"])).abs().max().item() <= 1e-3
+
+
+def test_mc_dropout_votes_and_entropy_vs_reference_golden():
+    ops, O, S = _setup()
+    g = np.load(os.path.join(GOLD, "mc_dropout_mobilenet.npz"))
+    n, hw, ncls, T = [int(v) for v in g["meta"]]
+    pm, om = _product("mobilenet", ncls, O, seed=2)
+    pm.eval()
+    x, lab = O.synthetic_batch(n, hw, hw, ncls, first_index=50)
+    m1, m2 = O.dropout_masks(n, T, seed=3)
+    ref_votes = torch.from_numpy(g["votes"]).long()
+    # margins of the reference passes decide where exactness is demanded
+    om.eval()
+    with torch.no_grad():
+        margins = []
+        for t in range(T):
+            top = om(x, (m1[t], m2[t])).topk(2, dim=1)[0]
+            margins.append(top[:, 0] - top[:, 1])
+    safe = torch.stack(margins, 1) > 1e-3
+    # (1) hoisted fast path
+    votes = pm.mc_dropout_votes(x.cuda(), T, masks=(m1, m2)).cpu().long()
+    assert torch.equal(votes[safe], ref_votes[safe])
+    assert int((votes != ref_votes).sum()) <= int((~safe).sum())
+    # (2) the reference way: T full forwards with the same masks
+    with torch.no_grad():
+        full = torch.stack([pm(x.cuda(), dropout_masks=(m1[t].cuda(), m2[t].cuda())).argmax(1) for t in range(T)], 1).cpu()
+    assert torch.equal(full[safe], ref_votes[safe])
+    # (3) reduction kernel on the reference's own votes -> the reference's entropy maps / means
+    emap, means = ops.vote_entropy(torch.from_numpy(g["votes"]).cuda(), lab.cuda(), ncls)
+    assert (emap.cpu() - torch.from_numpy(g["entropy"])).abs().max().item() <= 1e-5
+    assert (means.cpu() - torch.from_numpy(g["mean"])).abs().max().item() <= 1e-5
+    # (4) end to end through the selector surface, scores within 1e-3 of the reference's
+    from active_selection.mc_dropout import ActiveSelectionMCDropout
+
+    sel = ActiveSelectionMCDropout(ncls, None, hw, n)
+    maps, mean2 = sel._get_vote_entropy_for_batch(pm, x.cuda(), lab.cuda(), steps=T, masks=(m1, m2), with_means=True)
+    assert len(maps) == n and maps[0].shape == (hw, hw)
+    if int((votes != ref_votes).sum()) == 0:
+        assert (mean2.cpu() - torch.from_numpy(g["mean"])).abs().max().item() <= 1e-3
+
+
+@pytest.mark.parametrize("T,C", [(10, 19), (20, 21)])
+def test_vote_entropy_scripted_golden(T, C):
+    ops, O, S = _setup()
+    g = np.load(os.path.join(GOLD, "vote_entropy_T%d_C%d.npz" % (T, C)))
+    emap, means = ops.vote_entropy(torch.from_numpy(g["votes"]).cuda(), torch.from_numpy(g["label"]).cuda(), C)
+    ref = torch.from_numpy(g["entropy"])
+    assert (emap.cpu() - ref).abs().max().item() <= 1e-5
+    assert (means.cpu() - ref.mean(dim=(1, 2))).abs().max().item() <= 1e-5
+
+
+def test_losses_vs_reference_golden():
+    ops, O, S = _setup()
+    from utils.loss import SegmentationLosses
+
+    g = np.load(os.path.join(GOLD, "loss.npz"))
+    gen = torch.Generator().manual_seed(7)
+    logit = torch.randn(2, 19, 21, 23, generator=gen) * 3
+    target = torch.randint(0, 19, (2, 21, 23), generator=gen).float()
+    target[:, :3] = 255
+    wt = torch.rand(19, generator=gen) + 0.5
+    for wname, w in (("plain", None), ("weighted", wt)):
+        crit = SegmentationLosses(weight=w, cuda=True)
+        for mode in ("ce", "focal"):
+            lg = logit.cuda().requires_grad_(True)
+            loss = crit.build_loss(mode)(lg, target.cuda())
+            loss.backward()
+            ref = float(g["%s_%s_loss" % (mode, wname)])
+            assert abs(loss.item() - ref) <= 1e-5 * max(1.0, abs(ref)), (mode, wname, loss.item(), ref)
+            gref = torch.from_numpy(g["%s_%s_grad" % (mode, wname)])
+            assert (lg.grad.cpu() - gref).abs().max().item() <= 1e-4 * max(gref.abs().max().item(), 1e-6)
+    with pytest.raises(NotImplementedError):
+        SegmentationLosses().build_loss("dice")
+    sw = torch.tensor([1.0, 0.25])
+    val = SegmentationLosses(cuda=True).SampleWeightedCrossEntropyLoss(logit.cuda(), target.cuda(), sw)
+    assert abs(val.item() - float(g["sample_weighted_loss"])) <= 1e-5
+
+
+def test_ceal_scores_vs_golden_and_selector():
+    ops, O, S = _setup()
+    g = np.load(os.path.join(GOLD, "softmax_scores.npz"))
+    gen = torch.Generator().manual_seed(8)
+    logits = torch.randn(2, 19, 17, 19, generator=gen) * 2
+    lab = torch.randint(0, 19, (2, 17, 19), generator=gen).float()
+    lab[:, :2] = 255
+    for mode, key in ((0, "conf"), (1, "margin"), (2, "entropy")):
+        smap, mean = ops.softmax_scores(logits.cuda(), lab.cuda(), 19, mode, want_map=True)
+        ref = torch.from_numpy(g[key])
+        assert (smap.cpu() - ref).abs().max().item() <= 1e-5, key
+        assert (mean.cpu() - ref.mean(dim=(1, 2))).abs().max().item() <= 1e-5
+    assert np.array_equal(ops.weak_labels(logits.cuda(), lab.cuda(), 19).cpu().numpy(), g["weak"])
+
+    # selector surface on a synthetic pool vs the oracle computing the same scores on the CPU
+    from active_selection.ceal import ActiveSelectionCEAL
+
+    pm, om = _product("mobilenet", 19, O, seed=6)
+    pm.eval()
+    om.eval()
+    keys = [("img_%03d" % i).encode("ascii") for i in range(5)]
+    pool = {k: O.synthetic_batch(1, 65, 65, 19, first_index=300 + i) for i, k in enumerate(keys)}
+
+    def factory(images, include_labels, bs=2):
+        for i in range(0, len(images), bs):
+            chunk = images[i:i + bs]
+            yield {"image": torch.cat([pool[k][0] for k in chunk]), "label": torch.cat([pool[k][1] for k in chunk])}
+
+    sel = ActiveSelectionCEAL(19, None, 65, 2, loader_factory=factory)
+    with torch.no_grad():
+        lo = torch.cat([om(pool[k][0]) for k in keys])
+    labs = torch.cat([pool[k][1] for k in keys])
+    conf, margin, ent = S.softmax_score_maps(lo, labs, 19)
+    ent_scores = [float(np.mean(e.numpy())) for e in ent]
+    got_sel, got_ent = sel.get_maximum_entropy_samples(pm, keys, 2)
+    assert np.abs(np.array(got_ent) - np.array(ent_scores)).max() <= 1e-3
+    assert list(got_sel) == S.select_top(ent_scores, keys, 2, reverse=True)
+    conf_scores = [float(torch.mean(c)) for c in conf]
+    assert list(sel.get_least_confident_samples(pm, keys, 2)) == S.select_top(conf_scores, keys, 2, reverse=False)
+    weak = sel.get_weakly_labeled_data(pm, keys, threshold=max(ent_scores) + 1, entropies=None)
+    assert set(weak.keys()) == set(keys) and weak[keys[0]].dtype == np.uint8 and weak[keys[0]].shape == (65, 65)
+
+
+def test_coreset_selector_vs_oracle():
+    ops, O, S = _setup()
+    from active_selection.core_set import ActiveSelectionCoreSet
+
+    g = np.load(os.path.join(GOLD, "kcenter.npz"))
+    cs = ActiveSelectionCoreSet(None, None, None)
+    assert cs._select_batch(g["small_feats"].astype(np.float32), [6], 5) == g["small_picks"].tolist() == [0, 2, 8, 4, 7]
+    big = np.asarray(O._hash_uniform(300 * 2736, 99), dtype=np.float32).reshape(300, 2736)
+    assert cs._select_batch(big, list(range(10)), 25) == g["big_picks"].tolist()
+
+    pm, om = _product("mobilenet", 19, O, seed=9)
+    pm.eval()
+    om.eval()
+    keys = [("img_%03d" % i).encode("ascii") for i in range(6)]
+    pool = {k: O.synthetic_batch(1, 257, 257, 19, first_index=400 + i)[0] for i, k in enumerate(keys)}
+
+    def factory(images, include_labels, bs=2):
+        for i in range(0, len(images), bs):
+            yield torch.cat([pool[k] for k in images[i:i + bs]])
+
+    class Wrapper(torch.nn.Module):  # selectors receive a DataParallel-style wrapper with .module
+        def __init__(self, m):
+            super().__init__()
+            self.module = m
+
+        def forward(self, x):
+            return self.module(x)
+
+    sel = ActiveSelectionCoreSet(None, 257, 2, loader_factory=factory)
+    got = sel.get_k_center_greedy_selections(2, Wrapper(pm), keys[2:], keys[:2])
+    om.return_features = True
+    with torch.no_grad():
+        feats = torch.cat([om(pool[k])[1] for k in keys])
+    f64 = S.coreset_features(feats, 64)
+    assert f64.shape == (6, 2736)
+    picks, _ = S.kcenter_greedy(f64, [0, 1], 2)
+    assert got == [keys[i] for i in picks]
+    assert pm.return_features is False
+
+
+def test_region_selection_vs_reference_golden():
+    ops, O, S = _setup()
+    from active_selection.mc_dropout import ActiveSelectionMCDropout
+
+    g = np.load(os.path.join(GOLD, "nms_png.npz"))
+    imgs = torch.stack([torch.from_numpy(g["img0"].astype(np.float32) / 256), torch.from_numpy(g["img1"].astype(np.float32) / 256)])
+    maps = ops.box_sum(imgs.cuda(), 127)
+    ops.minmax_normalize_(maps)
+    regions, count = ActiveSelectionMCDropout.square_nms(maps, 127, (512 * 512) // (127 * 127))
+    assert count == int(g["count"])
+    assert regions[0] == [tuple(r) for r in g["regions0"].tolist()]
+    assert regions[1] == [tuple(r) for r in g["regions1"].tolist()]
+    em = torch.rand(40, 40)
+    ref = S.suppress_labeled(em.clone(), [(3, 4, 10, 12), (30, 30, 10, 10)])
+    emd = em.clone().cuda()
+    ActiveSelectionMCDropout.suppress_labeled_entropy(emd, [(3, 4, 10, 12), (30, 30, 10, 10)])
+    assert torch.equal(emd.cpu(), ref)
+
+
+def test_train_two_steps_vs_reference_golden():
+    """forward (train-mode BN) + CE + backward + SGD, twice, against the reference's recorded losses and
+    weights (G12) and against the oracle's first-step gradients."""
+    ops, O, S = _setup()
+    from utils.loss import SegmentationLosses
+
+    g = np.load(os.path.join(GOLD, "train2_mobilenet.npz"))
+    ncls, n, hw = 19, 2, 97
+    pm, om = _product("mobilenet", ncls, O, seed=4, randomize_bn_stats=False)
+    pm.train()
+    om.train()
+    x, lab = O.synthetic_batch(n, hw, hw, ncls, first_index=200)
+    m1, m2 = O.dropout_masks(n, 2, seed=5)
+    crit = SegmentationLosses(cuda=True).build_loss("ce")
+    lr = 0.01
+    opt = torch.optim.SGD([{"params": pm.get_1x_lr_params(), "lr": lr}, {"params": pm.get_10x_lr_params(), "lr": lr * 10}],
+                          momentum=0.9, weight_decay=5e-4, nesterov=False)
+    # oracle first-step gradients
+    lo = S.ce_loss(om(x, (m1[0], m2[0])), lab)
+    lo.backward()
+    ograd = {k: p.grad.clone() for k, p in om.named_parameters()}
+    losses = []
+    for step in range(2):
+        opt.zero_grad()
+        loss = crit(pm(x.cuda(), dropout_masks=(m1[step].cuda(), m2[step].cuda())), lab.cuda())
+        loss.backward()
+        if step == 0:
+            worst = 0.0
+            for k, p in pm.named_parameters():
+                ref = ograd[k]
+                rel = (p.grad.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+                worst = max(worst, rel)
+                assert rel <= 2e-2, "grad %s rel err %.3e" % (k, rel)
+            print("first-step gradient worst rel err vs oracle: %.3e" % worst)
+        opt.step()
+        losses.append(loss.item())
+    ref_losses = g["losses"]
+    assert abs(losses[0] - ref_losses[0]) <= 1e-4 * abs(ref_losses[0]), (losses, ref_losses)
+    assert abs(losses[1] - ref_losses[1]) <= 2e-3 * abs(ref_losses[1]), (losses, ref_losses)
+    sd = pm.state_dict()
+    for key in g.files:
+        if key == "losses" or key.startswith("init__"):
+            continue
+        name = key.replace("__", ".")
+        got = sd[name].detach().float().cpu().reshape(-1)[:4096]
+        ref = torch.from_numpy(g[key])
+        init = torch.from_numpy(g["init__" + key])
+        upd = max((ref - init).abs().max().item(), 1e-3)
+        rel = (got - ref).abs().max().item() / upd
+        assert rel <= 5e-2, "%s differs from the reference after 2 SGD steps: %.3e of the update" % (name, rel)
+    assert int(sd["decoder.bn1.num_batches_tracked"]) == 2
