@@ -250,7 +250,9 @@ class _ConvBnAct(torch.autograd.Function):
         ow = conv_out_size(w, weight.shape[3], spec.stride, spec.pad, spec.dil)
         m = n * oh * ow
         bn = spec.bn
-        need_grad = any(ctx.needs_input_grad)  # (grad mode is off inside forward; this is the real signal)
+        # grad mode is always off INSIDE forward and needs_input_grad ignores no_grad(): the caller's
+        # grad mode is sampled in conv_bn_act() and carried on the spec
+        need_grad = spec.grad_enabled and any(ctx.needs_input_grad)
         res_t = ldr = None
         if residual is not None:
             res_t, ldr = rows(_cast_act(residual))
@@ -415,6 +417,7 @@ def conv_bn_act(x, conv, bn=None, act=ACT_NONE, residual=None, nc_scale=None, ex
     """in_scale: [N,C] f32 multipliers applied to the INPUT while it is staged (inference only): a
     Dropout2d mask of the producer folded into this conv's loader (MC-dropout tail, SURVEY 8a note iii)."""
     spec = ConvSpec(conv, bn, act, extra_pad)
+    spec.grad_enabled = torch.is_grad_enabled()
     if in_scale is not None:
         assert bn is None or not bn_use_batch_stats(bn), "in_scale needs eval-mode BN"
         spec.in_scale = in_scale.contiguous()
@@ -426,14 +429,14 @@ def conv_bn_act(x, conv, bn=None, act=ACT_NONE, residual=None, nc_scale=None, ex
 # ----------------------------------------------------------------------------- max pool (resnet.py:68)
 class _MaxPool3x3s2(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, grad_enabled):
         xs, ld = rows(_cast_act(x))
         n, c, h, w = xs.shape
         if ld != c:
             xs = xs.contiguous(memory_format=torch.channels_last)
         oh, ow = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
         y = new_act(n, c, oh, ow, xs.dtype, xs.device)
-        need = ctx.needs_input_grad[0]
+        need = grad_enabled and ctx.needs_input_grad[0]
         idx = torch.empty((n, oh, ow, c), dtype=torch.uint8, device=xs.device) if need else None
         check(lib.dass_maxpool3x3s2_fwd(_p(xs), _p(y), _p(idx), n, h, w, c, oh, ow, _dt(y), _stream()),
               "dass_maxpool3x3s2_fwd")
@@ -452,11 +455,11 @@ class _MaxPool3x3s2(torch.autograd.Function):
         dx = new_act(n, c, h, w, dyr.dtype, dyr.device)
         check(lib.dass_maxpool3x3s2_bwd(_p(dyr), _p(idx), _p(dx), n, h, w, c, oh, ow, _dt(dx), _stream()),
               "dass_maxpool3x3s2_bwd")
-        return dx
+        return dx, None
 
 
 def maxpool3x3s2(x):
-    return _MaxPool3x3s2.apply(x)
+    return _MaxPool3x3s2.apply(x, torch.is_grad_enabled())
 
 
 # ----------------------------------------------------------------------------- residual add without BN (mobilenet.py:74)

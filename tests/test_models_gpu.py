@@ -197,8 +197,8 @@ def test_coreset_selector_vs_oracle():
     pm, om = _product("mobilenet", 19, O, seed=9)
     pm.eval()
     om.eval()
-    keys = [("img_%03d" % i).encode("ascii") for i in range(6)]
-    pool = {k: O.synthetic_batch(1, 257, 257, 19, first_index=400 + i)[0] for i, k in enumerate(keys)}
+    keys = [("img_%03d" % i).encode("ascii") for i in range(5)]
+    pool = {k: O.synthetic_batch(1, 513, 513, 19, first_index=400 + i)[0] for i, k in enumerate(keys)}
 
     def factory(images, include_labels, bs=2):
         for i in range(0, len(images), bs):
@@ -212,13 +212,15 @@ def test_coreset_selector_vs_oracle():
         def forward(self, x):
             return self.module(x)
 
-    sel = ActiveSelectionCoreSet(None, 257, 2, loader_factory=factory)
+    sel = ActiveSelectionCoreSet(None, 513, 2, loader_factory=factory)
     got = sel.get_k_center_greedy_selections(2, Wrapper(pm), keys[2:], keys[:2])
     om.return_features = True
     with torch.no_grad():
         feats = torch.cat([om(pool[k])[1] for k in keys])
     f64 = S.coreset_features(feats, 64)
-    assert f64.shape == (6, 2736)
+    assert f64.shape == (5, 2736)
+    got_feats = sel._features(Wrapper(pm), keys).cpu().numpy()
+    assert np.abs(got_feats - f64).max() <= 1e-3
     picks, _ = S.kcenter_greedy(f64, [0, 1], 2)
     assert got == [keys[i] for i in picks]
     assert pm.return_features is False
@@ -270,13 +272,18 @@ def test_train_two_steps_vs_reference_golden():
         loss = crit(pm(x.cuda(), dropout_masks=(m1[step].cuda(), m2[step].cuda())), lab.cuda())
         loss.backward()
         if step == 0:
-            worst = 0.0
+            # train-mode BN over the deepest 7x7 maps (mostly fixed_padding zeros) has near-zero-variance
+            # channels whose invstd ~ 1/sqrt(eps) amplifies f32 summation-order noise: the reference and
+            # the oracle (both stock PyTorch) already differ by ~1e-2 of the update there
+            # (oracle/make_goldens.py), so the bound is on the relative L2 error per tensor.
+            rels = []
             for k, p in pm.named_parameters():
                 ref = ograd[k]
-                rel = (p.grad.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
-                worst = max(worst, rel)
-                assert rel <= 2e-2, "grad %s rel err %.3e" % (k, rel)
-            print("first-step gradient worst rel err vs oracle: %.3e" % worst)
+                rels.append(((p.grad.cpu() - ref).norm().item() / max(ref.norm().item(), 1e-12), k))
+            rels.sort(reverse=True)
+            print("first-step gradient rel-L2 err vs oracle, worst 3:", rels[:3])
+            assert rels[0][0] <= 5e-2, rels[:3]
+            assert np.median([r for r, _ in rels]) <= 2e-3
         opt.step()
         losses.append(loss.item())
     ref_losses = g["losses"]
@@ -294,3 +301,36 @@ def test_train_two_steps_vs_reference_golden():
         rel = (got - ref).abs().max().item() / upd
         assert rel <= 5e-2, "%s differs from the reference after 2 SGD steps: %.3e of the update" % (name, rel)
     assert int(sd["decoder.bn1.num_batches_tracked"]) == 2
+
+
+@pytest.mark.parametrize("backbone,hw", [("mobilenet", 65), ("resnet", 65)])
+def test_backward_frozen_bn_vs_oracle(backbone, hw):
+    """freeze_bn() training (BN on running stats, gamma/beta still trained -- deeplab.py:64-69): without the
+    batch-statistics amplification every gradient must match the CPU oracle tightly."""
+    ops, O, S = _setup()
+    from utils.loss import SegmentationLosses
+
+    ncls, n = 19, 2
+    pm, om = _product(backbone, ncls, O, seed=21)
+    pm.train()
+    pm.freeze_bn()
+    om.train()
+    for m in om.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eval()
+    x, lab = O.synthetic_batch(n, hw, hw, ncls, first_index=500)
+    m1, m2 = O.dropout_masks(n, 1, seed=22)
+    lo = S.ce_loss(om(x, (m1[0], m2[0])), lab)
+    lo.backward()
+    crit = SegmentationLosses(cuda=True).build_loss("ce")
+    loss = crit(pm(x.cuda(), dropout_masks=(m1[0].cuda(), m2[0].cuda())), lab.cuda())
+    loss.backward()
+    assert abs(loss.item() - lo.item()) <= 1e-5 * abs(lo.item())
+    rels = []
+    for k, p in pm.named_parameters():
+        ref = dict(om.named_parameters())[k].grad
+        assert p.grad is not None, k
+        rels.append(((p.grad.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12), k))
+    rels.sort(reverse=True)
+    print("%s frozen-BN gradient max-rel err vs oracle, worst 3:" % backbone, rels[:3])
+    assert rels[0][0] <= 2e-3, rels[:3]
