@@ -1,0 +1,269 @@
+#!/usr/bin/env python
+"""bench.py -- DeepLab-v3+ ResNet-101 513x513 training + MC-dropout pool scoring on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one synthetic batch: zero_grad -> forward -> CE loss -> backward
+-> (N>1: RCCL gradient all-reduce) -> SGD step on DeepLab-R101 os16, 19 classes, 513x513, per-GPU batch 8
+(the configuration BASELINE.json's metric is quoted on).  Inputs are generated
+from per-image seeds and are resident in HBM before the timed region.  W untimed warm-up steps, then
+EXACTLY K timed steps between barrier + synchronize; the max over ranks is reported by rank 0 as ONE
+JSON line.  The same line carries
+  mc_dropout : pool-images/s of the T=10 MC-dropout vote-entropy scoring call on the same model,
+  roofline   : the dominant kernel (implicit-GEMM conv, decoder 3x3 304->256 @129^2 shape) timed live
+               with events on the launch stream against the f32 MFMA peak,
+  cpu_baseline: the CPU oracle (stock PyTorch fp32 restatement, oracle/) timed on this box's host cores
+               on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "deep-active-semantic-segmentation_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+TRAIN_GFLOP_PER_IMAGE = 556.9  # 3 x 92.81 GMAC x 2 (R101 os16 513^2)
+MC_GFLOP_PER_IMAGE = 573.6     # 2 x (71.26 + 10 x 21.55) GMAC, T=10
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch")
+    ap.add_argument("--size", type=int, default=513)
+    ap.add_argument("--backbone", default="resnet101")
+    ap.add_argument("--classes", type=int, default=19)
+    ap.add_argument("--mc-steps", type=int, default=10, help="T of the MC-dropout scoring leg")
+    ap.add_argument("--mc-batches", type=int, default=3, help="timed scoring batches per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mc", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def synthetic_batch(n, h, w, num_classes, first_index):
+    imgs, labs = [], []
+    for i in range(n):
+        g = torch.Generator().manual_seed(1000 + first_index + i)
+        imgs.append(torch.randn(3, h, w, generator=g))
+        lab = torch.randint(0, num_classes, (h, w), generator=g).float()
+        lab[: h // 10] = 255
+        labs.append(lab)
+    return torch.stack(imgs), torch.stack(labs)
+
+
+def allreduce_grads(params, world):
+    """DDP-style gradient averaging: flat f32 buckets, one RCCL all-reduce each (xGMI)."""
+    import torch.distributed as dist
+
+    bucket, size, works = [], 0, []
+    cap = 64 * 1024 * 1024 // 4
+
+    def flush():
+        nonlocal bucket, size
+        if not bucket:
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in bucket])
+        works.append((dist.all_reduce(flat, async_op=True), flat, bucket))
+        bucket, size = [], 0
+
+    for p in params:
+        if p.grad is None:
+            continue
+        bucket.append(p)
+        size += p.grad.numel()
+        if size >= cap:
+            flush()
+    flush()
+    for work, flat, ps in works:
+        work.wait()
+        flat.div_(world)
+        off = 0
+        for p in ps:
+            n = p.grad.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")  # RCCL on ROCm
+
+    from dass_hip import ops
+    from models.deeplab import DeepLab
+    from utils.loss import SegmentationLosses
+    from active_selection.mc_dropout import ActiveSelectionMCDropout
+
+    ops.set_compute_dtype(torch.float32)
+    torch.manual_seed(1234)  # identical random-init weights on every rank
+    model = DeepLab(backbone=args.backbone, output_stride=16, num_classes=args.classes, sync_bn=False,
+                    freeze_bn=False, pretrained=False).to(dev)
+    criterion = SegmentationLosses(cuda=True).build_loss("ce")
+    lr = 0.01
+    optimizer = torch.optim.SGD([{"params": model.get_1x_lr_params(), "lr": lr},
+                                 {"params": model.get_10x_lr_params(), "lr": lr * 10}],
+                                momentum=0.9, weight_decay=5e-4, nesterov=False)
+    params = [p for g in optimizer.param_groups for p in g["params"]]
+    b, s = args.batch, args.size
+    image, target = synthetic_batch(b, s, s, args.classes, first_index=rank * b)
+    image, target = image.to(dev), target.to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def train_step():
+        optimizer.zero_grad(set_to_none=True)
+        out = model(image)
+        loss = criterion(out, target)
+        loss.backward()
+        if dist is not None:
+            allreduce_grads(params, world)
+        optimizer.step()
+        return loss
+
+    model.train()
+    for _ in range(args.warmup):
+        train_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    final_loss = float(loss)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    train_ips = b * world * args.steps / dt
+
+    # ------------------------------------------------------------------ MC-dropout pool scoring (T passes)
+    mc = None
+    if not args.no_mc:
+        model.eval()
+        nb = args.mc_batches
+        pool_keys = [("pool_%06d" % i).encode("ascii") for i in range(world * nb * b)]
+        # this rank's shard, resident in HBM before timing (per-image seeds: content independent of sharding)
+        from active_selection.base import shard_bounds
+
+        s0, s1 = shard_bounds(len(pool_keys), rank, world)
+        shard = {}
+        for gi in range(s0, s1):
+            im, lb = synthetic_batch(1, s, s, args.classes, first_index=100000 + gi)
+            shard[pool_keys[gi]] = (im.to(dev), lb.to(dev))
+
+        def factory(images, include_labels):
+            for i in range(0, len(images), b):
+                chunk = images[i:i + b]
+                yield {"image": torch.cat([shard[k][0] for k in chunk]), "label": torch.cat([shard[k][1] for k in chunk])}
+
+        selector = ActiveSelectionMCDropout(args.classes, None, s, b, loader_factory=factory)
+        selector.get_vote_entropy_for_images(model, pool_keys[: world * b] if world == 1 else pool_keys, 1, steps=args.mc_steps)  # warm-up
+        barrier()
+        t0 = time.perf_counter()
+        selected = selector.get_vote_entropy_for_images(model, pool_keys, max(1, len(pool_keys) // 8), steps=args.mc_steps)
+        barrier()
+        dts = time.perf_counter() - t0
+        tmax = torch.tensor([dts], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dts = float(tmax.item())
+        pool_ips = len(pool_keys) / dts
+        mc = {"metric": "mc_dropout_pool_images_per_s", "value": round(pool_ips, 3), "unit": "images/s", "T": args.mc_steps,
+              "pool_images": len(pool_keys), "seconds": round(dts, 4), "selected": len(selected),
+              "frac_of_f32_mfma_peak": round(pool_ips * MC_GFLOP_PER_IMAGE / 1e3 / (F32_MFMA_PEAK_TFLOPS * world), 4),
+              "sharding": "contiguous key shards per rank + RCCL all_gather of per-image scores" if world > 1 else "single rank"}
+
+    # ------------------------------------------------------------------ roofline of the dominant kernel
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        n_, h_, c_, k_ = b, (s + 3) // 4, 304, 256  # decoder.last_conv.0: 3x3 304->256 @129^2, the largest single layer
+        x = torch.randn((n_, h_, h_, c_), device=dev)
+        w = torch.randn((k_, 3, 3, c_), device=dev) * 0.02
+        y = torch.empty((n_, h_, h_, k_), device=dev)
+        dims = (n_, h_, h_, c_, h_, h_, k_, 3, 3, 1, 1, 1)
+        for _ in range(3):
+            ops.conv_launch(x, c_, w, y, k_, dims)
+        reps = 20
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            ops.conv_launch(x, c_, w, y, k_, dims)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        flops = 2.0 * n_ * h_ * h_ * k_ * 9 * c_
+        achieved = flops / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<float,128,128,2,2> (3x3 304->256 @%dx%d, batch %d)" % (h_, h_, n_),
+                "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launch_ms": round(ms, 4), "flops_per_launch": flops,
+                "train_step_frac": round(train_ips * TRAIN_GFLOP_PER_IMAGE / 1e3 / (F32_MFMA_PEAK_TFLOPS * world), 4)}
+
+    # ------------------------------------------------------------------ CPU baseline (oracle, bounded sample)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import deeplab_cpu as O
+        from oracle import selection_cpu as S
+
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        om = O.ODeepLab(args.backbone, 16, args.classes)
+        om.train()
+        oopt = torch.optim.SGD(om.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
+        xs, ls = synthetic_batch(1, 65, 65, args.classes, 0)
+        S.ce_loss(om(xs), ls).backward()  # thread-pool / allocator warm-up on a tiny input
+        cb = 2
+        xc, lc = synthetic_batch(cb, s, s, args.classes, 0)
+        t0 = time.perf_counter()
+        oopt.zero_grad()
+        lo = S.ce_loss(om(xc), lc)
+        lo.backward()
+        oopt.step()
+        dtc = time.perf_counter() - t0
+        cpu = {"value": round(cb / dtc, 4), "unit": "images/s", "cores": cores, "kind": "port",
+               "sample": "1 train step (fwd+CE+bwd+SGD), batch %d, %s %dx%d, stock PyTorch CPU fp32 (oracle/deeplab_cpu.py), %.1f s"
+                         % (cb, args.backbone, s, s, dtc)}
+
+    if rank == 0:
+        line = {"metric": "train_images_per_s (DeepLab-v3+ R101 513x513; + mc_dropout pool-images/s in 'mc_dropout')",
+                "value": round(train_ips, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "DeepLab-v3+ %s os16 %d-class %dx%d train step (fwd+CE+bwd+SGD), per-GPU batch %d"
+                                       % (args.backbone, args.classes, s, s, b),
+                           "global_batch": b * world, "parallelism": "dp%d" % world, "bn": "per-GPU",
+                           "final_loss": round(final_loss, 5)},
+                "mc_dropout": mc, "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
