@@ -95,6 +95,16 @@ def allreduce_grads(params, world):
             off += n
 
 
+def log(msg):
+    """progress to stderr and (when present) gpurun_out/: a silent run is taken for a hung one"""
+    line = "[bench %s] %s" % (time.strftime("%H:%M:%S"), msg)
+    print(line, file=sys.stderr, flush=True)
+    d = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "bench_progress.log"), "a") as f:
+            f.write(line + "\n")
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -146,20 +156,26 @@ def main():
         return loss
 
     model.train()
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
+        tw = time.perf_counter()
         train_step()
+        torch.cuda.synchronize()
+        if rank == 0:
+            log("warm-up step %d: %.1f ms" % (i, (time.perf_counter() - tw) * 1e3))
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = train_step()
     barrier()
     dt = time.perf_counter() - t0
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     train_ips = b * world * args.steps / dt
+    if rank == 0:
+        log("train: %.2f images/s (%.1f ms/step)" % (train_ips, dt / args.steps * 1e3))
 
     # ------------------------------------------------------------------ MC-dropout pool scoring (T passes)
     mc = None
@@ -193,6 +209,8 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dts = float(tmax.item())
         pool_ips = len(pool_keys) / dts
+        if rank == 0:
+            log("mc-dropout T=%d: %.2f pool images/s" % (args.mc_steps, pool_ips))
         mc = {"metric": "mc_dropout_pool_images_per_s", "value": round(pool_ips, 3), "unit": "images/s", "T": args.mc_steps,
               "pool_images": len(pool_keys), "seconds": round(dts, 4), "selected": len(selected),
               "frac_of_f32_mfma_peak": round(pool_ips * MC_GFLOP_PER_IMAGE / 1e3 / (F32_MFMA_PEAK_TFLOPS * world), 4),
@@ -219,6 +237,7 @@ def main():
         ms = e0.elapsed_time(e1) / reps
         flops = 2.0 * n_ * h_ * h_ * k_ * 9 * c_
         achieved = flops / (ms * 1e-3) / 1e12
+        log("dominant conv kernel: %.3f ms/launch = %.1f TFLOP/s" % (ms, achieved))
         roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<float,128,128,2,2> (3x3 304->256 @%dx%d, batch %d)" % (h_, h_, n_),
                 "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
@@ -231,14 +250,20 @@ def main():
         from oracle import deeplab_cpu as O
         from oracle import selection_cpu as S
 
-        cores = os.cpu_count() or 1
+        # the box's CPU share, not the host's core count: oversubscribing a cgroup-limited box stalls for minutes
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        cores = max(1, min(cores, 16))
+        log("cpu baseline on %d cores ..." % cores)
         torch.set_num_threads(cores)
         om = O.ODeepLab(args.backbone, 16, args.classes)
         om.train()
         oopt = torch.optim.SGD(om.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
         xs, ls = synthetic_batch(1, 65, 65, args.classes, 0)
         S.ce_loss(om(xs), ls).backward()  # thread-pool / allocator warm-up on a tiny input
-        cb = 2
+        cb = 1
         xc, lc = synthetic_batch(cb, s, s, args.classes, 0)
         t0 = time.perf_counter()
         oopt.zero_grad()
