@@ -1,0 +1,287 @@
+"""CPU suite (python -m pytest tests -m "not gpu"): the oracle against the reference-generated golden
+fixtures, the host-side logic, the C-ABI surface (loads, exports every declared symbol, argument checks
+that return before any launch) and the world_size-2 sharding path over gloo.  No GPU compute here."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+from oracle import deeplab_cpu as O  # noqa: E402
+from oracle import selection_cpu as S  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- oracle vs reference goldens
+@pytest.mark.parametrize("tag,backbone", [("mobilenet", "mobilenet"), ("resnet50", "resnet")])
+def test_oracle_e2e_matches_reference_golden(tag, backbone):
+    g = np.load(os.path.join(GOLD, "e2e_%s.npz" % tag))
+    n, hw, ncls = [int(v) for v in g["meta"]]
+    om = O.ODeepLab(backbone, 16, ncls)
+    O.fill_state_dict(om, seed=1)
+    om.eval()
+    om.return_features = True
+    x, _ = O.synthetic_batch(n, hw, hw, ncls)
+    with torch.no_grad():
+        out, feats = om(x)
+    assert (out - torch.from_numpy(g["logits"])).abs().max().item() <= 1e-4
+    margin = torch.from_numpy(g["margin"].astype(np.float32))
+    safe = margin > 1e-3
+    assert torch.equal(out.argmax(1)[safe], torch.from_numpy(g["argmax"]).long()[safe])
+    pooled = torch.nn.functional.avg_pool2d(feats, 8, 4)
+    assert (pooled - torch.from_numpy(g["feat_pooled"])).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("T,C", [(10, 19), (20, 21)])
+def test_oracle_vote_entropy_golden(T, C):
+    g = np.load(os.path.join(GOLD, "vote_entropy_T%d_C%d.npz" % (T, C)))
+    maps = S.vote_entropy_maps(torch.from_numpy(g["votes"]).long(), torch.from_numpy(g["label"]), C)
+    assert (torch.stack(maps) - torch.from_numpy(g["entropy"])).abs().max().item() == 0.0
+    # properties: unanimous votes -> 0, a 50/50 split -> exactly 1 bit, masked rows -> 0
+    assert float(torch.stack(maps)[:, :6].abs().max()) < 1e-9
+    assert abs(float(maps[0][6:12].max()) - 1.0) < 1e-6 and abs(float(maps[0][6:12].min()) - 1.0) < 1e-6
+    assert float(torch.stack(maps)[:, 20:].abs().max()) == 0.0
+
+
+def test_oracle_mc_dropout_golden():
+    g = np.load(os.path.join(GOLD, "mc_dropout_mobilenet.npz"))
+    n, hw, ncls, T = [int(v) for v in g["meta"]]
+    om = O.ODeepLab("mobilenet", 16, ncls)
+    O.fill_state_dict(om, seed=2)
+    om.eval()
+    x, lab = O.synthetic_batch(n, hw, hw, ncls, first_index=50)
+    m1, m2 = O.dropout_masks(n, T, seed=3)
+    assert set(m1.unique().tolist()) <= {0.0, 2.0} and all(abs(v - 4.0 / 3) < 1e-6 or v == 0 for v in m2.unique().tolist())
+    votes = S.mc_votes(om, x, (m1, m2))
+    ref = torch.from_numpy(g["votes"]).long()
+    assert float((votes != ref).float().mean()) <= 1e-4
+    maps = S.vote_entropy_maps(ref, lab, ncls)
+    assert (torch.stack(maps) - torch.from_numpy(g["entropy"])).abs().max().item() == 0.0
+    # deterministic-prefix hoist (SURVEY 8a i-iii): masks folded as input scales == full stochastic forward
+    with torch.no_grad():
+        hi, low = om.backbone(x)
+        a = om.aspp(hi, None)
+        lowf = torch.relu(om.decoder.bn1(om.decoder.conv1(low)))
+        feats = torch.cat((torch.nn.functional.interpolate(a, size=lowf.shape[2:], mode="bilinear", align_corners=True), lowf), 1)
+        lc = om.decoder.last_conv
+        for t in range(2):
+            scale = torch.cat((m1[t], torch.ones(n, 48)), 1)[:, :, None, None]
+            y = torch.relu(lc[4](lc[3](torch.relu(lc[1](lc[0](feats * scale))))))
+            low_res = lc[7](y * m2[t][:, :, None, None])
+            out = torch.nn.functional.interpolate(low_res, size=x.shape[2:], mode="bilinear", align_corners=True)
+            full = om(x, (m1[t], m2[t]))
+            assert (out - full).abs().max().item() <= 1e-4
+
+
+def test_oracle_losses_golden():
+    g = np.load(os.path.join(GOLD, "loss.npz"))
+    gen = torch.Generator().manual_seed(7)
+    logit = torch.randn(2, 19, 21, 23, generator=gen) * 3
+    target = torch.randint(0, 19, (2, 21, 23), generator=gen).float()
+    target[:, :3] = 255
+    wt = torch.rand(19, generator=gen) + 0.5
+    for wname, w in (("plain", None), ("weighted", wt)):
+        for mode, fn in (("ce", S.ce_loss), ("focal", S.focal_loss)):
+            lg = logit.clone().requires_grad_(True)
+            loss = fn(lg, target, w)
+            loss.backward()
+            assert abs(float(loss.detach()) - float(g["%s_%s_loss" % (mode, wname)])) <= 1e-6
+            assert (lg.grad - torch.from_numpy(g["%s_%s_grad" % (mode, wname)])).abs().max().item() <= 1e-7
+    assert abs(float(S.sample_weighted_ce_loss(logit, target, torch.tensor([1.0, 0.25]))) - float(g["sample_weighted_loss"])) <= 1e-6
+
+
+def test_oracle_softmax_scores_kcenter_nms_golden():
+    g = np.load(os.path.join(GOLD, "softmax_scores.npz"))
+    gen = torch.Generator().manual_seed(8)
+    logits = torch.randn(2, 19, 17, 19, generator=gen) * 2
+    lab = torch.randint(0, 19, (2, 17, 19), generator=gen).float()
+    lab[:, :2] = 255
+    conf, margin, ent = S.softmax_score_maps(logits, lab, 19)
+    for got, key in ((conf, "conf"), (margin, "margin"), (ent, "entropy")):
+        assert np.abs(got.numpy() - g[key]).max() <= 1e-6
+    assert np.array_equal(S.weak_label_maps(logits, lab, 19), g["weak"])
+    k = np.load(os.path.join(GOLD, "kcenter.npz"))
+    assert S.kcenter_greedy(k["small_feats"].astype(np.float64), [6], 5)[0] == k["small_picks"].tolist() == [0, 2, 8, 4, 7]
+    big = np.asarray(O._hash_uniform(300 * 2736, 99), dtype=np.float64).reshape(300, 2736)
+    assert S.kcenter_greedy(big, list(range(10)), 25)[0] == k["big_picks"].tolist()
+    nm = np.load(os.path.join(GOLD, "nms_png.npz"))
+    maps = torch.stack([S.box_sum(torch.from_numpy(nm[key].astype(np.float32) / 256), 127) for key in ("img0", "img1")])
+    S.minmax_normalize(maps)
+    regions, count = S.square_nms(maps, 127, (512 * 512) // (127 * 127))
+    assert count == int(nm["count"]) == 10
+    assert regions[0] == [tuple(r) for r in nm["regions0"].tolist()] and regions[1] == [tuple(r) for r in nm["regions1"].tolist()]
+    assert regions[0][0] == (18, 72, 127, 127)
+
+
+def test_hash_fill_is_stable():
+    u = O._hash_uniform(5, 7)
+    assert u.dtype == np.float32 and np.all((u >= 0) & (u < 1))
+    assert np.array_equal(u, O._hash_uniform(5, 7)) and not np.array_equal(u, O._hash_uniform(5, 8))
+    om = O.ODeepLab("mobilenet", 16, 19)
+    O.fill_state_dict(om, seed=1)
+    w = om.state_dict()["decoder.last_conv.7.weight"]
+    assert abs(float(w.flatten()[0]) - float(np.float32((O._hash_uniform(w.numel(), (__import__("zlib").crc32(b"decoder.last_conv.7.weight") + 1000003) & 0x7FFFFFFF)[0] * 2 - 1) * (6.0 / 256) ** 0.5))) < 1e-7
+
+
+# ----------------------------------------------------------------------------- C-ABI surface
+def test_abi_exports_every_declared_symbol():
+    from dass_hip import _lib
+
+    header = open(os.path.join(ROOT, "include", "dass_hip.h")).read()
+    declared = set(re.findall(r"\b(dass_\w+)\s*\(", re.sub(r"/\*.*?\*/", "", header, flags=re.S)))
+    assert declared == set(_lib.PROTOTYPES) and len(declared) >= 45
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = set(re.findall(r"\bT (dass_\w+)", out))
+    assert declared <= exported, declared - exported
+    assert _lib.lib.dass_arch() == b"gfx950" and _lib.lib.dass_version() >= 1
+    # the library is built for gfx950 only
+    assert b"gfx950" in open(_lib.LIB_PATH, "rb").read()
+
+
+def test_abi_argument_checks_without_gpu():
+    """entry points validate shapes/alignment/null pointers and return DASS_ERR_ARG before any HIP call"""
+    from dass_hip import _lib
+
+    L = _lib.lib
+    assert L.dass_stat_rows(1) == 1 and L.dass_stat_rows(128) == 1 and L.dass_stat_rows(129) == 2
+    assert L.dass_score_blocks() == 64
+    assert L.dass_conv2d_igemm(None, 4, None, None, 4, None, None, None, 0, None, 1, 8, 8, 4, 8, 8, 4, 1, 1, 1, 0, 1, 1, 0, 0, None) == 1
+    assert L.dass_channel_stats(None, 4, 10, 4, None, 0, None) == 1
+    assert L.dass_ce_fwd(None, None, 1, None, 1, 19, 10, 255, None, None) == 1
+    assert L.dass_vote_entropy(None, None, 1, 10, 10, 19, None, None, None, None) == 1
+    with pytest.raises(RuntimeError):
+        _lib.check(1, "dass_conv2d_igemm")
+
+
+def test_product_fails_loudly_without_gpu_or_library(tmp_path):
+    from dass_hip import _lib, ops
+
+    with pytest.raises(ImportError):
+        _lib.load(str(tmp_path / "missing.so"))
+    from models.deeplab import DeepLab
+
+    m = DeepLab(backbone="mobilenet", num_classes=19, sync_bn=False, pretrained=False)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        m(torch.zeros(1, 3, 33, 33))
+    # the product never imports the oracle
+    pkg = os.path.join(ROOT, "deep-active-semantic-segmentation_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                assert "oracle" not in open(os.path.join(dirpath, f)).read().replace("oracle/", ""), f
+
+
+# ----------------------------------------------------------------------------- host logic of the mirror surface
+def test_surface_matches_reference_names():
+    from models.aspp import ASPP
+    from models.decoder import Decoder
+    from models.deeplab import DeepLab
+    from models.backbone import build_backbone
+    from utils.loss import SegmentationLosses
+    import active_selection
+    import constants
+
+    assert constants.MC_DROPOUT_RATE == 0.25 and constants.MC_STEPS == 20
+    m = DeepLab(backbone="mobilenet", output_stride=16, num_classes=21, sync_bn=True, freeze_bn=True, pretrained=False)
+    assert m.model_name == "deeplab" and m.return_features is False and m.noisy_features is False
+    assert all(not b.training for b in m.modules() if isinstance(b, torch.nn.BatchNorm2d))  # freeze_bn
+    om = O.ODeepLab("mobilenet", 16, 21)
+    assert list(m.state_dict().keys()) == list(om.state_dict().keys())
+    assert all(tuple(a.shape) == tuple(b.shape) for a, b in zip(m.state_dict().values(), om.state_dict().values()))
+    n1, n10 = len(list(m.get_1x_lr_params())), len(list(m.get_10x_lr_params()))
+    assert n1 + n10 == len(list(m.parameters())) and n1 > 0 and n10 > 0
+    with pytest.raises(Exception, match="Unknown backbone"):
+        ASPP("vgg", 16, torch.nn.BatchNorm2d)
+    with pytest.raises(NotImplementedError):
+        ASPP("mobilenet", 4, torch.nn.BatchNorm2d)
+    with pytest.raises(NotImplementedError):
+        Decoder(19, "vgg", torch.nn.BatchNorm2d, False)
+    with pytest.raises(NotImplementedError):
+        build_backbone("vgg", 16, torch.nn.BatchNorm2d, False, 3, False)
+    with pytest.raises(NotImplementedError):
+        SegmentationLosses(cuda=False).build_loss("dice")
+    with pytest.raises(NotImplementedError):
+        active_selection.get_active_selection_class("accuracy_labels", 19, None, 513, 4)
+    sel = active_selection.get_active_selection_class("variance", 19, "env", 513, 4)
+    assert sel.env == "env" and sel.crop_size == 513 and sel.dataloader_batch_size == 4 and sel.dataset_num_classes == 19
+    assert type(active_selection.get_active_selection_class("coreset", 19, None, 513, 4)).__name__ == "ActiveSelectionCoreSet"
+    assert type(active_selection.get_active_selection_class("ceal_margin", 19, None, 513, 4)).__name__ == "ActiveSelectionCEAL"
+    keys = [b"a", b"b", b"c", b"d"]
+    picked = sel.get_random_uncertainity(keys, 2)
+    assert len(picked) == 2 and set(picked) <= set(keys)
+    # conv weights live in channels_last (KRSC) storage and survive a state_dict round trip
+    w = m.decoder.last_conv[0].weight
+    assert w.permute(0, 2, 3, 1).is_contiguous()
+    m.load_state_dict(om.state_dict())
+    assert m.decoder.last_conv[0].weight.permute(0, 2, 3, 1).is_contiguous()
+
+
+def test_rows_helper_and_shapes():
+    from dass_hip import ops
+
+    x = ops.new_act(2, 304, 5, 7, torch.float32, "cpu")
+    assert x.shape == (2, 304, 5, 7) and ops.rows(x)[1] == 304
+    sl, ld = ops.rows(x[:, :256])
+    assert ld == 304 and sl.data_ptr() == x.data_ptr()
+    y, ld = ops.rows(torch.zeros(2, 8, 5, 7))  # NCHW-contiguous gets re-laid out once
+    assert ld == 8 and y.permute(0, 2, 3, 1).is_contiguous()
+    p = ops.new_act(3, 256, 1, 1, torch.float32, "cpu")
+    assert ops.rows(p)[1] == 256
+    assert ops.conv_out_size(513, 7, 2, 3, 1) == 257 and ops.conv_out_size(33, 3, 1, 18, 18) == 33
+    m = ops.dropout2d_mask(4, 256, 0.25, "cpu", torch.Generator().manual_seed(0))
+    assert all(v == 0.0 or abs(v - 4.0 / 3) < 1e-6 for v in m.unique().tolist())
+
+
+def test_shard_bounds_cover_pool():
+    from active_selection.base import shard_bounds
+
+    for n, w in ((2975, 8), (10, 3), (3, 8), (0, 2)):
+        spans = [shard_bounds(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        assert max(e - s for s, e in spans) - min(e - s for s, e in spans) <= 1
+    assert shard_bounds(2975, 0, 8) == (0, 372)
+
+
+_GLOO_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+from active_selection.base import ActiveSelectionBase, shard_bounds, all_gather_rows
+from oracle import selection_cpu as S
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+keys = [("k%03d" % i).encode() for i in range(11)]
+score_of = lambda k: float((int(k[1:]) * 7919) % 13)   # ties on purpose: stable order must survive the gather
+sel = ActiveSelectionBase(None, 65, 2)
+local, start = sel.local_slice(keys)
+assert (start, start + len(local)) == shard_bounds(len(keys), rank, world)
+scores = sel.gather(torch.tensor([score_of(k) for k in local]), len(keys))
+feats = sel.gather(torch.arange(len(local) * 3, dtype=torch.float32).reshape(len(local), 3) + 100 * rank, len(keys))
+assert feats.shape == (11, 3)
+picked = S.select_top(scores.tolist(), keys, 4, reverse=True)
+ref = S.select_top([score_of(k) for k in keys], keys, 4, reverse=True)
+assert picked == ref, (picked, ref)
+print("rank %d ok %s" % (rank, picked))
+dist.destroy_process_group()
+"""
+
+
+def test_pool_sharding_world2_gloo(tmp_path):
+    """N>1 scoring path: contiguous key shards + all_gather of per-image scores, identical selection on every rank"""
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script), os.path.join(ROOT, "deep-active-semantic-segmentation_amd"), ROOT],
+                                      env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "rank 0 ok" in outs[0] and "rank 1 ok" in outs[1]
+    assert outs[0].split("ok")[1].strip() == outs[1].split("ok")[1].strip()
