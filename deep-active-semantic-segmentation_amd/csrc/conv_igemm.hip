@@ -138,27 +138,44 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
         if (__syncthreads_or((int)any)) tapmask |= (1ull << t);
     }
 
-    uint4 ra[AR], rb[BR];
-    auto load_stage = [&](int t, int cc) {
+    // Address arithmetic is hoisted out of the channel-slab loop: per-row byte offsets are recomputed
+    // only when the tap changes, so a slab costs one add per load (VALU issue slots are not free next
+    // to 64-cycle MFMAs).
+    long b_off[BR];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+        const int k = n0 + lrow + 32 * j;
+        b_off[j] = k < p.K ? (long)k * p.wk_stride * ES : -1;
+    }
+    long a_off[AR];
+    long tap_w_off = 0;
+    auto set_tap = [&](int t) {
         const int r = t / p.S, s = t - r * p.S;
-        const int c = cc * BK + lchunk * EPV;
-        const bool okc = c < p.C;
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
             long pix;
-            const bool ok = tap_pixel(j, r, s, pix) && okc;
+            a_off[j] = tap_pixel(j, r, s, pix) ? pix * p.ldx * ES : -1;
+        }
+        tap_w_off = (long)t * p.C * ES;
+    };
+    uint4 ra[AR], rb[BR];
+    auto load_stage = [&](int cc) {
+        const int c = cc * BK + lchunk * EPV;
+        const bool okc = c < p.C;
+        const long cb = (long)c * ES;
+#pragma unroll
+        for (int j = 0; j < AR; ++j) {
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (ok) {
-                v = *reinterpret_cast<const uint4 *>(p.x + (pix * p.ldx + c) * ES);
+            if (a_off[j] >= 0 && okc) {
+                v = *reinterpret_cast<const uint4 *>(p.x + a_off[j] + cb);
                 if (p.in_scale) v = scale_vec<T>(v, p.in_scale + (long)a_n[j] * p.C + c);
             }
             ra[j] = v;
         }
 #pragma unroll
         for (int j = 0; j < BR; ++j) {
-            const int k = n0 + lrow + 32 * j;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (k < p.K && okc) v = *reinterpret_cast<const uint4 *>(p.w + ((long)k * p.wk_stride + (long)t * p.C + c) * ES);
+            if (b_off[j] >= 0 && okc) v = *reinterpret_cast<const uint4 *>(p.w + b_off[j] + tap_w_off + cb);
             rb[j] = v;
         }
     };
@@ -180,7 +197,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
         rem_mask &= rem_mask - 1;
         cur_cc = 0;
         have = true;
-        load_stage(cur_t, cur_cc);
+        set_tap(cur_t);
+        load_stage(cur_cc);
     }
     while (have) {
         __syncthreads();  // everyone finished reading the previous slab
@@ -197,11 +215,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
             if (rem_mask) {
                 cur_t = __builtin_ctzll(rem_mask);
                 rem_mask &= rem_mask - 1;
+                set_tap(cur_t);
             } else {
                 have = false;
             }
         }
-        if (have) load_stage(cur_t, cur_cc);
+        if (have) load_stage(cur_cc);
 
         const char *ap = As + (wm * TMW + (lane & 31)) * ROWB + (lane >> 5) * 16;
         const char *bp = Bs + (wn * TNW + (lane & 31)) * ROWB + (lane >> 5) * 16;
