@@ -70,7 +70,7 @@ template <> __device__ __forceinline__ uint4 scale_vec<bf16_t>(uint4 v, const fl
 constexpr int ROWB = 144;  // LDS bytes per staged row (128 data + 16 pad)
 
 template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 * 64) ? 4 : 5)) void conv_igemm_kernel(const ConvP p) {
     constexpr int ES = sizeof(T);
     constexpr int EPV = 16 / ES;  // elements per 16-byte vector
     constexpr int BK = 8 * EPV;   // reduction elements per staged slab (128 B)
@@ -318,30 +318,49 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
     const T *dyg = reinterpret_cast<const T *>(p.dy);
 
     f32x4 ra[PASS_A], rb[PASS_B];
+    // per-thread pixel cursors advance by BP every slab: (n, oh, ow) are carried incrementally instead of
+    // being re-derived with two integer divisions per row per slab
+    int b_n[PASS_B], b_oh[PASS_B], b_ow[PASS_B];
+#pragma unroll
+    for (int j = 0; j < PASS_B; ++j) {
+        const long pix = pbeg + brow + j * RPP_B;
+        const int n = (int)(pix / ohw);
+        const int rem = (int)(pix - (long)n * ohw);
+        b_n[j] = n;
+        b_oh[j] = rem / p.OW;
+        b_ow[j] = rem - b_oh[j] * p.OW;
+    }
+    const bool a_kok = (k0 + achunk * 4) < p.K, b_cok = (c0 + bchunk * 4) < p.C;
+    const T *dy_col = dyg + k0 + achunk * 4;
+    const T *x_col = xg + c0 + bchunk * 4;
     auto load_stage = [&](long pb) {
 #pragma unroll
         for (int j = 0; j < PASS_A; ++j) {
             const long pix = pb + arow + j * RPP_A;
-            const int k = k0 + achunk * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (pix < pend && k < p.K) v = ld4<T>(dyg + pix * p.lddy + k);
+            if (pix < pend && a_kok) v = ld4<T>(dy_col + pix * p.lddy);
             ra[j] = v;
         }
 #pragma unroll
         for (int j = 0; j < PASS_B; ++j) {
             const long pix = pb + brow + j * RPP_B;
-            const int c = c0 + bchunk * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (pix < pend && c < p.C) {
-                const int n = (int)(pix / ohw);
-                const int rem = (int)(pix - (long)n * ohw);
-                const int oh = rem / p.OW, ow = rem - oh * p.OW;
-                const int iy = oh * p.stride - p.pad + r * p.dil;
-                const int ix = ow * p.stride - p.pad + s * p.dil;
+            if (pix < pend && b_cok) {
+                const int iy = b_oh[j] * p.stride - p.pad + r * p.dil;
+                const int ix = b_ow[j] * p.stride - p.pad + s * p.dil;
                 if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                    v = ld4<T>(xg + (((long)n * p.H + iy) * p.W + ix) * p.ldx + c);
+                    v = ld4<T>(x_col + (((long)b_n[j] * p.H + iy) * p.W + ix) * p.ldx);
             }
             rb[j] = v;
+            // advance this cursor by BP pixels
+            b_ow[j] += BP;
+            while (b_ow[j] >= p.OW) {
+                b_ow[j] -= p.OW;
+                if (++b_oh[j] >= p.OH) {
+                    b_oh[j] = 0;
+                    ++b_n[j];
+                }
+            }
         }
     };
 
@@ -445,15 +464,22 @@ template <typename T> int dispatch_conv(ConvP &p, hipStream_t st) {
     return launch_conv<T, 64, 64, 2, 2>(p, st);
 }
 
-template <typename T, int BMK, int BNC> int launch_wgrad(WgradP &p, hipStream_t st) {
+// Work split of the weight gradient.  Every pixel-split adds its whole K x R*S x C tile set into dW with
+// f32 atomics (chip-wide ~1.3 TB/s), so the split count is a trade: enough workgroups to fill 256 CUs,
+// but each one long enough (>= MIN_SLABS slabs of 32 pixels) that the atomic tail stays small.
+static long wgrad_split(long base, long M, long target_wgs, long min_slabs) {
+    long want = (target_wgs + base - 1) / base;
+    long maxsplit = M / (32 * min_slabs);
+    if (maxsplit < 1) maxsplit = 1;
+    if (want > maxsplit) want = maxsplit;
+    return want < 1 ? 1 : want;
+}
+
+template <typename T, int BMK, int BNC> int launch_wgrad(WgradP &p, hipStream_t st, long split) {
     p.ktiles = (p.K + BMK - 1) / BMK;
     p.ctiles = (p.C + BNC - 1) / BNC;
     const long base = (long)p.ktiles * p.ctiles * p.R * p.S;
-    long want = (1024 + base - 1) / base;  // aim at ~4 workgroups per CU
-    long maxsplit = (p.M + 255) / 256;     // at least 8 slabs of 32 pixels per workgroup
-    if (want > maxsplit) want = maxsplit;
-    if (want < 1) want = 1;
-    long pps = (p.M + want - 1) / want;
+    long pps = (p.M + split - 1) / split;
     pps = (pps + 31) / 32 * 32;
     p.pix_per_split = (int)pps;
     p.psplit = (int)((p.M + pps - 1) / pps);
@@ -464,11 +490,21 @@ template <typename T, int BMK, int BNC> int launch_wgrad(WgradP &p, hipStream_t 
 }
 
 template <typename T> int dispatch_wgrad(WgradP &p, hipStream_t st) {
+    const long rs = (long)p.R * p.S;
+    auto base_of = [&](int bk, int bc) { return (long)((p.K + bk - 1) / bk) * ((p.C + bc - 1) / bc) * rs; };
+    const long target = 640, min_slabs = 16;
     const bool kbig = p.K > 64, cbig = p.C > 64;
-    if (kbig && cbig) return launch_wgrad<T, 128, 128>(p, st);
-    if (kbig) return launch_wgrad<T, 128, 64>(p, st);
-    if (cbig) return launch_wgrad<T, 64, 128>(p, st);
-    return launch_wgrad<T, 64, 64>(p, st);
+    if (kbig && cbig) {
+        // big tiles unless they cannot fill the chip with long-enough workgroups
+        const long b = base_of(128, 128);
+        const long sp = wgrad_split(b, p.M, target, min_slabs);
+        if (b * sp >= 400) return launch_wgrad<T, 128, 128>(p, st, sp);
+        const long b2 = base_of(64, 64);
+        return launch_wgrad<T, 64, 64>(p, st, wgrad_split(b2, p.M, target, min_slabs));
+    }
+    if (kbig) return launch_wgrad<T, 128, 64>(p, st, wgrad_split(base_of(128, 64), p.M, target, min_slabs));
+    if (cbig) return launch_wgrad<T, 64, 128>(p, st, wgrad_split(base_of(64, 128), p.M, target, min_slabs));
+    return launch_wgrad<T, 64, 64>(p, st, wgrad_split(base_of(64, 64), p.M, target, min_slabs));
 }
 
 }  // namespace
