@@ -63,42 +63,54 @@ __global__ __launch_bounds__(256) void colstat_kernel(const T *__restrict__ x, l
     }
 }
 
-// one block per 64 channels; 4 row lanes; f64 accumulation of the partial rows
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ partial, int rows, int K,
-                                                          double count, double rep, const float *gamma,
-                                                          const float *beta, float *running_mean, float *running_var,
-                                                          float momentum, float eps, float *mean, float *invstd,
-                                                          float *scale, float *shift) {
-    __shared__ double red[2][4][64];
-    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int k = blockIdx.x * 64 + c;
-    double s = 0.0, ss = 0.0;
+// f64 reduction of the partial rows: one 1024-thread block per 32 channels, 32 row lanes each
+constexpr int FIN_CH = 32, FIN_LANES = 32;
+__device__ __forceinline__ bool reduce_partials(const float *__restrict__ partial, int rows, int K, int &k, double &s,
+                                                double &ss) {
+    __shared__ double red[2][FIN_LANES][FIN_CH + 1];
+    const int c = threadIdx.x % FIN_CH, rl = threadIdx.x / FIN_CH;
+    k = blockIdx.x * FIN_CH + c;
+    double a = 0.0, b = 0.0;
     if (k < K)
-        for (int r = rl; r < rows; r += 4) {
-            s += (double)partial[((long)r * 2 + 0) * K + k];
-            ss += (double)partial[((long)r * 2 + 1) * K + k];
+        for (int r = rl; r < rows; r += FIN_LANES) {
+            a += (double)partial[((long)r * 2 + 0) * K + k];
+            b += (double)partial[((long)r * 2 + 1) * K + k];
         }
-    red[0][rl][c] = s;
-    red[1][rl][c] = ss;
+    red[0][rl][c] = a;
+    red[1][rl][c] = b;
     __syncthreads();
-    if (rl == 0 && k < K) {
-        s = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
-        ss = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
-        const double mu = s * rep / count;
-        double var = ss * rep / count - mu * mu;
-        if (var < 0.0) var = 0.0;
-        const double is = 1.0 / sqrt(var + (double)eps);
-        const float g = gamma ? gamma[k] : 1.f, b = beta ? beta[k] : 0.f;
-        mean[k] = (float)mu;
-        invstd[k] = (float)is;
-        const float sc = (float)((double)g * is);
-        scale[k] = sc;
-        shift[k] = (float)((double)b - mu * (double)g * is);
-        if (momentum >= 0.f && running_mean && running_var) {
-            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-            running_mean[k] = (1.f - momentum) * running_mean[k] + momentum * (float)mu;
-            running_var[k] = (1.f - momentum) * running_var[k] + momentum * (float)unb;
-        }
+    if (rl != 0 || k >= K) return false;
+    s = 0.0;
+    ss = 0.0;
+#pragma unroll 8
+    for (int i = 0; i < FIN_LANES; ++i) {
+        s += red[0][i][c];
+        ss += red[1][i][c];
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restrict__ partial, int rows, int K,
+                                                           double count, double rep, const float *gamma,
+                                                           const float *beta, float *running_mean, float *running_var,
+                                                           float momentum, float eps, float *mean, float *invstd,
+                                                           float *scale, float *shift) {
+    int k;
+    double s, ss;
+    if (!reduce_partials(partial, rows, K, k, s, ss)) return;
+    const double mu = s * rep / count;
+    double var = ss * rep / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const double is = 1.0 / sqrt(var + (double)eps);
+    const float g = gamma ? gamma[k] : 1.f, b = beta ? beta[k] : 0.f;
+    mean[k] = (float)mu;
+    invstd[k] = (float)is;
+    scale[k] = (float)((double)g * is);
+    shift[k] = (float)((double)b - mu * (double)g * is);
+    if (momentum >= 0.f && running_mean && running_var) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[k] = (1.f - momentum) * running_mean[k] + momentum * (float)mu;
+        running_var[k] = (1.f - momentum) * running_var[k] + momentum * (float)unb;
     }
 }
 
@@ -114,24 +126,13 @@ __global__ void bn_eval_kernel(const float *gamma, const float *beta, const floa
     shift[k] = b - rm[k] * g * is;
 }
 
-__global__ __launch_bounds__(256) void bwd_finalize_kernel(const float *__restrict__ partial, int rows, int K,
-                                                           float *dbeta, float *dgamma) {
-    __shared__ double red[2][4][64];
-    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int k = blockIdx.x * 64 + c;
-    double s = 0.0, ss = 0.0;
-    if (k < K)
-        for (int r = rl; r < rows; r += 4) {
-            s += (double)partial[((long)r * 2 + 0) * K + k];
-            ss += (double)partial[((long)r * 2 + 1) * K + k];
-        }
-    red[0][rl][c] = s;
-    red[1][rl][c] = ss;
-    __syncthreads();
-    if (rl == 0 && k < K) {
-        if (dbeta) dbeta[k] = (float)(red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-        if (dgamma) dgamma[k] = (float)(red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
-    }
+__global__ __launch_bounds__(1024) void bwd_finalize_kernel(const float *__restrict__ partial, int rows, int K,
+                                                            float *dbeta, float *dgamma) {
+    int k;
+    double s, ss;
+    if (!reduce_partials(partial, rows, K, k, s, ss)) return;
+    if (dbeta) dbeta[k] = (float)s;
+    if (dgamma) dgamma[k] = (float)ss;
 }
 
 template <typename T>
@@ -197,14 +198,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
     }
 }
 
-__global__ void colsum_finalize_kernel(const float *__restrict__ partial, int rows, int K, float *out) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K) return;
-    double s = 0.0;
-    for (int r = 0; r < rows; ++r) s += (double)partial[((long)r * 2) * K + k];
-    out[k] = (float)s;
-}
-
 bool ok4(int K, int64_t a, int64_t b = 4, int64_t c = 4, int64_t d = 4) {
     return K > 0 && K % 4 == 0 && a % 4 == 0 && b % 4 == 0 && c % 4 == 0 && d % 4 == 0;
 }
@@ -234,7 +227,7 @@ extern "C" int dass_bn_finalize(const float *partial, int rows, int K, double co
                                 const float *beta, float *running_mean, float *running_var, float momentum,
                                 float eps, float *mean, float *invstd, float *scale, float *shift, void *stream) {
     if (!partial || rows <= 0 || K <= 0 || count <= 0 || !mean || !invstd || !scale || !shift) return DASS_ERR_ARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((K + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial, rows, K,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((K + FIN_CH - 1) / FIN_CH), dim3(1024), 0, (hipStream_t)stream, partial, rows, K,
                        count, rep, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -296,7 +289,7 @@ extern "C" int dass_bn_bwd_reduce(const void *dout, int64_t lddo, const void *ou
 extern "C" int dass_bn_bwd_finalize(const float *partial, int rows, int K, float *dbeta, float *dgamma,
                                     void *stream) {
     if (!partial || rows <= 0 || K <= 0) return DASS_ERR_ARG;
-    hipLaunchKernelGGL(bwd_finalize_kernel, dim3((K + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial, rows, K,
+    hipLaunchKernelGGL(bwd_finalize_kernel, dim3((K + FIN_CH - 1) / FIN_CH), dim3(1024), 0, (hipStream_t)stream, partial, rows, K,
                        dbeta, dgamma);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -335,8 +328,8 @@ extern "C" int dass_colsum(const void *x, int64_t ldx, int64_t M, int K, float *
     if (!out) return DASS_ERR_ARG;
     const int rc = dass_channel_stats(x, ldx, M, K, partial, dtype, stream);
     if (rc != DASS_OK) return rc;
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial,
-                       dass_stat_rows(M), K, out);
+    hipLaunchKernelGGL(bwd_finalize_kernel, dim3((K + FIN_CH - 1) / FIN_CH), dim3(1024), 0, (hipStream_t)stream, partial,
+                       dass_stat_rows(M), K, out, nullptr);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }

@@ -111,6 +111,46 @@ class BNState(object):
         self.mean, self.invstd, self.scale, self.shift = buf[0], buf[1], buf[2], buf[3]
 
 
+_pending_counters = []
+_defer = {"depth": 0}
+
+
+class deferred_bn_counters(object):
+    """with deferred_bn_counters(): ... -> counters of every BN touched inside are bumped in ONE launch on
+    exit of the outermost scope (modules used stand-alone open their own scope)."""
+
+    def __enter__(self):
+        _defer["depth"] += 1
+
+    def __exit__(self, *exc):
+        _defer["depth"] -= 1
+        if _defer["depth"] == 0:
+            flush_bn_counters()
+        return False
+
+
+def bn_counter_scope(forward):
+    """decorator for nn.Module.forward: run inside a deferred_bn_counters() scope"""
+    import functools
+
+    @functools.wraps(forward)
+    def wrapped(self, *args, **kwargs):
+        with deferred_bn_counters():
+            return forward(self, *args, **kwargs)
+
+    return wrapped
+
+
+def flush_bn_counters():
+    """num_batches_tracked += 1 for every BN that normalised with batch statistics since the last flush:
+    one multi-tensor launch instead of 113 one-element adds per step (bookkeeping, not arithmetic on
+    activations).  Called at the end of DeepLab.forward and from every state_dict()/load hook below."""
+    if _pending_counters:
+        pend = list(_pending_counters)
+        del _pending_counters[:]
+        torch._foreach_add_(pend, 1)
+
+
 def bn_train_state(x, ld, m, k, bn, rep=1.0):
     partial, nrows = channel_stats(x, ld, m, k)
     st = BNState(k, x.device)
@@ -119,7 +159,9 @@ def bn_train_state(x, ld, m, k, bn, rep=1.0):
     if bn.track_running_stats and bn.running_mean is not None:
         mom = 0.1 if bn.momentum is None else float(bn.momentum)
         rm, rv = bn.running_mean, bn.running_var
-        bn.num_batches_tracked.add_(1)
+        _pending_counters.append(bn.num_batches_tracked)
+        if _defer["depth"] == 0 or len(_pending_counters) >= 512:
+            flush_bn_counters()
     check(lib.dass_bn_finalize(_p(partial), nrows, k, float(m) * rep, float(rep), _p(bn.weight), _p(bn.bias), _p(rm),
                                _p(rv), mom, float(bn.eps), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
                                _stream()), "dass_bn_finalize")

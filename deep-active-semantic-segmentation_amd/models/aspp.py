@@ -59,6 +59,7 @@ class ASPP(nn.Module):
         self.dropout = nn.Dropout2d(0.5)
         self._init_weight()
 
+    @ops.bn_counter_scope
     def forward(self, x, dropout_mask=None, apply_dropout=True):
         """dropout_mask: optional explicit [N,256] multipliers (reproducible stochastic passes);
         apply_dropout=False returns the pre-dropout activation (used by the hoisted MC-dropout tail)."""

@@ -104,6 +104,7 @@ class MobileNetV2(nn.Module):
                 x = m(x)
         return x
 
+    @ops.bn_counter_scope
     def forward(self, x):
         low_level_feat = self._run(self.low_level_features, x, True)
         x = self._run(self.high_level_features, low_level_feat, False)

@@ -66,6 +66,7 @@ class ResNet(nn.Module):
             self._load_pretrained_model()
         channels_last_weights(self)
 
+    @ops.bn_counter_scope
     def forward(self, input):
         x = ops.conv_bn_act(input, self.conv1, self.bn1, ops.ACT_RELU, image_input=True)
         x = ops.maxpool3x3s2(x)

@@ -54,6 +54,7 @@ class Decoder(nn.Module):
         h = ops.conv_bn_act(h, lc[3], lc[4], ops.ACT_RELU, nc_scale=mask)
         return ops.conv_bn_act(h, lc[7])
 
+    @ops.bn_counter_scope
     def forward(self, x, low_level_feat, dropout_mask=None):
         second_to_last_features = self.features(x, low_level_feat)
         return self.head(second_to_last_features, dropout_mask), second_to_last_features

@@ -53,6 +53,7 @@ class DeepLab(nn.Module):
         # deeplab.py:39-56 draws numpy gaussians on the host; same distribution drawn on the device here
         return torch.randn_like(t.float()) * abs(float(t.float().mean()) * frac)
 
+    @ops.bn_counter_scope
     def forward(self, input, dropout_masks=None):
         m_aspp, m_dec = dropout_masks if dropout_masks is not None else (None, None)
         if self.noisy_features is True:
