@@ -34,6 +34,10 @@ struct ConvP {
     long wk_stride;  // R*S*C
     int N, H, W, C, OH, OW, K, R, S, stride, pad, dil, ustride, act;
     int M, cchunks, mtiles, ntiles;
+    // output sub-grid (phase-decomposed dgrad of strided convs): this launch covers output pixels
+    // (oy*o_mul + oy_add, ox*o_mul + ox_add), oy < OHs, ox < OWs, and only the taps in tap_allow
+    int OHs, OWs, o_mul, oy_add, ox_add;
+    unsigned long long tap_allow;
 };
 
 template <typename T> struct Mma;
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 
     int a_iy0[AR], a_ix0[AR], a_n[AR];
     long a_nb[AR];
     bool a_ok[AR];
-    const int ohw = p.OH * p.OW;
+    const int ohw = p.OHs * p.OWs;
 #pragma unroll
     for (int j = 0; j < AR; ++j) {
         const int m = m0 + lrow + 32 * j;
@@ -103,8 +107,9 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 
         const int mm = a_ok[j] ? m : 0;
         const int n = mm / ohw;
         const int rem = mm - n * ohw;
-        const int oh = rem / p.OW;
-        const int ow = rem - oh * p.OW;
+        const int ohs = rem / p.OWs;
+        const int oh = ohs * p.o_mul + p.oy_add;
+        const int ow = (rem - ohs * p.OWs) * p.o_mul + p.ox_add;
         a_iy0[j] = oh * p.stride - p.pad;
         a_ix0[j] = ow * p.stride - p.pad;
         a_n[j] = n;
@@ -128,6 +133,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 
     const int ntaps = p.R * p.S;
     unsigned long long tapmask = 0ull;
     for (int t = 0; t < ntaps; ++t) {
+        if (!((p.tap_allow >> t) & 1ull)) continue;  // uniform: host-side phase filter
         const int r = t / p.S, s = t - r * p.S;
         bool any = false;
 #pragma unroll
@@ -254,10 +260,16 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 
                 const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
                 const int m = m0 + wm * TMW + mt * 32 + row;
                 if (m < p.M) {
+                    long mo = m;  // output pixel index; differs from m only for a phase sub-grid
+                    if (p.o_mul != 1) {
+                        const int n = m / ohw, rem = m - n * ohw;
+                        const int ohs = rem / p.OWs;
+                        mo = ((long)n * p.OH + ohs * p.o_mul + p.oy_add) * p.OW + (rem - ohs * p.OWs) * p.o_mul + p.ox_add;
+                    }
                     float v = acc[mt][nt][reg] * sc + sh;
-                    if (res) v += Elem<T>::ld(res + (long)m * p.ldr + k);
+                    if (res) v += Elem<T>::ld(res + mo * p.ldr + k);
                     v = apply_act(v, p.act);
-                    Elem<T>::st(y + (long)m * p.ldy + k, v);
+                    Elem<T>::st(y + mo * p.ldy + k, v);
                 }
             }
         }
@@ -535,7 +547,48 @@ extern "C" int dass_conv2d_igemm(const void *x, int64_t ldx, const void *w, void
     p.N = N; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K; p.R = R; p.S = S;
     p.stride = stride; p.pad = pad; p.dil = dil; p.ustride = ustride; p.act = act;
     p.M = N * OH * OW;
+    p.OHs = OH; p.OWs = OW; p.o_mul = 1; p.oy_add = 0; p.ox_add = 0;
+    p.tap_allow = ~0ull;
     hipStream_t st = (hipStream_t)stream;
+    if (ustride > 1 && stride == 1 && !scale && !shift && !residual && act == DASS_ACT_NONE) {
+        // dgrad of a strided conv: output pixel (oy,ox) only sees taps with (oy - pad + r*dil) % ustride == 0.
+        // One launch per output phase (oy%us, ox%us) with exactly its taps -- no work on structural zeros.
+        bool any_empty = false;
+        unsigned long long masks[8][8];
+        if (ustride > 8) return DASS_ERR_UNSUPPORTED;
+        for (int py = 0; py < ustride; ++py)
+            for (int px = 0; px < ustride; ++px) {
+                unsigned long long mk = 0ull;
+                for (int r = 0; r < R; ++r)
+                    for (int s2 = 0; s2 < S; ++s2) {
+                        const int ty = py - pad + r * dil, tx = px - pad + s2 * dil;
+                        if (((ty % ustride) + ustride) % ustride == 0 && ((tx % ustride) + ustride) % ustride == 0)
+                            mk |= 1ull << (r * S + s2);
+                    }
+                masks[py][px] = mk;
+                if (!mk && py < OH && px < OW) any_empty = true;
+            }
+        if (any_empty) {
+            const size_t es = dtype == DASS_F32 ? 4 : 2;
+            if (ldy != K) {  // strided rows: zero row by row is not needed on this path (dgrad outputs are dense)
+                return DASS_ERR_UNSUPPORTED;
+            }
+            if (hipMemsetAsync(y, 0, es * (size_t)N * OH * OW * K, st) != hipSuccess) return DASS_ERR_LAUNCH;
+        }
+        for (int py = 0; py < ustride; ++py)
+            for (int px = 0; px < ustride; ++px) {
+                if (!masks[py][px] || py >= OH || px >= OW) continue;
+                ConvP q = p;
+                q.OHs = (OH - py + ustride - 1) / ustride;
+                q.OWs = (OW - px + ustride - 1) / ustride;
+                q.o_mul = ustride; q.oy_add = py; q.ox_add = px;
+                q.tap_allow = masks[py][px];
+                q.M = N * q.OHs * q.OWs;
+                const int rc = dtype == DASS_F32 ? dispatch_conv<float>(q, st) : dispatch_conv<bf16_t>(q, st);
+                if (rc != DASS_OK) return rc;
+            }
+        return DASS_OK;
+    }
     return dtype == DASS_F32 ? dispatch_conv<float>(p, st) : dispatch_conv<bf16_t>(p, st);
 }
 
