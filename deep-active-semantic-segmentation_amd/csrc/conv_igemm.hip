@@ -38,6 +38,7 @@ struct ConvP {
     // (oy*o_mul + oy_add, ox*o_mul + ox_add), oy < OHs, ox < OWs, and only the taps in tap_allow
     int OHs, OWs, o_mul, oy_add, ox_add;
     unsigned long long tap_allow;
+    int wide_c;  // row-tap mode (WIDE kernels): true input channels; p.C = S*wide_c, taps = R
 };
 
 template <typename T> struct Mma;
@@ -72,8 +73,12 @@ template <> __device__ __forceinline__ uint4 scale_vec<bf16_t>(uint4 v, const fl
 }
 
 constexpr int ROWB = 144;  // LDS bytes per staged row (128 data + 16 pad)
+constexpr long kInvalidOff = 1l << 62;  // WIDE mode: legal row offsets may be negative (ix0 < 0)
 
-template <typename T, int BM, int BN, int WM, int WN>
+// WIDE ("row-tap") variant for the 3-channel network stems (7x7/s2 ResNet, 3x3/s2 MobileNet): a tap is a
+// whole kernel ROW -- the S*Cin input values x[n, iy, ix0 .. ix0+S-1, :] are contiguous in a dense NHWC
+// image -- so the reduction is R slabs of S*Cin (=21 or 9) values instead of R*S slabs of a padded channel.
+template <typename T, int BM, int BN, int WM, int WN, bool WIDE = false>
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 * 64) ? 4 : 5)) void conv_igemm_kernel(const ConvP p) {
     constexpr int ES = sizeof(T);
     constexpr int EPV = 16 / ES;  // elements per 16-byte vector
@@ -118,6 +123,10 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 
 
     auto tap_pixel = [&](int j, int r, int s, long &pix) -> bool {
         int iy = a_iy0[j] + r * p.dil, ix = a_ix0[j] + s * p.dil;
+        if (WIDE) {  // only the row must exist; columns are checked per element
+            pix = a_nb[j] + (long)iy * p.W + ix;
+            return a_ok[j] && iy >= 0 && iy < p.H;
+        }
         bool ok = a_ok[j] && iy >= 0 && ix >= 0;
         if (p.ustride > 1) {
             ok = ok && (iy % p.ustride == 0) && (ix % p.ustride == 0);
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
             long pix;
-            a_off[j] = tap_pixel(j, r, s, pix) ? pix * p.ldx * ES : -1;
+            a_off[j] = tap_pixel(j, r, s, pix) ? pix * p.ldx * ES : (WIDE ? kInvalidOff : -1);
         }
         tap_w_off = (long)t * p.C * ES;
     };
@@ -169,6 +178,30 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 
         const int c = cc * BK + lchunk * EPV;
         const bool okc = c < p.C;
         const long cb = (long)c * ES;
+        if (WIDE) {
+            // element-wise (unaligned, per-column validity): x index j -> column ix0 + j / Cin
+#pragma unroll
+            for (int j = 0; j < AR; ++j) {
+                T tmp[EPV];
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    const int q = c + e;
+                    const int ix = a_ix0[j] + q / p.wide_c;
+                    const bool ok = a_off[j] != kInvalidOff && q < p.C && ix >= 0 && ix < p.W;
+                    tmp[e] = ok ? *reinterpret_cast<const T *>(p.x + a_off[j] + cb + e * ES) : (T)0;
+                }
+                ra[j] = *reinterpret_cast<const uint4 *>(tmp);
+            }
+#pragma unroll
+            for (int j = 0; j < BR; ++j) {
+                T tmp[EPV];
+#pragma unroll
+                for (int e = 0; e < EPV; ++e)
+                    tmp[e] = (b_off[j] >= 0 && c + e < p.C) ? *reinterpret_cast<const T *>(p.w + b_off[j] + tap_w_off + cb + e * ES) : (T)0;
+                rb[j] = *reinterpret_cast<const uint4 *>(tmp);
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -290,9 +323,10 @@ struct WgradP {
     long ldx, lddy;
     int N, H, W, C, OH, OW, K, R, S, stride, pad, dil;
     int M, ktiles, ctiles, psplit, pix_per_split;
+    int wide_c;
 };
 
-template <typename T, int BMK, int BNC>
+template <typename T, int BMK, int BNC, bool WIDE = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
     constexpr int BP = 32;          // pixels per staged slab
     constexpr int LDA = BMK + 4;    // floats per LDS row (pad keeps 16-B alignment, staggers rows)
@@ -357,7 +391,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
         for (int j = 0; j < PASS_B; ++j) {
             const long pix = pb + brow + j * RPP_B;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (pix < pend && b_cok) {
+            if (WIDE) {
+                // row-tap mode: "channel" q = c0 + 4*bchunk + e addresses column ix0 + q / Cin of input row iy
+                const int iy = b_oh[j] * p.stride - p.pad + r;
+                const int ix0 = b_ow[j] * p.stride - p.pad;
+                if (pix < pend && iy >= 0 && iy < p.H) {
+                    const T *row = x_col + (((long)b_n[j] * p.H + iy) * p.W + ix0) * p.wide_c;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int q = c0 + bchunk * 4 + e;
+                        const int ix = ix0 + q / p.wide_c;
+                        if (q < p.C && ix >= 0 && ix < p.W) v[e] = Elem<T>::ld(row + e);
+                    }
+                }
+            } else if (pix < pend && b_cok) {
                 const int iy = b_oh[j] * p.stride - p.pad + r * p.dil;
                 const int ix = b_ow[j] * p.stride - p.pad + s * p.dil;
                 if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
@@ -456,11 +503,11 @@ __global__ void weight_transform_kernel(const float *__restrict__ src, T *__rest
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN> int launch_conv(ConvP &p, hipStream_t st) {
+template <typename T, int BM, int BN, int WM, int WN, bool WIDE = false> int launch_conv(ConvP &p, hipStream_t st) {
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = (p.K + BN - 1) / BN;
     const int grid = p.mtiles * p.ntiles;
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN>), dim3(grid), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, WIDE>), dim3(grid), dim3(256), 0, st, p);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
@@ -487,7 +534,7 @@ static long wgrad_split(long base, long M, long target_wgs, long min_slabs) {
     return want < 1 ? 1 : want;
 }
 
-template <typename T, int BMK, int BNC> int launch_wgrad(WgradP &p, hipStream_t st, long split) {
+template <typename T, int BMK, int BNC, bool WIDE = false> int launch_wgrad(WgradP &p, hipStream_t st, long split) {
     p.ktiles = (p.K + BMK - 1) / BMK;
     p.ctiles = (p.C + BNC - 1) / BNC;
     const long base = (long)p.ktiles * p.ctiles * p.R * p.S;
@@ -496,7 +543,7 @@ template <typename T, int BMK, int BNC> int launch_wgrad(WgradP &p, hipStream_t 
     p.pix_per_split = (int)pps;
     p.psplit = (int)((p.M + pps - 1) / pps);
     const long grid = base * p.psplit;
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, BMK, BNC>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, BMK, BNC, WIDE>), dim3((unsigned)grid), dim3(256), 0, st, p);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
@@ -629,4 +676,46 @@ extern "C" int dass_weight_transform(const float *src, void *dst, int K, int R, 
         return DASS_ERR_UNSUPPORTED;
     DASS_LAUNCH_CHECK();
     return DASS_OK;
+}
+
+extern "C" int dass_conv2d_rowtap(const void *x, const void *w, void *y, int64_t ldy, int N, int H, int W, int Cin, int OH,
+                                  int OW, int K, int R, int S, int stride, int pad, int dtype, void *stream) {
+    if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || K <= 0 || R <= 0 || S <= 0)
+        return DASS_ERR_ARG;
+    if (dtype != DASS_F32) return DASS_ERR_UNSUPPORTED;
+    if (R > 64 || S * Cin > 32 || stride < 1 || (long)N * OH * OW >= (1l << 31)) return DASS_ERR_ARG;
+    ConvP p;
+    p.x = (const char *)x; p.w = (const char *)w; p.y = (char *)y;
+    p.scale = nullptr; p.shift = nullptr; p.res = nullptr; p.in_scale = nullptr;
+    p.ldx = Cin; p.ldy = ldy; p.ldr = 0;
+    p.wk_stride = (long)R * S * Cin;
+    p.N = N; p.H = H; p.W = W; p.C = S * Cin; p.OH = OH; p.OW = OW; p.K = K; p.R = R; p.S = 1;
+    p.stride = stride; p.pad = pad; p.dil = 1; p.ustride = 1; p.act = DASS_ACT_NONE;
+    p.M = N * OH * OW;
+    p.OHs = OH; p.OWs = OW; p.o_mul = 1; p.oy_add = 0; p.ox_add = 0;
+    p.tap_allow = ~0ull;
+    p.wide_c = Cin;
+    p.cchunks = 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (K <= 32) return launch_conv<float, 128, 32, 4, 1, true>(p, st);
+    return launch_conv<float, 128, 64, 2, 2, true>(p, st);
+}
+
+extern "C" int dass_conv2d_rowtap_wgrad(const void *x, const void *dy, int64_t lddy, float *dw, int N, int H, int W, int Cin,
+                                        int OH, int OW, int K, int R, int S, int stride, int pad, int dtype, void *stream) {
+    if (!x || !dy || !dw || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || K <= 0 || R <= 0 || S <= 0)
+        return DASS_ERR_ARG;
+    if (dtype != DASS_F32) return DASS_ERR_UNSUPPORTED;
+    if (S * Cin > 64 || K % 4 != 0 || lddy % 4 != 0 || (long)N * OH * OW >= (1l << 31)) return DASS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * R * S * Cin, st) != hipSuccess) return DASS_ERR_LAUNCH;
+    WgradP p;
+    p.x = (const char *)x; p.dy = (const char *)dy; p.dw = dw;
+    p.ldx = Cin; p.lddy = lddy;
+    p.N = N; p.H = H; p.W = W; p.C = S * Cin; p.OH = OH; p.OW = OW; p.K = K; p.R = R; p.S = 1;
+    p.stride = stride; p.pad = pad; p.dil = 1;
+    p.M = N * OH * OW;
+    p.wide_c = Cin;
+    const long base = (long)((K + 63) / 64) * R;
+    return launch_wgrad<float, 64, 64, true>(p, st, wgrad_split(base, p.M, 640, 16));
 }

@@ -259,6 +259,11 @@ def _conv_forward_raw(spec, x, ldx, n, h, w, c, weight, y, ldy, oh, ow, **epi):
         assert not epi
         check(lib.dass_dwconv3x3_fwd(_p(x), ldx, _p(_dw_weight(weight)), _p(y), ldy, n, h, w, c, oh, ow, spec.stride,
                                      spec.pad, spec.dil, _dt(y), _stream()), "dass_dwconv3x3_fwd")
+    elif getattr(spec, "rowtap", False):
+        assert not any(v is not None and v != 0 for v in epi.values()), "row-tap stem has no fused epilogue"
+        r, s = weight.shape[2], weight.shape[3]
+        check(lib.dass_conv2d_rowtap(_p(x), _p(_krsc_master(weight)), _p(y), ldy, n, h, w, c, oh, ow, k, r, s, spec.stride,
+                                     spec.pad, _dt(y), _stream()), "dass_conv2d_rowtap")
     else:
         r, s = weight.shape[2], weight.shape[3]
         w_op = weight_operand(weight, 0, y.dtype, cpad=c)
@@ -278,8 +283,11 @@ class _ConvBnAct(torch.autograd.Function):
         n, c_in, h, w = x.shape
         k = weight.shape[0]
         r = weight.shape[2]
+        rowtap = (image_input and dt == torch.float32 and weight.shape[3] * c_in <= 32 and spec.dil == 1
+                  and not spec.depthwise)
+        spec.rowtap = rowtap
         if image_input:
-            c = _pad_to(c_in, _epv(dt))
+            c = c_in if rowtap else _pad_to(c_in, _epv(dt))   # row-tap stem reads the dense 3-channel image
             xr = torch.empty((n, h, w, c), dtype=dt, device=dev)
             xin = x.contiguous().float()
             check(lib.dass_nchw_to_nhwc(_p(xin), _p(xr), n, c_in, h, w, c, _dt(xr), _stream()), "dass_nchw_to_nhwc")
@@ -307,7 +315,7 @@ class _ConvBnAct(torch.autograd.Function):
         state = None
         y_raw = None
         batch_stats = bn is not None and bn_use_batch_stats(bn)
-        fuse = (not spec.depthwise) and (bn is None or (not batch_stats and not need_grad))
+        fuse = (not spec.depthwise) and (not rowtap) and (bn is None or (not batch_stats and not need_grad))
         if fuse:
             scale = shift = None
             if bn is not None:
@@ -433,7 +441,12 @@ class _ConvBnAct(torch.autograd.Function):
                 check(lib.dass_conv2d_igemm(_p(dy), lddy, _p(w_t), _p(dx), c, None, None, None, 0, None, n, oh, ow,
                                             kk, h, w, c, r, s, 1, pad_t, spec.dil, spec.stride, ACT_NONE, _dt(dx),
                                             _stream()), "dass_conv2d_igemm(dgrad)")
-            if ctx.needs_input_grad[1]:
+            if ctx.needs_input_grad[1] and getattr(spec, "rowtap", False):
+                dwk = torch.empty((k, r, s, c_in), dtype=torch.float32, device=dev)
+                check(lib.dass_conv2d_rowtap_wgrad(_p(xs), _p(dy), lddy, _p(dwk), n, h, w, c_in, oh, ow, k, r, s, spec.stride,
+                                                   spec.pad, _dt(dy), _stream()), "dass_conv2d_rowtap_wgrad")
+                dw = dwk.permute(0, 3, 1, 2)
+            elif ctx.needs_input_grad[1]:
                 dwk = torch.empty((kk, r, s, c), dtype=torch.float32, device=dev)
                 check(lib.dass_conv2d_wgrad(_p(xs), ldx, _p(dy), lddy, _p(dwk), n, h, w, c, oh, ow, kk, r, s,
                                             spec.stride, spec.pad, spec.dil, _dt(dy), _stream()), "dass_conv2d_wgrad")

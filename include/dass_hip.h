@@ -70,6 +70,17 @@ int dass_conv2d_wgrad(const void *x, int64_t ldx, const void *dy, int64_t lddy, 
                       int N, int H, int W, int C, int OH, int OW, int K,
                       int R, int S, int stride, int pad, int dil, int dtype, void *stream);
 
+/* Network stems (resnet.py:65 7x7/s2, mobilenet.py:14 3x3/s2 over the 3-channel image): "row-tap" form of
+ * the same implicit GEMM.  x is a DENSE NHWC image [N,H,W,Cin] (ld = Cin, no channel padding); a tap is a
+ * whole kernel row, whose S*Cin input values are contiguous, so the reduction is R slabs of S*Cin (<= 32)
+ * instead of R*S slabs of a padded channel.  w is KRSC (= [K][R][S*Cin]); dilation 1; f32 only. */
+int dass_conv2d_rowtap(const void *x, const void *w, void *y, int64_t ldy,
+                       int N, int H, int W, int Cin, int OH, int OW, int K,
+                       int R, int S, int stride, int pad, int dtype, void *stream);
+int dass_conv2d_rowtap_wgrad(const void *x, const void *dy, int64_t lddy, float *dw,
+                             int N, int H, int W, int Cin, int OH, int OW, int K,
+                             int R, int S, int stride, int pad, int dtype, void *stream);
+
 /* KRSC f32 master weights -> device operand.  mode 0: cast/copy [K][R][S][Csrc] -> [K][R][S][Cdst]
  * (zero pad or truncate channels); mode 1: dgrad operand [C][R][S][K] with taps flipped. */
 int dass_weight_transform(const float *src, void *dst, int K, int R, int S, int Csrc, int Cdst,
