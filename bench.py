@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mc", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="f32 = parity mode (headline); bf16 = storage bf16, f32 accumulate")
     return ap.parse_args()
 
 
@@ -126,7 +127,7 @@ def main():
     from utils.loss import SegmentationLosses
     from active_selection.mc_dropout import ActiveSelectionMCDropout
 
-    ops.set_compute_dtype(torch.float32)
+    ops.set_compute_dtype(torch.float32 if args.dtype == "f32" else torch.bfloat16)
     torch.manual_seed(1234)  # identical random-init weights on every rank
     model = DeepLab(backbone=args.backbone, output_stride=16, num_classes=args.classes, sync_bn=False,
                     freeze_bn=False, pretrained=False).to(dev)
@@ -287,7 +288,7 @@ def main():
         line = {"metric": "train_images_per_s (DeepLab-v3+ R101 513x513; + mc_dropout pool-images/s in 'mc_dropout')",
                 "value": round(train_ips, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                 "config": {"workload": "DeepLab-v3+ %s os16 %d-class %dx%d train step (fwd+CE+bwd+SGD), per-GPU batch %d"
                                        % (args.backbone, args.classes, s, s, b),
                            "global_batch": b * world, "parallelism": "dp%d" % world, "bn": "per-GPU",

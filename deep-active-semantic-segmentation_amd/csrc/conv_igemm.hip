@@ -477,6 +477,170 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ wgrad, bf16
+// Same decomposition as conv_wgrad_kernel, on v_mfma_f32_32x32x16_bf16.  Both operands want 8 consecutive
+// PIXELS (the reduction index) of one channel per lane while memory and the LDS image are [pixel][channel]:
+// exactly the case for gfx950's transposed LDS read.  ds_read_b64_tr_b16 hands lane i of a 16-lane group
+// column i of a 4-row x 16-column block, so two reads give the 8-deep fragment with no shuffles.  LDS rows
+// are pitched at (2*channels + 64) bytes so the four rows of a block fall in four different 64-B bank windows.
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2u lds_read_tr16(unsigned addr) {
+    v2u v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+
+template <int BMK, int BNC>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradP p) {
+    constexpr int BP = 64;                              // pixels per staged slab = 4 MFMA k-steps
+    constexpr int PA = BMK * 2 + 64, PB = BNC * 2 + 64;  // LDS row pitch in bytes
+    constexpr int TMW = BMK / 2, TNW = BNC / 2, MT = TMW / 32, NT = TNW / 32;
+    constexpr int CPR_A = BMK / 8, RPP_A = 256 / CPR_A, PASS_A = BP / RPP_A;  // 16-B chunks = 8 channels
+    constexpr int CPR_B = BNC / 8, RPP_B = 256 / CPR_B, PASS_B = BP / RPP_B;
+    static_assert(MT >= 1 && NT >= 1 && PASS_A >= 1 && PASS_B >= 1, "tile");
+
+    __shared__ __attribute__((aligned(16))) char smem[BP * PA + BP * PB];
+    char *As = smem;
+    char *Bs = smem + BP * PA;
+
+    int wg = blockIdx.x;
+    const int ps = wg % p.psplit;
+    wg /= p.psplit;
+    const int tap = wg % (p.R * p.S);
+    wg /= (p.R * p.S);
+    const int ct = wg % p.ctiles;
+    const int kt = wg / p.ctiles;
+    const int k0 = kt * BMK, c0 = ct * BNC;
+    const int r = tap / p.S, s = tap - r * p.S;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ohw = p.OH * p.OW;
+    const long pbeg = (long)ps * p.pix_per_split;
+    long pend = pbeg + p.pix_per_split;
+    if (pend > p.M) pend = p.M;
+
+    const int arow = tid / CPR_A, achunk = tid % CPR_A;
+    const int brow = tid / CPR_B, bchunk = tid % CPR_B;
+    const bf16_t *xg = reinterpret_cast<const bf16_t *>(p.x);
+    const bf16_t *dyg = reinterpret_cast<const bf16_t *>(p.dy);
+
+    int b_n[PASS_B], b_oh[PASS_B], b_ow[PASS_B];
+#pragma unroll
+    for (int j = 0; j < PASS_B; ++j) {
+        const long pix = pbeg + brow + j * RPP_B;
+        const int n = (int)(pix / ohw);
+        const int rem = (int)(pix - (long)n * ohw);
+        b_n[j] = n;
+        b_oh[j] = rem / p.OW;
+        b_ow[j] = rem - b_oh[j] * p.OW;
+    }
+    const bool a_kok = (k0 + achunk * 8) < p.K, b_cok = (c0 + bchunk * 8) < p.C;
+    const bf16_t *dy_col = dyg + k0 + achunk * 8;
+    const bf16_t *x_col = xg + c0 + bchunk * 8;
+    uint4 ra[PASS_A], rb[PASS_B];
+    auto load_stage = [&](long pb) {
+#pragma unroll
+        for (int j = 0; j < PASS_A; ++j) {
+            const long pix = pb + arow + j * RPP_A;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (pix < pend && a_kok) v = *reinterpret_cast<const uint4 *>(dy_col + pix * p.lddy);
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < PASS_B; ++j) {
+            const long pix = pb + brow + j * RPP_B;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (pix < pend && b_cok) {
+                const int iy = b_oh[j] * p.stride - p.pad + r * p.dil;
+                const int ix = b_ow[j] * p.stride - p.pad + s * p.dil;
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                    v = *reinterpret_cast<const uint4 *>(x_col + (((long)b_n[j] * p.H + iy) * p.W + ix) * p.ldx);
+            }
+            rb[j] = v;
+            b_ow[j] += BP;
+            while (b_ow[j] >= p.OW) {
+                b_ow[j] -= p.OW;
+                if (++b_oh[j] >= p.OH) {
+                    b_oh[j] = 0;
+                    ++b_n[j];
+                }
+            }
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // transposed-read lane roles: group g = lane>>4 -> channel half (g&1), pixel half (g>>1); inside the
+    // group lane 4q+p supplies the address of row q, 4-channel column chunk p
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const unsigned a_base = (unsigned)(size_t)As + (unsigned)((8 * (g >> 1) + q) * PA + (wm * TMW + 16 * (g & 1) + 4 * pp) * 2);
+    const unsigned b_base = (unsigned)(size_t)Bs + (unsigned)((8 * (g >> 1) + q) * PB + (wn * TNW + 16 * (g & 1) + 4 * pp) * 2);
+
+    long pb = pbeg;
+    if (pb < pend) load_stage(pb);
+    while (pb < pend) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PASS_A; ++j) *reinterpret_cast<uint4 *>(As + (arow + j * RPP_A) * PA + achunk * 16) = ra[j];
+#pragma unroll
+        for (int j = 0; j < PASS_B; ++j) *reinterpret_cast<uint4 *>(Bs + (brow + j * RPP_B) * PB + bchunk * 16) = rb[j];
+        __syncthreads();
+        pb += BP;
+        if (pb < pend) load_stage(pb);
+#pragma unroll
+        for (int ks = 0; ks < BP / 16; ++ks) {
+            v2u af[MT][2], bfr[NT][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                af[mt][0] = lds_read_tr16(a_base + (ks * 16) * PA + mt * 64);
+                af[mt][1] = lds_read_tr16(a_base + (ks * 16 + 4) * PA + mt * 64);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                bfr[nt][0] = lds_read_tr16(b_base + (ks * 16) * PB + nt * 64);
+                bfr[nt][1] = lds_read_tr16(b_base + (ks * 16 + 4) * PB + nt * 64);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                uint4 a4 = make_uint4(af[mt][0][0], af[mt][0][1], af[mt][1][0], af[mt][1][1]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    uint4 b4 = make_uint4(bfr[nt][0][0], bfr[nt][0][1], bfr[nt][1][0], bfr[nt][1][1]);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&a4),
+                                                                          *reinterpret_cast<const bf16x8 *>(&b4),
+                                                                          acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    const long rs = (long)p.R * p.S;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int c = c0 + wn * TNW + nt * 32 + (lane & 31);
+        if (c >= p.C) continue;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                const int k = k0 + wm * TMW + mt * 32 + row;
+                if (k < p.K) atomicAdd(p.dw + ((long)k * rs + tap) * p.C + c, acc[mt][nt][reg]);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ weights
 template <typename T>
 __global__ void weight_transform_kernel(const float *__restrict__ src, T *__restrict__ dst, int K, int R, int S,
@@ -546,6 +710,31 @@ template <typename T, int BMK, int BNC, bool WIDE = false> int launch_wgrad(Wgra
     hipLaunchKernelGGL((conv_wgrad_kernel<T, BMK, BNC, WIDE>), dim3((unsigned)grid), dim3(256), 0, st, p);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
+}
+
+template <int BMK, int BNC> int launch_wgrad_bf16(WgradP &p, hipStream_t st, long split) {
+    p.ktiles = (p.K + BMK - 1) / BMK;
+    p.ctiles = (p.C + BNC - 1) / BNC;
+    const long base = (long)p.ktiles * p.ctiles * p.R * p.S;
+    long pps = (p.M + split - 1) / split;
+    pps = (pps + 63) / 64 * 64;
+    p.pix_per_split = (int)pps;
+    p.psplit = (int)((p.M + pps - 1) / pps);
+    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BMK, BNC>), dim3((unsigned)(base * p.psplit)), dim3(256), 0, st, p);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+int dispatch_wgrad_bf16(WgradP &p, hipStream_t st) {
+    const long rs = (long)p.R * p.S;
+    auto base_of = [&](int bk, int bc) { return (long)((p.K + bk - 1) / bk) * ((p.C + bc - 1) / bc) * rs; };
+    const long target = 768, min_slabs = 16;  // slabs of 32 pixels, as in the f32 heuristic
+    if (p.K > 64 && p.C > 64) {
+        const long b = base_of(128, 128);
+        const long sp = wgrad_split(b, p.M, target, min_slabs);
+        if (b * sp >= 400) return launch_wgrad_bf16<128, 128>(p, st, sp);
+    }
+    return launch_wgrad_bf16<64, 64>(p, st, wgrad_split(base_of(64, 64), p.M, target, min_slabs));
 }
 
 template <typename T> int dispatch_wgrad(WgradP &p, hipStream_t st) {
@@ -657,6 +846,7 @@ extern "C" int dass_conv2d_wgrad(const void *x, int64_t ldx, const void *dy, int
     p.N = N; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K; p.R = R; p.S = S;
     p.stride = stride; p.pad = pad; p.dil = dil;
     p.M = N * OH * OW;
+    if (dtype == DASS_BF16 && C % 8 == 0 && K % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0) return dispatch_wgrad_bf16(p, st);
     return dtype == DASS_F32 ? dispatch_wgrad<float>(p, st) : dispatch_wgrad<bf16_t>(p, st);
 }
 

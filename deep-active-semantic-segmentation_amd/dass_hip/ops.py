@@ -306,7 +306,7 @@ class _ConvBnAct(torch.autograd.Function):
         res_t = ldr = None
         if residual is not None:
             res_t, ldr = rows(_cast_act(residual))
-        kpad = _pad_to(k, 4)
+        kpad = _pad_to(k, _epv(dt))
         if kpad != k:  # e.g. the 19-class classifier: keep a zero pad column so rows stay 16-B aligned
             out = zeros_act(n, kpad, oh, ow, dt, dev)[:, :k]
         else:
@@ -366,7 +366,7 @@ class _ConvBnAct(torch.autograd.Function):
         dout_r, lddo = rows(_cast_act(dout))
         dgamma = dbeta = dbias = dres = None
         simple = (not ctx.has_bn) and spec.act == ACT_NONE and nc_scale is None and not ctx.has_res
-        kp = _pad_to(k, 4)
+        kp = _pad_to(k, _epv(dt))
         if simple:
             # conv (+bias): dy = dout.  (K may be unaligned: work on a zero-padded copy of width kp)
             if lddo % 4 != 0 or kp != k:
@@ -699,7 +699,7 @@ class _UpsampleToNCHW(torch.autograd.Function):
     def backward(ctx, g):
         n, c, ih, iw, oh, ow = ctx.dims
         g = g.contiguous().float()
-        cp = _pad_to(c, 4)
+        cp = _pad_to(c, _epv(ctx.dt))
         dx = zeros_act(n, cp, ih, iw, ctx.dt, g.device) if cp != c else new_act(n, c, ih, iw, ctx.dt, g.device)
         check(lib.dass_bilinear_bwd(_p(g), 0, _p(dx), cp, n, ih, iw, c, oh, ow, 1, _dt(dx), _stream()),
               "dass_bilinear_bwd")

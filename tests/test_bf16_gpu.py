@@ -1,0 +1,153 @@
+"""bf16 perf mode (bf16 storage, f32 MFMA accumulate) -- NOT the parity mode.  Kernels are checked against
+f32 math on bf16-rounded operands (so only the output rounding / accumulation order differ), and the
+end-to-end deviation from the f32 reference goldens is MEASURED and bounded loosely (bf16
+storage cannot meet the 1e-3 logits / bit-exact argmax contract; those are asserted in f32 mode only)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(autouse=True)
+def _bf16_mode():
+    from dass_hip import ops
+
+    ops.set_compute_dtype(torch.bfloat16)
+    yield
+    ops.set_compute_dtype(torch.float32)
+
+
+def _r(t):
+    return t.bfloat16().float()
+
+
+def _close(a, b, tol, what):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    scale = max(b.abs().max().item(), 1e-6)
+    err = (a - b).abs().max().item() / scale
+    assert err <= tol, "%s: rel err %.3e > %.1e" % (what, err, tol)
+
+
+CASES = [(2, 64, 17, 17, 64, 1, 1, 0, 1), (2, 32, 19, 23, 96, 3, 1, 1, 1), (1, 128, 33, 33, 256, 3, 1, 6, 6),
+         (2, 48, 21, 21, 128, 3, 2, 1, 1), (2, 256, 9, 9, 512, 1, 2, 0, 1), (1, 304, 17, 17, 256, 3, 1, 1, 1),
+         (2, 512, 9, 9, 512, 3, 1, 2, 2), (3, 64, 9, 9, 48, 1, 1, 2, 1), (1, 2048, 5, 5, 256, 1, 1, 0, 1),
+         (4, 256, 33, 33, 256, 3, 1, 1, 1)]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_bf16(case):
+    from dass_hip import ops
+
+    n, c, h, w, k, ks, stride, pad, dil = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = _r(torch.randn(n, c, h, w, generator=g))
+    conv = nn.Conv2d(c, k, ks, stride, pad, dil, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(_r(torch.randn(conv.weight.shape, generator=g) * (2.0 / (c * ks * ks)) ** 0.5))
+    xr = x.clone().requires_grad_(True)
+    yr = conv(xr)
+    go = _r(torch.randn(yr.shape, generator=g))
+    yr.backward(go)
+    conv_d = nn.Conv2d(c, k, ks, stride, pad, dil, bias=False).cuda()
+    with torch.no_grad():
+        conv_d.weight.copy_(conv.weight)
+    conv_d.weight.data = conv_d.weight.data.contiguous(memory_format=torch.channels_last)
+    xd = x.cuda().bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    yd = ops.conv_bn_act(xd, conv_d)
+    assert yd.dtype == torch.bfloat16
+    _close(yd, yr, 1e-2, "bf16 conv fwd %s" % (case,))
+    yd.backward(go.cuda().bfloat16().contiguous(memory_format=torch.channels_last))
+    _close(xd.grad, xr.grad, 1e-2, "bf16 conv dgrad %s" % (case,))
+    assert conv_d.weight.grad.dtype == torch.float32
+    _close(conv_d.weight.grad, conv.weight.grad, 2e-3, "bf16 conv wgrad (f32 accumulate) %s" % (case,))
+
+
+def test_conv_bn_relu_residual_bf16():
+    from dass_hip import ops
+    import copy
+
+    g = torch.Generator().manual_seed(3)
+    n, c, h, w, k = 2, 64, 15, 15, 128
+    x, res = _r(torch.randn(n, c, h, w, generator=g)), _r(torch.randn(n, k, h, w, generator=g))
+    conv, bn = nn.Conv2d(c, k, 3, 1, 2, 2, bias=False), nn.BatchNorm2d(k)
+    with torch.no_grad():
+        conv.weight.copy_(_r(conv.weight))
+        bn.weight.copy_(torch.rand(k, generator=g) + 0.5)
+    conv_d, bn_d = copy.deepcopy(conv).cuda(), copy.deepcopy(bn).cuda()
+    xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    ref = F.relu(bn(conv(xr)) + rr)
+    go = _r(torch.randn(ref.shape, generator=g))
+    ref.backward(go)
+    cl = lambda t: t.cuda().bfloat16().contiguous(memory_format=torch.channels_last)  # noqa: E731
+    xd, rd = cl(x).requires_grad_(True), cl(res).requires_grad_(True)
+    out = ops.conv_bn_act(xd, conv_d, bn_d, ops.ACT_RELU, residual=rd)
+    _close(out, ref, 3e-2, "fwd")
+    out.backward(cl(go))
+    _close(xd.grad, xr.grad, 5e-2, "dx")
+    # dy has zero mean per channel only in exact arithmetic; bf16-rounded dy times the positive-mean ReLU input
+    # leaves a common-mode residue (stock PyTorch autocast-bf16 shows the same): loose bound by design
+    _close(conv_d.weight.grad, conv.weight.grad, 2e-1, "dw")
+    _close(bn_d.weight.grad, bn.weight.grad, 5e-2, "dgamma")
+    _close(bn_d.running_var, bn.running_var, 2e-2, "running_var")
+
+
+@pytest.mark.parametrize("tag,backbone", [("mobilenet", "mobilenet"), ("resnet50", "resnet")])
+def test_e2e_bf16_deviation_is_reported(tag, backbone):
+    from models.deeplab import DeepLab
+    from oracle import deeplab_cpu as O
+
+    g = np.load(os.path.join(GOLD, "e2e_%s.npz" % tag))
+    n, hw, ncls = [int(v) for v in g["meta"]]
+    om = O.ODeepLab(backbone, 16, ncls)
+    O.fill_state_dict(om, seed=1)
+    pm = DeepLab(backbone=backbone, num_classes=ncls, sync_bn=False, pretrained=False)
+    pm.load_state_dict(om.state_dict())
+    pm = pm.cuda().eval()
+    x, _ = O.synthetic_batch(n, hw, hw, ncls)
+    with torch.no_grad():
+        out = pm(x.cuda())
+    assert out.dtype == torch.float32  # logits leave the module as NCHW f32 in every mode
+    ref = torch.from_numpy(g["logits"])
+    rel = (out.cpu() - ref).abs().mean().item() / ref.abs().mean().item()
+    flips = (out.argmax(1).cpu() != torch.from_numpy(g["argmax"]).long()).float().mean().item()
+    print("bf16 %s: mean |dlogit| / mean |logit| = %.3f, argmax flip rate = %.3f (untrained net)" % (tag, rel, flips))
+    assert rel < 0.25 and flips < 0.35 and torch.isfinite(out).all()
+
+
+def test_train_step_and_mc_votes_bf16():
+    from models.deeplab import DeepLab
+    from utils.loss import SegmentationLosses
+    from oracle import deeplab_cpu as O
+    from oracle import selection_cpu as S
+
+    om = O.ODeepLab("mobilenet", 16, 19)
+    O.fill_state_dict(om, seed=4, randomize_bn_stats=False)
+    pm = DeepLab(backbone="mobilenet", num_classes=19, sync_bn=False, pretrained=False)
+    pm.load_state_dict(om.state_dict())
+    pm = pm.cuda().train()
+    om.train()
+    x, lab = O.synthetic_batch(2, 97, 97, 19, first_index=200)
+    m1, m2 = O.dropout_masks(2, 4, seed=5)
+    lo = S.ce_loss(om(x, (m1[0], m2[0])), lab)
+    loss = SegmentationLosses(cuda=True).build_loss("ce")(pm(x.cuda(), dropout_masks=(m1[0].cuda(), m2[0].cuda())), lab.cuda())
+    loss.backward()
+    assert abs(loss.item() - lo.item()) <= 5e-2 * abs(lo.item()), (loss.item(), lo.item())
+    lo.backward()
+    gref = om.decoder.last_conv[0].weight.grad
+    cos = F.cosine_similarity(pm.decoder.last_conv[0].weight.grad.cpu().flatten(), gref.flatten(), dim=0).item()
+    print("bf16 train step: loss %.4f (f32 oracle %.4f), decoder wgrad cosine %.4f" % (loss.item(), lo.item(), cos))
+    # stock PyTorch autocast(bf16) on the same untrained net and inputs gives cosine 0.745 for this tensor (measured)
+    assert cos > 0.6
+    pm.eval()
+    om.eval()
+    votes = pm.mc_dropout_votes(x.cuda(), 4, masks=(m1, m2)).cpu().long()
+    ref = S.mc_votes(om, x, (m1, m2))
+    agree = (votes == ref).float().mean().item()
+    print("bf16 MC votes agree with the f32 oracle on %.3f of pixels" % agree)
+    assert agree > 0.6
