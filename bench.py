@@ -291,6 +291,10 @@ def main():
     env.world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # rehearsal knobs for a 1-GPU box: DASS_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # DASS_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device); never set by the driver
+    if os.environ.get("DASS_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     env.dev = torch.device("cuda", local_rank)
     env.dist = None
@@ -298,7 +302,7 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")  # RCCL on ROCm
+        dist.init_process_group(backend=os.environ.get("DASS_BENCH_BACKEND", "nccl"))  # nccl = RCCL on ROCm
         env.dist = dist
 
     head = run_mode(args, env, args.dtype, args.steps, args.warmup)

@@ -73,7 +73,6 @@ template <> __device__ __forceinline__ uint4 scale_vec<bf16_t>(uint4 v, const fl
 }
 
 constexpr int ROWB = 144;  // LDS bytes per staged row (128 data + 16 pad)
-constexpr long kInvalidOff = 1l << 62;  // WIDE mode: legal row offsets may be negative (ix0 < 0)
 
 // WIDE ("row-tap") variant for the 3-channel network stems (7x7/s2 ResNet, 3x3/s2 MobileNet): a tap is a
 // whole kernel ROW -- the S*Cin input values x[n, iy, ix0 .. ix0+S-1, :] are contiguous in a dense NHWC
@@ -100,11 +99,17 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 
     const int lrow = tid >> 3, lchunk = tid & 7;
     const int wm = wave / WN, wn = wave - wm * WN;
 
-    // ---- per-thread description of the A rows it stages
-    int a_iy0[AR], a_ix0[AR], a_n[AR];
-    long a_nb[AR];
+    // ---- per-thread description of the A rows it stages.  For every tap the input pixel of a row is
+    // (by + ey(r), bx + ex(s)) with (ey, ex) the same for all rows, so a row keeps ONE base offset and a
+    // validity bit per tap; the per-slab address is base + a wave-uniform tap delta + channel offset.
+    //   forward conv         : by = oh*stride - pad, ey = r*dil
+    //   phase of a dgrad     : by = ohs (sub-grid index), ey = (oy_add - pad + r*dil) / ustride  (exact)
+    int a_by[AR], a_bx[AR], a_n[AR];
+    long a_base[AR];
+    unsigned long long a_vmask[AR];
     bool a_ok[AR];
     const int ohw = p.OHs * p.OWs;
+    const bool phase = p.o_mul != 1;
 #pragma unroll
     for (int j = 0; j < AR; ++j) {
         const int m = m0 + lrow + 32 * j;
@@ -113,82 +118,61 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 
         const int n = mm / ohw;
         const int rem = mm - n * ohw;
         const int ohs = rem / p.OWs;
-        const int oh = ohs * p.o_mul + p.oy_add;
-        const int ow = (rem - ohs * p.OWs) * p.o_mul + p.ox_add;
-        a_iy0[j] = oh * p.stride - p.pad;
-        a_ix0[j] = ow * p.stride - p.pad;
+        const int ows = rem - ohs * p.OWs;
+        a_by[j] = phase ? ohs : ohs * p.stride - p.pad;
+        a_bx[j] = phase ? ows : ows * p.stride - p.pad;
         a_n[j] = n;
-        a_nb[j] = (long)n * p.H * p.W;
+        a_base[j] = (((long)n * p.H + a_by[j]) * p.W + a_bx[j]) * p.ldx * ES;
+        a_vmask[j] = 0ull;
     }
+    auto tap_ey = [&](int r) -> int { return phase ? (p.oy_add - p.pad + r * p.dil) / p.ustride : r * p.dil; };
+    auto tap_ex = [&](int s) -> int { return phase ? (p.ox_add - p.pad + s * p.dil) / p.ustride : s * p.dil; };
 
-    auto tap_pixel = [&](int j, int r, int s, long &pix) -> bool {
-        int iy = a_iy0[j] + r * p.dil, ix = a_ix0[j] + s * p.dil;
-        if (WIDE) {  // only the row must exist; columns are checked per element
-            pix = a_nb[j] + (long)iy * p.W + ix;
-            return a_ok[j] && iy >= 0 && iy < p.H;
-        }
-        bool ok = a_ok[j] && iy >= 0 && ix >= 0;
-        if (p.ustride > 1) {
-            ok = ok && (iy % p.ustride == 0) && (ix % p.ustride == 0);
-            iy /= p.ustride;
-            ix /= p.ustride;
-        }
-        ok = ok && iy < p.H && ix < p.W;
-        pix = a_nb[j] + (long)iy * p.W + ix;
-        return ok;
-    };
-
-    // ---- which taps touch this tile at all
+    // ---- which taps touch this tile at all (and, per row, which taps are inside the image)
     const int ntaps = p.R * p.S;
     unsigned long long tapmask = 0ull;
     for (int t = 0; t < ntaps; ++t) {
         if (!((p.tap_allow >> t) & 1ull)) continue;  // uniform: host-side phase filter
         const int r = t / p.S, s = t - r * p.S;
+        const int ey = tap_ey(r), ex = tap_ex(s);
         bool any = false;
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
-            long pix;
-            any = any || tap_pixel(j, r, s, pix);
+            const int iy = a_by[j] + ey, ix = a_bx[j] + ex;
+            // WIDE: only the row must exist; columns are checked per element when loading
+            const bool ok = a_ok[j] && iy >= 0 && iy < p.H && (WIDE || (ix >= 0 && ix < p.W));
+            if (ok) a_vmask[j] |= (1ull << t);
+            any = any || ok;
         }
         if (__syncthreads_or((int)any)) tapmask |= (1ull << t);
     }
 
-    // Address arithmetic is hoisted out of the channel-slab loop: per-row byte offsets are recomputed
-    // only when the tap changes, so a slab costs one add per load (VALU issue slots are not free next
-    // to 64-cycle MFMAs).
     long b_off[BR];
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
         const int k = n0 + lrow + 32 * j;
         b_off[j] = k < p.K ? (long)k * p.wk_stride * ES : -1;
     }
-    long a_off[AR];
-    long tap_w_off = 0;
-    auto set_tap = [&](int t) {
-        const int r = t / p.S, s = t - r * p.S;
-#pragma unroll
-        for (int j = 0; j < AR; ++j) {
-            long pix;
-            a_off[j] = tap_pixel(j, r, s, pix) ? pix * p.ldx * ES : (WIDE ? kInvalidOff : -1);
-        }
-        tap_w_off = (long)t * p.C * ES;
-    };
     uint4 ra[AR], rb[BR];
-    auto load_stage = [&](int cc) {
+    auto load_stage = [&](int t, int cc) {
+        const int r = t / p.S, s = t - r * p.S;
+        const long tap_x_off = ((long)tap_ey(r) * p.W + tap_ex(s)) * p.ldx * ES;  // wave-uniform
+        const long tap_w_off = (long)t * p.C * ES;
         const int c = cc * BK + lchunk * EPV;
         const bool okc = c < p.C;
         const long cb = (long)c * ES;
         if (WIDE) {
-            // element-wise (unaligned, per-column validity): x index j -> column ix0 + j / Cin
+            // element-wise (unaligned, per-column validity): x index q -> column bx + q / Cin
 #pragma unroll
             for (int j = 0; j < AR; ++j) {
                 T tmp[EPV];
+                const bool rowok = (a_vmask[j] >> t) & 1ull;
 #pragma unroll
                 for (int e = 0; e < EPV; ++e) {
                     const int q = c + e;
-                    const int ix = a_ix0[j] + q / p.wide_c;
-                    const bool ok = a_off[j] != kInvalidOff && q < p.C && ix >= 0 && ix < p.W;
-                    tmp[e] = ok ? *reinterpret_cast<const T *>(p.x + a_off[j] + cb + e * ES) : (T)0;
+                    const int ix = a_bx[j] + q / p.wide_c;
+                    const bool ok = rowok && q < p.C && ix >= 0 && ix < p.W;
+                    tmp[e] = ok ? *reinterpret_cast<const T *>(p.x + a_base[j] + tap_x_off + cb + e * ES) : (T)0;
                 }
                 ra[j] = *reinterpret_cast<const uint4 *>(tmp);
             }
@@ -205,8 +189,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (a_off[j] >= 0 && okc) {
-                v = *reinterpret_cast<const uint4 *>(p.x + a_off[j] + cb);
+            if (((a_vmask[j] >> t) & 1ull) && okc) {
+                v = *reinterpret_cast<const uint4 *>(p.x + a_base[j] + tap_x_off + cb);
                 if (p.in_scale) v = scale_vec<T>(v, p.in_scale + (long)a_n[j] * p.C + c);
             }
             ra[j] = v;
@@ -227,17 +211,16 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // ---- reduction loop over (active tap, channel slab)
+    // ---- reduction loop: channel slab OUTER, active taps INNER -- consecutive slabs re-read the same
+    // (shifted) neighbourhood of the input, so the 9x tap re-reads are served by L1/L2 instead of the fabric
     unsigned long long rem_mask = tapmask;
     int cur_t = -1, cur_cc = 0;
     bool have = false;
     if (rem_mask) {
         cur_t = __builtin_ctzll(rem_mask);
         rem_mask &= rem_mask - 1;
-        cur_cc = 0;
         have = true;
-        set_tap(cur_t);
-        load_stage(cur_cc);
+        load_stage(cur_t, cur_cc);
     }
     while (have) {
         __syncthreads();  // everyone finished reading the previous slab
@@ -248,18 +231,17 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 
         __syncthreads();
 
         // advance and prefetch the next slab (loads stay in flight under the MFMAs)
-        ++cur_cc;
-        if (cur_cc >= p.cchunks) {
-            cur_cc = 0;
-            if (rem_mask) {
-                cur_t = __builtin_ctzll(rem_mask);
-                rem_mask &= rem_mask - 1;
-                set_tap(cur_t);
-            } else {
-                have = false;
-            }
+        if (rem_mask) {
+            cur_t = __builtin_ctzll(rem_mask);
+            rem_mask &= rem_mask - 1;
+        } else if (++cur_cc < p.cchunks) {
+            rem_mask = tapmask;
+            cur_t = __builtin_ctzll(rem_mask);
+            rem_mask &= rem_mask - 1;
+        } else {
+            have = false;
         }
-        if (have) load_stage(cur_cc);
+        if (have) load_stage(cur_t, cur_cc);
 
         const char *ap = As + (wm * TMW + (lane & 31)) * ROWB + (lane >> 5) * 16;
         const char *bp = Bs + (wn * TNW + (lane & 31)) * ROWB + (lane >> 5) * 16;
@@ -825,6 +807,7 @@ extern "C" int dass_conv2d_igemm(const void *x, int64_t ldx, const void *w, void
             }
         return DASS_OK;
     }
+    if (ustride > 1) return DASS_ERR_UNSUPPORTED;  // transposed addressing exists only in the phase-decomposed form
     return dtype == DASS_F32 ? dispatch_conv<float>(p, st) : dispatch_conv<bf16_t>(p, st);
 }
 
