@@ -399,3 +399,61 @@ def test_inverted_residual_blocks_exact():
                 e32 = (res["f32"][k] - ref).norm().item() / max(ref.norm().item(), 1e-12)
                 ehip = (res["hip"][k] - ref).norm().item() / max(ref.norm().item(), 1e-12)
                 assert ehip <= 5 * e32 + 2e-6, ((cin, cout, stride, dil, t, hw), train, k, e32, ehip)
+
+
+def test_region_maps_and_remaining_ceal_selectors_vs_oracle():
+    """create_region_maps (mc_dropout.py:123-171) end to end on a synthetic pool, and the margin / fusion
+    selectors (ceal.py:72-98,133-140), against the oracle composing the same steps on the CPU."""
+    ops, O, S = _setup()
+    import constants
+    from active_selection.ceal import ActiveSelectionCEAL
+    from active_selection.mc_dropout import ActiveSelectionMCDropout
+
+    ncls, hw, T, region = 19, 65, 4, 17
+    pm, om = _product("mobilenet", ncls, O, seed=12)
+    pm.eval()
+    om.eval()
+    keys = [("img_%03d" % i).encode("ascii") for i in range(4)]
+    pool = {k: O.synthetic_batch(1, hw, hw, ncls, first_index=700 + i) for i, k in enumerate(keys)}
+
+    def factory(images, include_labels, bs=2):
+        for i in range(0, len(images), bs):
+            chunk = images[i:i + bs]
+            yield {"image": torch.cat([pool[k][0] for k in chunk]), "label": torch.cat([pool[k][1] for k in chunk])}
+
+    # --- CEAL margin + fusion
+    sel = ActiveSelectionCEAL(ncls, None, hw, 2, loader_factory=factory)
+    with torch.no_grad():
+        lo = torch.cat([om(pool[k][0]) for k in keys])
+    labs = torch.cat([pool[k][1] for k in keys])
+    conf, margin, ent = S.softmax_score_maps(lo, labs, ncls)
+    margin_scores = [float(np.mean(m.numpy())) for m in margin]
+    assert list(sel.get_least_margin_samples(pm, keys, 2)) == S.select_top(margin_scores, keys, 2, reverse=False)
+    fused = sel.get_fusion_of_confidence_margin_entropy_samples(pm, keys, 2)
+    assert len(fused) == 2 and set(fused) <= set(keys)
+
+    # --- region maps: votes come from the HIP model (dropout draws are its own), so the oracle re-derives
+    # everything downstream of the votes: entropy -> suppression -> box sums -> global min-max -> NMS
+    class Recorder(ActiveSelectionMCDropout):
+        def _votes(self, model, image_batch, steps, masks=None):
+            v = super()._votes(model, image_batch, steps, masks)
+            self.seen.append(v.cpu())
+            return v
+
+    rsel = Recorder(ncls, None, hw, 2, loader_factory=factory)
+    rsel.seen = []
+    constants.MC_STEPS = T
+    existing = [[], [(5, 5, region, region)], [], []]
+    got_regions, got_count = rsel.create_region_maps(pm, keys, existing, region, 2)
+    constants.MC_STEPS = 20
+    assert all(not m.training for m in pm.modules() if isinstance(m, torch.nn.Dropout2d))  # model.eval() on exit
+    votes = torch.cat(rsel.seen)
+    assert votes.shape == (4, T, hw, hw) and votes.dtype == torch.uint8
+    maps = S.vote_entropy_maps(votes.long(), labs, ncls)
+    for i, regs in enumerate(existing):
+        S.suppress_labeled(maps[i], regs)
+    score = torch.stack([S.box_sum(m, region) for m in maps])
+    S.minmax_normalize(score)
+    want_regions, want_count = S.square_nms(score, region, (2 * hw * hw) / (region * region))
+    assert got_count == want_count
+    assert got_regions == {keys[i]: r for i, r in enumerate(want_regions) if r}
