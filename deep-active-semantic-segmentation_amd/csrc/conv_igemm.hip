@@ -658,14 +658,26 @@ template <typename T, int BM, int BN, int WM, int WN, bool WIDE = false> int lau
     return DASS_OK;
 }
 
+// Tile choice by a wave-quantisation cost model.  Workgroups are dealt round-robin over 256 CUs and the
+// kernel is MFMA-bound, so a launch takes ceil(workgroups / 256) "rounds" of one tile each (the busiest CU
+// decides), times the tile's MFMA work over its efficiency (small tiles stage more bytes per flop and leave
+// fewer MFMAs between barriers; a single workgroup per CU has nothing to overlap its loads with).  Padded
+// rows/columns of edge tiles are paid for.  Efficiencies from tools/conv_sweep.py.
 template <typename T> int dispatch_conv(ConvP &p, hipStream_t st) {
     constexpr int EPV = 16 / sizeof(T);
     p.cchunks = (p.C + 8 * EPV - 1) / (8 * EPV);
-    const long target = 512;  // >= 2 workgroups per CU
-    auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.K + bn - 1) / bn); };
     if (p.K <= 32) return launch_conv<T, 128, 32, 4, 1>(p, st);
-    if (p.K > 64 && tiles(128, 128) >= target) return launch_conv<T, 128, 128, 2, 2>(p, st);
-    if (tiles(128, 64) >= target) return launch_conv<T, 128, 64, 2, 2>(p, st);
+    auto cost = [&](int bm, int bn, double eff) {
+        const long wgs = (long)((p.M + bm - 1) / bm) * ((p.K + bn - 1) / bn);
+        const long rounds = (wgs + 255) / 256;
+        const double lonely = wgs < 256 ? 0.7 : 1.0;  // one workgroup per CU: no partner to hide latency
+        return (double)rounds * bm * bn / (eff * lonely);
+    };
+    const double c128 = p.K > 64 ? cost(128, 128, 1.0) : 1e30;
+    const double c12864 = cost(128, 64, 0.93);
+    const double c64 = cost(64, 64, 0.85);
+    if (c128 <= c12864 && c128 <= c64) return launch_conv<T, 128, 128, 2, 2>(p, st);
+    if (c12864 <= c64) return launch_conv<T, 128, 64, 2, 2>(p, st);
     return launch_conv<T, 64, 64, 2, 2>(p, st);
 }
 
