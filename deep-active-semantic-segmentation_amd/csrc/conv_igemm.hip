@@ -322,13 +322,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
     __shared__ __attribute__((aligned(16))) float As[BP * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[BP * LDB];
 
-    int wg = blockIdx.x;
-    const int ps = wg % p.psplit;
-    wg /= p.psplit;
+    // Workgroups that read the SAME pixel range (all taps, all K/C tiles of one pixel split) get consecutive
+    // logical ids and, through the XCD remap, the same L2: dY / X slabs come from HBM once per split instead
+    // of once per (tap, tile).
+    int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int tap = wg % (p.R * p.S);
     wg /= (p.R * p.S);
     const int ct = wg % p.ctiles;
-    const int kt = wg / p.ctiles;
+    wg /= p.ctiles;
+    const int kt = wg % p.ktiles;
+    const int ps = wg / p.ktiles;
     const int k0 = kt * BMK, c0 = ct * BNC;
     const int r = tap / p.S, s = tap - r * p.S;
 
@@ -486,13 +489,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradP p)
     char *As = smem;
     char *Bs = smem + BP * PA;
 
-    int wg = blockIdx.x;
-    const int ps = wg % p.psplit;
-    wg /= p.psplit;
+    // Workgroups that read the SAME pixel range (all taps, all K/C tiles of one pixel split) get consecutive
+    // logical ids and, through the XCD remap, the same L2: dY / X slabs come from HBM once per split instead
+    // of once per (tap, tile).
+    int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int tap = wg % (p.R * p.S);
     wg /= (p.R * p.S);
     const int ct = wg % p.ctiles;
-    const int kt = wg / p.ctiles;
+    wg /= p.ctiles;
+    const int kt = wg % p.ktiles;
+    const int ps = wg / p.ktiles;
     const int k0 = kt * BMK, c0 = ct * BNC;
     const int r = tap / p.S, s = tap - r * p.S;
 
