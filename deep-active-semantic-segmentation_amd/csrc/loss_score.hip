@@ -399,6 +399,53 @@ __global__ __launch_bounds__(256) void argmax_stage2_kernel(const double *__rest
     }
 }
 
+// ---------------------------------------------------------------------------------------- max-subset
+// greedy facility location of active_selection/max_subset.py:17-39: D[i][j] = ||a_i - b_j||_2 (f64, as
+// sklearn's pairwise_distances on float64 rows), score_j = -sum_i min(mind_i, D[i][j]), mind update by column.
+__global__ __launch_bounds__(256) void pairwise_dist_kernel(const float *__restrict__ a, long n,
+                                                            const float *__restrict__ b, long m, int d,
+                                                            double *__restrict__ D) {
+    const long pair = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= n * m) return;
+    const long i = pair / m, j = pair - i * m;
+    const int lane = threadIdx.x & 63;
+    const float *x = a + i * d, *y = b + j * d;
+    double s = 0.0;
+    for (int q = lane; q < d; q += 64) {
+        const double df = (double)x[q] - (double)y[q];
+        s += df * df;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) D[pair] = sqrt(s);
+}
+
+// one block per candidate column j; selected columns get -inf
+__global__ __launch_bounds__(256) void facility_scores_kernel(const double *__restrict__ D, long n, long m,
+                                                              const double *__restrict__ mind,
+                                                              const uint8_t *__restrict__ selected,
+                                                              double *__restrict__ scores) {
+    __shared__ double sh[256];
+    const long j = blockIdx.x;
+    double s = 0.0;
+    for (long i = threadIdx.x; i < n; i += 256) s += fmin(mind[i], D[i * m + j]);
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) scores[j] = selected[j] ? -INFINITY : -sh[0];
+}
+
+__global__ void facility_update_kernel(const double *__restrict__ D, long n, long m, const long *__restrict__ jptr,
+                                       double *__restrict__ mind, uint8_t *__restrict__ selected) {
+    const long j = jptr[0];
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) mind[i] = fmin(mind[i], D[i * m + j]);
+    if (i == 0) selected[j] = 1;
+}
+
 __global__ void sgd_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ buf, long n,
                            float lr, float momentum, float wd, int first) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -563,3 +610,30 @@ extern "C" int dass_sgd_step(float *p, const float *g, float *buf, int64_t n, fl
 
 extern "C" int dass_version(void) { return 1; }
 extern "C" const char *dass_arch(void) { return "gfx950"; }
+
+extern "C" int dass_pairwise_dist_f64(const float *a, int64_t n, const float *b, int64_t m, int d, double *D, void *stream) {
+    if (!a || !b || !D || n <= 0 || m <= 0 || d <= 0) return DASS_ERR_ARG;
+    const long pairs = (long)n * m;
+    hipLaunchKernelGGL(pairwise_dist_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, (long)n,
+                       b, (long)m, d, D);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_facility_scores(const double *D, int64_t n, int64_t m, const double *mind, const uint8_t *selected,
+                                    double *scores, void *stream) {
+    if (!D || !mind || !selected || !scores || n <= 0 || m <= 0) return DASS_ERR_ARG;
+    hipLaunchKernelGGL(facility_scores_kernel, dim3((unsigned)m), dim3(256), 0, (hipStream_t)stream, D, (long)n, (long)m, mind,
+                       selected, scores);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_facility_update(const double *D, int64_t n, int64_t m, const int64_t *col, double *mind,
+                                    uint8_t *selected, void *stream) {
+    if (!D || !col || !mind || !selected || n <= 0 || m <= 0) return DASS_ERR_ARG;
+    hipLaunchKernelGGL(facility_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, D, (long)n,
+                       (long)m, (const long *)col, mind, selected);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}

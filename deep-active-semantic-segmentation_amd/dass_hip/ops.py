@@ -986,3 +986,39 @@ def square_nms(score_maps, region_size, max_selection_count):
     for i, r, c in picks[:cnt].tolist():
         regions[i].append((r, c, region_size, region_size))
     return regions, cnt
+
+
+def max_representative(all_features, candidate_features, count):
+    """greedy facility location (max_subset.py:17-39) on the device: each pick maximises
+    -sum_i min(mind_i, D[i][j]) over unselected candidates (first max wins, like the reference's strict '>')."""
+    a = all_features.contiguous().float()
+    b = candidate_features.contiguous().float()
+    n, d = a.shape
+    m = b.shape[0]
+    dev = a.device
+    dist = torch.empty((n, m), dtype=torch.float64, device=dev)
+    check(lib.dass_pairwise_dist_f64(_p(a), n, _p(b), m, d, _p(dist), _stream()), "dass_pairwise_dist_f64")
+    mind = torch.full((n,), float("inf"), dtype=torch.float64, device=dev)
+    selected = torch.zeros((m,), dtype=torch.uint8, device=dev)
+    scores = torch.empty((m,), dtype=torch.float64, device=dev)
+    nb = lib.dass_argmax_blocks(m)
+    pval = torch.empty((nb,), dtype=torch.float64, device=dev)
+    pidx = torch.empty((nb,), dtype=torch.int64, device=dev)
+    picks = torch.empty((max(count, 1),), dtype=torch.int64, device=dev)
+    for j in range(count):
+        check(lib.dass_facility_scores(_p(dist), n, m, _p(mind), _p(selected), _p(scores), _stream()), "dass_facility_scores")
+        check(lib.dass_argmax_f64(_p(scores), m, _p(pval), _p(pidx), _p(picks[j:j + 1]), None, _stream()), "dass_argmax_f64")
+        check(lib.dass_facility_update(_p(dist), n, m, _p(picks[j:j + 1]), _p(mind), _p(selected), _stream()),
+              "dass_facility_update")
+    return picks[:count]
+
+
+def add_noise_(x, std, generator=None):
+    """x += N(0, std) (deeplab.py:39-56, mc_noise.py:24-25): torch draws the gaussians, the add is dass_add_channels"""
+    xs, ld = rows(x)
+    n, c, h, w = xs.shape
+    noise = torch.randn((n, h, w, c), device=xs.device, dtype=torch.float32, generator=generator).mul_(std).to(xs.dtype)
+    if c % 4 == 0 and ld % 4 == 0:
+        check(lib.dass_add_channels(_p(noise), c, _p(xs), ld, n * h * w, c, _dt(xs), _stream()), "dass_add_channels")
+        return xs
+    return xs + noise.permute(0, 3, 1, 2)

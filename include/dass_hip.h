@@ -226,6 +226,15 @@ int dass_affine_inplace(float *v, int64_t n, const float *min_max, void *stream)
 int dass_square_nms(float *maps, int N, int H, int W, int region, int max_picks, float *imax, int *iarg,
                     int *picks, int *count, void *stream);
 
+/* greedy facility location of active_selection/max_subset.py:17-39 ("max representative samples"):
+ * D[i][j] = ||a_i - b_j||_2 in f64; scores[j] = -sum_i min(mind[i], D[i][j]) (-inf for selected columns);
+ * update: mind[i] = min(mind[i], D[i][*col]), selected[*col] = 1 (column index read from device memory). */
+int dass_pairwise_dist_f64(const float *a, int64_t n, const float *b, int64_t m, int d, double *D, void *stream);
+int dass_facility_scores(const double *D, int64_t n, int64_t m, const double *mind, const uint8_t *selected,
+                         double *scores, void *stream);
+int dass_facility_update(const double *D, int64_t n, int64_t m, const int64_t *col, double *mind,
+                         uint8_t *selected, void *stream);
+
 /* fused SGD(momentum, weight decay, nesterov=False) step over one flat f32 tensor
  * (torch.optim.SGD as built at active_train.py:60): g += wd*p; buf = mom*buf + g; p -= lr*buf */
 int dass_sgd_step(float *p, const float *g, float *buf, int64_t n, float lr, float momentum,

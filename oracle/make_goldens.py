@@ -272,6 +272,24 @@ def main():
     ref["MCDropout"].suppress_labeled_entropy(em_ref, [(3, 4, 10, 12), (30, 30, 10, 10)])
     assert maxdiff(em_ref, S.suppress_labeled(em.clone(), [(3, 4, 10, 12), (30, 30, 10, 10)])) == 0
 
+    # ---------------------------------------------------------------- max-subset greedy (tests.py:616-642 inputs)
+    from active_selection.max_subset import ActiveSelectionMaxSubset
+
+    np.random.seed(seed=27)
+    clusters = [np.random.normal(loc=2.0, scale=1.0, size=(400, 1024)), np.random.normal(loc=4.0, scale=1.0, size=(400, 1024)),
+                np.random.normal(loc=6.0, scale=1.0, size=(150, 1024)), np.random.normal(loc=4.0, scale=3.0, size=(50, 1024))]
+    images_ms = np.concatenate(clusters, axis=0)
+    cands = list(np.random.randint(0, len(images_ms), 8))
+    ms = ActiveSelectionMaxSubset(None, None, None)
+    sel_ref = [int(i) for i in ms._max_representative_samples(list(images_ms), list(images_ms[cands, :]), 4)]
+    assert sel_ref == S.max_representative_samples(images_ms, images_ms[cands, :], 4)
+    big_ms = np.asarray(O._hash_uniform(400 * 2736, 123), dtype=np.float64).reshape(400, 2736)
+    cidx = list(range(0, 400, 7))
+    sel_big = [int(i) for i in ms._max_representative_samples(list(big_ms), list(big_ms[cidx]), 20)]
+    assert sel_big == S.max_representative_samples(big_ms, big_ms[cidx], 20)
+    np.savez_compressed(os.path.join(OUT, "max_subset.npz"), candidates=np.array(cands), picks=np.array(sel_ref),
+                        big_picks=np.array(sel_big))
+
     # ---------------------------------------------------------------- G12: two SGD training steps (mobilenet, 65^2, train-mode BN, dropout off via p masks)
     ncls, n, hw = 19, 2, 97
     rm = ref["DeepLab"](backbone="mobilenet", output_stride=16, num_classes=ncls, sync_bn=False, pretrained=False)

@@ -148,3 +148,27 @@ def square_nms(score_maps, region_size, max_selection_count):
         if score_maps.max() < 0.01:
             break
     return selected, count
+
+
+# ------------------------------------------------------------------ max-subset (max_subset.py:17-39)
+def max_representative_samples(image_features, candidate_features, selection_count):
+    """greedy facility location: each pick minimises sum_i min(mind_i, D[i, j]) over unpicked candidates j
+    (first strict improvement wins), D = sklearn euclidean distances in f64"""
+    from sklearn.metrics import pairwise_distances
+
+    dist = pairwise_distances(np.asarray(image_features, dtype=np.float64), np.asarray(candidate_features, dtype=np.float64),
+                              metric="euclidean")
+    mind = np.full(dist.shape[0], np.inf)
+    picked = []
+    for _ in range(selection_count):
+        best_score, best_j, best_mind = -np.inf, None, None
+        for j in range(dist.shape[1]):
+            if j in picked:
+                continue
+            tmp = np.minimum(mind, dist[:, j])
+            score = -np.sum(tmp)
+            if score > best_score:
+                best_score, best_j, best_mind = score, j, tmp
+        picked.append(best_j)
+        mind = best_mind
+    return picked
