@@ -988,6 +988,21 @@ def square_nms(score_maps, region_size, max_selection_count):
     return regions, cnt
 
 
+def confusion_accumulate(cm, target, pred_or_logits, num_class):
+    """cm[gt][pred] += 1 on the device (utils/metrics.py:37-42); pred_or_logits: [N,H,W] class map or [N,C,H,W] logits"""
+    tgt = target.contiguous().float()
+    if pred_or_logits.dim() == 4:
+        lg = pred_or_logits.contiguous().float()
+        n, c, h, w = lg.shape
+        check(lib.dass_confusion_accumulate(_p(lg), None, _p(tgt), n, c, h * w, num_class, _p(cm), _stream()),
+              "dass_confusion_accumulate")
+    else:
+        pr = pred_or_logits.contiguous().to(torch.uint8)
+        n, h, w = pr.shape
+        check(lib.dass_confusion_accumulate(None, _p(pr), _p(tgt), n, 0, h * w, num_class, _p(cm), _stream()),
+              "dass_confusion_accumulate")
+
+
 def max_representative(all_features, candidate_features, count):
     """greedy facility location (max_subset.py:17-39) on the device: each pick maximises
     -sum_i min(mind_i, D[i][j]) over unselected candidates (first max wins, like the reference's strict '>')."""

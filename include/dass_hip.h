@@ -235,6 +235,12 @@ int dass_facility_scores(const double *D, int64_t n, int64_t m, const double *mi
 int dass_facility_update(const double *D, int64_t n, int64_t m, const int64_t *col, double *mind,
                          uint8_t *selected, void *stream);
 
+/* validation metrics (active_train.py:159-163 + utils/metrics.py:37-42): cm[gt*num_class + pred] += 1 over the
+ * pixels with 0 <= gt < num_class; pred = argmax over classes of the NCHW f32 logits (first max), or the uint8
+ * map `pred` when given (then logits may be NULL).  cm is int64 [num_class][num_class] on the device. */
+int dass_confusion_accumulate(const float *logits, const uint8_t *pred, const float *target, int N, int C,
+                              int64_t HW, int num_class, int64_t *cm, void *stream);
+
 /* fused SGD(momentum, weight decay, nesterov=False) step over one flat f32 tensor
  * (torch.optim.SGD as built at active_train.py:60): g += wd*p; buf = mom*buf + g; p -= lr*buf */
 int dass_sgd_step(float *p, const float *g, float *buf, int64_t n, float lr, float momentum,

@@ -114,3 +114,29 @@ def test_noise_selectors_run_and_reduce_like_the_oracle():
         assert cnt >= 1 and all(k in keys for k in regions)
     finally:
         constants.MC_STEPS = 20
+
+
+def test_evaluator_device_confusion_matrix_vs_reference_formulas():
+    """argmax + confusion matrix on the device == the reference's numpy argmax + bincount"""
+    ops, O, S = _setup()
+    from utils.metrics import Evaluator
+
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(3, 19, 33, 41, generator=g)
+    target = torch.randint(0, 19, (3, 33, 41), generator=g).float()
+    target[:, :4] = 255
+    target[0, 5] = -1
+    ref = Evaluator(19)  # numpy path == utils/metrics.py:37-46 line for line
+    ref.add_batch(target.numpy(), np.argmax(logits.numpy(), axis=1))
+    dev = Evaluator(19)
+    dev.add_batch(target.cuda(), logits.cuda())                       # fused argmax + histogram
+    assert np.array_equal(dev.confusion_matrix, ref.confusion_matrix)
+    dev2 = Evaluator(19)
+    dev2.add_batch(target.cuda(), logits.argmax(1).cuda())            # ready prediction map
+    dev2.add_batch(target.cuda(), logits.argmax(1).cuda())
+    assert np.array_equal(dev2.confusion_matrix, 2 * ref.confusion_matrix)
+    for fn in ("Pixel_Accuracy", "Pixel_Accuracy_Class", "Mean_Intersection_over_Union",
+               "Frequency_Weighted_Intersection_over_Union"):
+        assert abs(getattr(dev, fn)() - getattr(ref, fn)()) < 1e-12
+    dev.reset()
+    assert dev.confusion_matrix.sum() == 0
