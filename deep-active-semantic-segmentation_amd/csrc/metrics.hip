@@ -52,3 +52,41 @@ extern "C" int dass_confusion_accumulate(const float *logits, const uint8_t *pre
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- SyncBN
+// Cross-rank batch statistics: every rank reduces its partial rows to sums[2][K] (+ count),
+// RCCL all-reduces that small vector, and this kernel turns the global sums into mean / invstd / scale / shift.
+// clamp_var = 1 reproduces the reference's vendored SyncBN exactly: invstd = clamp(biased_var, eps)^-1/2
+// (models/sync_batchnorm/batchnorm.py:113-125), not (var + eps)^-1/2; running_var uses the unbiased variance.
+namespace {
+__global__ void bn_finalize_sums_kernel(const float *__restrict__ sums, int K, double count, const float *gamma,
+                                        const float *beta, float *running_mean, float *running_var, float momentum,
+                                        float eps, int clamp_var, float *mean, float *invstd, float *scale, float *shift) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const double mu = (double)sums[k] / count;
+    double var = (double)sums[K + k] / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const double is = clamp_var ? 1.0 / sqrt(var > (double)eps ? var : (double)eps) : 1.0 / sqrt(var + (double)eps);
+    const float g = gamma ? gamma[k] : 1.f, b = beta ? beta[k] : 0.f;
+    mean[k] = (float)mu;
+    invstd[k] = (float)is;
+    scale[k] = (float)((double)g * is);
+    shift[k] = (float)((double)b - mu * (double)g * is);
+    if (momentum >= 0.f && running_mean && running_var) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[k] = (1.f - momentum) * running_mean[k] + momentum * (float)mu;
+        running_var[k] = (1.f - momentum) * running_var[k] + momentum * (float)unb;
+    }
+}
+}  // namespace
+
+extern "C" int dass_bn_finalize_sums(const float *sums, int K, double count, const float *gamma, const float *beta,
+                                     float *running_mean, float *running_var, float momentum, float eps, int clamp_var,
+                                     float *mean, float *invstd, float *scale, float *shift, void *stream) {
+    if (!sums || K <= 0 || count <= 0 || !mean || !invstd || !scale || !shift) return DASS_ERR_ARG;
+    hipLaunchKernelGGL(bn_finalize_sums_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, K, count,
+                       gamma, beta, running_mean, running_var, momentum, eps, clamp_var, mean, invstd, scale, shift);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}

@@ -162,10 +162,44 @@ def bn_train_state(x, ld, m, k, bn, rep=1.0):
         _pending_counters.append(bn.num_batches_tracked)
         if _defer["depth"] == 0 or len(_pending_counters) >= 512:
             flush_bn_counters()
+    world = sync_bn_world(bn)
+    if world > 1:
+        # SyncBN: local sums -> one RCCL all-reduce of [2K] floats -> global mean / clamp(var, eps)^-1/2.
+        # Ranks are assumed to hold equal element counts (DDP with equal per-GPU batches), so no count exchange.
+        import torch.distributed as dist
+
+        sums = torch.empty((2, k), dtype=torch.float32, device=x.device)
+        check(lib.dass_bn_bwd_finalize(_p(partial), nrows, k, _p(sums[0]), _p(sums[1]), _stream()), "dass_bn_bwd_finalize")
+        if rep != 1.0:
+            sums.mul_(rep)
+        dist.all_reduce(sums)
+        check(lib.dass_bn_finalize_sums(_p(sums), k, float(m) * rep * world, _p(bn.weight), _p(bn.bias), _p(rm), _p(rv), mom,
+                                        float(bn.eps), 1, _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
+                                        _stream()), "dass_bn_finalize_sums")
+        return st
     check(lib.dass_bn_finalize(_p(partial), nrows, k, float(m) * rep, float(rep), _p(bn.weight), _p(bn.bias), _p(rm),
                                _p(rv), mom, float(bn.eps), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
                                _stream()), "dass_bn_finalize")
     return st
+
+
+def sync_bn_world(bn):
+    """number of ranks a BN layer synchronises its batch statistics over (1 = plain per-GPU BN).
+    SynchronizedBatchNorm2d instances (marked `_dass_sync`) synchronise when torch.distributed is initialised."""
+    if not getattr(bn, "_dass_sync", False):
+        return 1
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size()
+    return 1
+
+
+def _allreduce_bn_grads(sums, world):
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.all_reduce(sums)
 
 
 def bn_eval_state(bn, k, device):
@@ -346,6 +380,7 @@ class _ConvBnAct(torch.autograd.Function):
             ctx.image_input = image_input
             ctx.dims = (n, h, w, c, oh, ow, k, ldx, ldo, c_in)
             ctx.train_stats = batch_stats
+            ctx.sync_world = sync_bn_world(bn) if batch_stats else 1
             ctx.has_bn = bn is not None
             ctx.has_bias = bias is not None
             ctx.has_res = residual is not None
@@ -404,13 +439,15 @@ class _ConvBnAct(torch.autograd.Function):
                 sums = torch.empty((2, k), dtype=torch.float32, device=dev)
                 db, dg = sums[0], sums[1]
                 check(lib.dass_bn_bwd_finalize(_p(partial), nrows, k, _p(db), _p(dg), _stream()), "dass_bn_bwd_finalize")
+                if ctx.has_bn and ctx.train_stats:
+                    _allreduce_bn_grads(sums, ctx.sync_world)  # SyncBN: dbeta/dgamma are sums over the GLOBAL batch
                 if ctx.has_bn:
                     dbeta, dgamma = db, dg
                 else:
                     dbias = db
             check(lib.dass_bn_bwd_apply(_p(dout_r), lddo, _p(out), ldo, _p(src), k, _p(mean_v), _p(invstd_v),
                                         _p(gamma_v.detach() if gamma_v is not None else None), _p(db), _p(dg),
-                                        _p(nc_scale), _p(dy), lddy, _p(dres), k, m, k, oh * ow, float(m),
+                                        _p(nc_scale), _p(dy), lddy, _p(dres), k, m, k, oh * ow, float(m) * ctx.sync_world,
                                         1 if ctx.train_stats else 0, spec.act, _dt(out), _stream()), "dass_bn_bwd_apply")
         # ---- conv backward
         dx = dw = None
@@ -662,6 +699,7 @@ class _BroadcastBN(torch.autograd.Function):
         ctx.save_for_backward(xv, yv, gamma, st.mean, st.invstd)
         ctx.dims = (n, c, h, w)
         ctx.train_stats = bn_use_batch_stats(bn)
+        ctx.sync_world = sync_bn_world(bn) if ctx.train_stats else 1
         return out
 
     @staticmethod
@@ -677,9 +715,11 @@ class _BroadcastBN(torch.autograd.Function):
                                      _p(partial), _dt(gs), _stream()), "dass_bn_bwd_reduce")
         sums = torch.empty((2, c), dtype=torch.float32, device=gr.device)
         check(lib.dass_bn_bwd_finalize(_p(partial), nrows, c, _p(sums[0]), _p(sums[1]), _stream()), "dass_bn_bwd_finalize")
+        if ctx.train_stats:
+            _allreduce_bn_grads(sums, ctx.sync_world)
         dx = torch.empty((n, c), dtype=gs.dtype, device=gs.device)
         check(lib.dass_bn_bwd_apply(_p(gs), c, _p(yv), c, _p(xv), c, _p(mean), _p(invstd), _p(gamma.detach()),
-                                    _p(sums[0]), _p(sums[1]), None, _p(dx), c, None, 0, n, c, 1, float(n),
+                                    _p(sums[0]), _p(sums[1]), None, _p(dx), c, None, 0, n, c, 1, float(n) * ctx.sync_world,
                                     1 if ctx.train_stats else 0, ACT_NONE, _dt(dx), _stream()), "dass_bn_bwd_apply")
         return dx.view(n, 1, 1, c).permute(0, 3, 1, 2), sums[1], sums[0], None, None, None
 

@@ -112,6 +112,12 @@ int dass_bn_finalize(const float *partial, int rows, int K, double count, double
                      const float *gamma, const float *beta, float *running_mean, float *running_var,
                      float momentum, float eps, float *mean, float *invstd, float *scale, float *shift,
                      void *stream);
+/* SyncBN (models/sync_batchnorm/batchnorm.py:48-125 semantics, one process per GPU): sums[0][k] = global sum x,
+ * sums[1][k] = global sum x^2 after the RCCL all-reduce, count = global element count per channel.
+ * clamp_var=1: invstd = clamp(biased_var, eps)^-1/2 as the reference's vendored SyncBN; 0: (var+eps)^-1/2. */
+int dass_bn_finalize_sums(const float *sums, int K, double count, const float *gamma, const float *beta,
+                          float *running_mean, float *running_var, float momentum, float eps, int clamp_var,
+                          float *mean, float *invstd, float *scale, float *shift, void *stream);
 /* eval-mode BN folded to scale/shift from running stats */
 int dass_bn_eval_scale_shift(const float *gamma, const float *beta, const float *running_mean,
                              const float *running_var, float eps, int K,
