@@ -67,40 +67,6 @@ def synthetic_batch(n, h, w, num_classes, first_index):
     return torch.stack(imgs), torch.stack(labs)
 
 
-def allreduce_grads(params, world):
-    """DDP-style gradient averaging: flat f32 buckets, one RCCL all-reduce each (xGMI), issued async so the
-    buckets pipeline; waits happen only before the optimizer step."""
-    import torch.distributed as dist
-
-    bucket, size, works = [], 0, []
-    cap = 64 * 1024 * 1024 // 4
-
-    def flush():
-        nonlocal bucket, size
-        if not bucket:
-            return
-        flat = torch.cat([p.grad.reshape(-1) for p in bucket])
-        works.append((dist.all_reduce(flat, async_op=True), flat, bucket))
-        bucket, size = [], 0
-
-    for p in params:
-        if p.grad is None:
-            continue
-        bucket.append(p)
-        size += p.grad.numel()
-        if size >= cap:
-            flush()
-    flush()
-    for work, flat, ps in works:
-        work.wait()
-        flat.div_(world)
-        off = 0
-        for p in ps:
-            n = p.grad.numel()
-            p.grad.copy_(flat[off:off + n].view_as(p.grad))
-            off += n
-
-
 def log(msg):
     """progress to stderr and (when present) gpurun_out/: a silent run is taken for a hung one"""
     line = "[bench %s] %s" % (time.strftime("%H:%M:%S"), msg)
@@ -122,6 +88,7 @@ def run_mode(args, env, dtype_name, steps, warmup):
     from utils.loss import SegmentationLosses
     from active_selection.base import shard_bounds
     from active_selection.mc_dropout import ActiveSelectionMCDropout
+    from dass_hip.dist import average_gradients
 
     rank, world, dev, dist = env.rank, env.world, env.dev, env.dist
     ops.set_compute_dtype(torch.float32 if dtype_name == "f32" else torch.bfloat16)
@@ -155,7 +122,7 @@ def run_mode(args, env, dtype_name, steps, warmup):
         loss = criterion(out, target)
         loss.backward()
         if dist is not None:
-            allreduce_grads(params, world)
+            average_gradients(params)
         optimizer.step()
         return loss
 
