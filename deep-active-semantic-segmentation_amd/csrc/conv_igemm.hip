@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 
 
         const char *ap = As + (wm * TMW + (lane & 31)) * ROWB + (lane >> 5) * 16;
         const char *bp = Bs + (wn * TNW + (lane & 31)) * ROWB + (lane >> 5) * 16;
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             uint4 a[MT], b[NT];
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) Mma<T>::run(a[mt], b[nt], acc[mt][nt]);
         }
+        __builtin_amdgcn_s_setprio(0);
     }
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
