@@ -351,60 +351,69 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
     const T *dyg = reinterpret_cast<const T *>(p.dy);
 
     f32x4 ra[PASS_A], rb[PASS_B];
-    // per-thread pixel cursors advance by BP every slab: (n, oh, ow) are carried incrementally instead of
-    // being re-derived with two integer divisions per row per slab
-    int b_n[PASS_B], b_oh[PASS_B], b_ow[PASS_B];
+    // per-thread pixel cursors advance by BP every slab: (oh, ow) and the element offset of the tap's input pixel
+    // are carried incrementally (adds only) instead of being re-derived with divisions and 64-bit multiplies;
+    // VALU issue slots next to 64-cycle MFMAs are not free (PMC: 4.9 VALU per MFMA before this, 60 % MFMA busy)
+    int b_oh[PASS_B], b_ow[PASS_B];
+    long b_xoff[PASS_B];
+    const long adv_px = (long)BP * p.stride * p.ldx;
+    const long adv_row = ((long)p.stride * p.W - (long)p.OW * p.stride) * p.ldx;
+    const long adv_img = ((long)p.H * p.W - (long)p.OH * p.stride * p.W) * p.ldx;
+    const int tap_dy = -p.pad + r * p.dil, tap_dx = -p.pad + (WIDE ? 0 : s * p.dil);
 #pragma unroll
     for (int j = 0; j < PASS_B; ++j) {
         const long pix = pbeg + brow + j * RPP_B;
         const int n = (int)(pix / ohw);
         const int rem = (int)(pix - (long)n * ohw);
-        b_n[j] = n;
         b_oh[j] = rem / p.OW;
         b_ow[j] = rem - b_oh[j] * p.OW;
+        b_xoff[j] = (((long)n * p.H + (b_oh[j] * p.stride + tap_dy)) * p.W + (b_ow[j] * p.stride + tap_dx)) * p.ldx;
     }
     const bool a_kok = (k0 + achunk * 4) < p.K, b_cok = (c0 + bchunk * 4) < p.C;
-    const T *dy_col = dyg + k0 + achunk * 4;
+    const T *dy_ptr[PASS_A];
+#pragma unroll
+    for (int j = 0; j < PASS_A; ++j) dy_ptr[j] = dyg + k0 + achunk * 4 + (pbeg + arow + j * RPP_A) * p.lddy;
+    const long adv_dy = (long)BP * p.lddy;
     const T *x_col = xg + c0 + bchunk * 4;
     auto load_stage = [&](long pb) {
+        const int left = (int)(pend - pb);  // pixels still to do from this slab's first row (uniform)
 #pragma unroll
         for (int j = 0; j < PASS_A; ++j) {
-            const long pix = pb + arow + j * RPP_A;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (pix < pend && a_kok) v = ld4<T>(dy_col + pix * p.lddy);
+            if (arow + j * RPP_A < left && a_kok) v = ld4<T>(dy_ptr[j]);
             ra[j] = v;
+            dy_ptr[j] += adv_dy;
         }
 #pragma unroll
         for (int j = 0; j < PASS_B; ++j) {
-            const long pix = pb + brow + j * RPP_B;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            const bool live = brow + j * RPP_B < left;
+            const int iy = b_oh[j] * p.stride + tap_dy;
+            const int ix = b_ow[j] * p.stride + tap_dx;
             if (WIDE) {
-                // row-tap mode: "channel" q = c0 + 4*bchunk + e addresses column ix0 + q / Cin of input row iy
-                const int iy = b_oh[j] * p.stride - p.pad + r;
-                const int ix0 = b_ow[j] * p.stride - p.pad;
-                if (pix < pend && iy >= 0 && iy < p.H) {
-                    const T *row = x_col + (((long)b_n[j] * p.H + iy) * p.W + ix0) * p.wide_c;
+                // row-tap mode: "channel" q = c0 + 4*bchunk + e addresses column ix + q / Cin of input row iy
+                if (live && iy >= 0 && iy < p.H) {
+                    const T *row = x_col + b_xoff[j];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int q = c0 + bchunk * 4 + e;
-                        const int ix = ix0 + q / p.wide_c;
-                        if (q < p.C && ix >= 0 && ix < p.W) v[e] = Elem<T>::ld(row + e);
+                        const int ixe = ix + q / p.wide_c;
+                        if (q < p.C && ixe >= 0 && ixe < p.W) v[e] = Elem<T>::ld(row + e);
                     }
                 }
-            } else if (pix < pend && b_cok) {
-                const int iy = b_oh[j] * p.stride - p.pad + r * p.dil;
-                const int ix = b_ow[j] * p.stride - p.pad + s * p.dil;
-                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                    v = ld4<T>(x_col + (((long)b_n[j] * p.H + iy) * p.W + ix) * p.ldx);
+            } else if (live && b_cok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                v = ld4<T>(x_col + b_xoff[j]);
             }
             rb[j] = v;
             // advance this cursor by BP pixels
             b_ow[j] += BP;
+            b_xoff[j] += adv_px;
             while (b_ow[j] >= p.OW) {
                 b_ow[j] -= p.OW;
+                b_xoff[j] += adv_row;
                 if (++b_oh[j] >= p.OH) {
                     b_oh[j] = 0;
-                    ++b_n[j];
+                    b_xoff[j] += adv_img;
                 }
             }
         }
@@ -516,45 +525,53 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradP p)
     const bf16_t *xg = reinterpret_cast<const bf16_t *>(p.x);
     const bf16_t *dyg = reinterpret_cast<const bf16_t *>(p.dy);
 
-    int b_n[PASS_B], b_oh[PASS_B], b_ow[PASS_B];
+    int b_oh[PASS_B], b_ow[PASS_B];
+    long b_xoff[PASS_B];
+    const long adv_px = (long)BP * p.stride * p.ldx;
+    const long adv_row = ((long)p.stride * p.W - (long)p.OW * p.stride) * p.ldx;
+    const long adv_img = ((long)p.H * p.W - (long)p.OH * p.stride * p.W) * p.ldx;
+    const int tap_dy = -p.pad + r * p.dil, tap_dx = -p.pad + s * p.dil;
 #pragma unroll
     for (int j = 0; j < PASS_B; ++j) {
         const long pix = pbeg + brow + j * RPP_B;
         const int n = (int)(pix / ohw);
         const int rem = (int)(pix - (long)n * ohw);
-        b_n[j] = n;
         b_oh[j] = rem / p.OW;
         b_ow[j] = rem - b_oh[j] * p.OW;
+        b_xoff[j] = (((long)n * p.H + (b_oh[j] * p.stride + tap_dy)) * p.W + (b_ow[j] * p.stride + tap_dx)) * p.ldx;
     }
     const bool a_kok = (k0 + achunk * 8) < p.K, b_cok = (c0 + bchunk * 8) < p.C;
-    const bf16_t *dy_col = dyg + k0 + achunk * 8;
+    const bf16_t *dy_ptr[PASS_A];
+#pragma unroll
+    for (int j = 0; j < PASS_A; ++j) dy_ptr[j] = dyg + k0 + achunk * 8 + (pbeg + arow + j * RPP_A) * p.lddy;
+    const long adv_dy = (long)BP * p.lddy;
     const bf16_t *x_col = xg + c0 + bchunk * 8;
     uint4 ra[PASS_A], rb[PASS_B];
     auto load_stage = [&](long pb) {
+        const int left = (int)(pend - pb);
 #pragma unroll
         for (int j = 0; j < PASS_A; ++j) {
-            const long pix = pb + arow + j * RPP_A;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (pix < pend && a_kok) v = *reinterpret_cast<const uint4 *>(dy_col + pix * p.lddy);
+            if (arow + j * RPP_A < left && a_kok) v = *reinterpret_cast<const uint4 *>(dy_ptr[j]);
             ra[j] = v;
+            dy_ptr[j] += adv_dy;
         }
 #pragma unroll
         for (int j = 0; j < PASS_B; ++j) {
-            const long pix = pb + brow + j * RPP_B;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (pix < pend && b_cok) {
-                const int iy = b_oh[j] * p.stride - p.pad + r * p.dil;
-                const int ix = b_ow[j] * p.stride - p.pad + s * p.dil;
-                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                    v = *reinterpret_cast<const uint4 *>(x_col + (((long)b_n[j] * p.H + iy) * p.W + ix) * p.ldx);
-            }
+            const int iy = b_oh[j] * p.stride + tap_dy;
+            const int ix = b_ow[j] * p.stride + tap_dx;
+            if (brow + j * RPP_B < left && b_cok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                v = *reinterpret_cast<const uint4 *>(x_col + b_xoff[j]);
             rb[j] = v;
             b_ow[j] += BP;
+            b_xoff[j] += adv_px;
             while (b_ow[j] >= p.OW) {
                 b_ow[j] -= p.OW;
+                b_xoff[j] += adv_row;
                 if (++b_oh[j] >= p.OH) {
                     b_oh[j] = 0;
-                    ++b_n[j];
+                    b_xoff[j] += adv_img;
                 }
             }
         }
