@@ -30,6 +30,7 @@ struct ConvP {
     const float *shift;
     const char *res;
     const float *in_scale;
+    float *stat_partial;  // optional [mtiles][2][K]: per-tile column sums / sums of squares of the RAW output (train-mode BN)
     long ldx, ldy, ldr;
     long wk_stride;  // R*S*C
     int N, H, W, C, OH, OW, K, R, S, stride, pad, dil, ustride, act;
@@ -259,6 +260,40 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 
                 for (int nt = 0; nt < NT; ++nt) Mma<T>::run(a[mt], b[nt], acc[mt][nt]);
         }
         __builtin_amdgcn_s_setprio(0);
+    }
+
+    if (p.stat_partial) {
+        // BatchNorm batch statistics fused into the producer: per-channel sum and sum of squares of this tile's
+        // rows straight from the accumulators (rows >= M hold zeros), one partial row per M-tile; the f64
+        // finalize kernel reduces them.  Saves the separate read of the conv output.
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(smem);  // [WM][2][BN]
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const float v = acc[mt][nt][reg];
+                    s1 += v;
+                    s2 += v * v;
+                }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 32) {
+                red[(wm * 2 + 0) * BN + wn * TNW + nt * 32 + lane] = s1;
+                red[(wm * 2 + 1) * BN + wn * TNW + nt * 32 + lane] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, col = tid - which * BN;
+            float a = 0.f;
+#pragma unroll
+            for (int q = 0; q < WM; ++q) a += red[(q * 2 + which) * BN + col];
+            if (n0 + col < p.K) p.stat_partial[((long)mt_i * 2 + which) * p.K + n0 + col] = a;
+        }
     }
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -776,10 +811,10 @@ template <typename T> int dispatch_wgrad(WgradP &p, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int dass_conv2d_igemm(const void *x, int64_t ldx, const void *w, void *y, int64_t ldy, const float *scale,
-                                 const float *shift, const void *residual, int64_t ldr, const float *in_scale, int N,
-                                 int H, int W, int C, int OH, int OW, int K, int R, int S, int stride, int pad,
-                                 int dil, int ustride, int act, int dtype, void *stream) {
+static int conv_entry(const void *x, int64_t ldx, const void *w, void *y, int64_t ldy, const float *scale,
+                      const float *shift, const void *residual, int64_t ldr, const float *in_scale, int N,
+                      int H, int W, int C, int OH, int OW, int K, int R, int S, int stride, int pad,
+                      int dil, int ustride, int act, int dtype, void *stream, float *stat_partial, int *stat_rows) {
     if (!x || !w || !y) return DASS_ERR_ARG;
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || K <= 0 || R <= 0 || S <= 0) return DASS_ERR_ARG;
     if (R * S > 64 || stride < 1 || dil < 1 || ustride < 1) return DASS_ERR_ARG;
@@ -795,6 +830,7 @@ extern "C" int dass_conv2d_igemm(const void *x, int64_t ldx, const void *w, void
     p.shift = shift;
     p.res = (const char *)residual;
     p.in_scale = in_scale;
+    p.stat_partial = stat_partial;
     p.ldx = ldx;
     p.ldy = ldy;
     p.ldr = ldr;
@@ -845,7 +881,27 @@ extern "C" int dass_conv2d_igemm(const void *x, int64_t ldx, const void *w, void
         return DASS_OK;
     }
     if (ustride > 1) return DASS_ERR_UNSUPPORTED;  // transposed addressing exists only in the phase-decomposed form
-    return dtype == DASS_F32 ? dispatch_conv<float>(p, st) : dispatch_conv<bf16_t>(p, st);
+    const int rc = dtype == DASS_F32 ? dispatch_conv<float>(p, st) : dispatch_conv<bf16_t>(p, st);
+    if (stat_rows) *stat_rows = p.mtiles;
+    return rc;
+}
+
+extern "C" int dass_conv2d_igemm(const void *x, int64_t ldx, const void *w, void *y, int64_t ldy, const float *scale,
+                                 const float *shift, const void *residual, int64_t ldr, const float *in_scale, int N,
+                                 int H, int W, int C, int OH, int OW, int K, int R, int S, int stride, int pad,
+                                 int dil, int ustride, int act, int dtype, void *stream) {
+    return conv_entry(x, ldx, w, y, ldy, scale, shift, residual, ldr, in_scale, N, H, W, C, OH, OW, K, R, S, stride, pad, dil,
+                      ustride, act, dtype, stream, nullptr, nullptr);
+}
+
+extern "C" int dass_conv2d_igemm_stats_rows(int64_t M) { return (int)((M + 63) / 64); }
+
+extern "C" int dass_conv2d_igemm_stats(const void *x, int64_t ldx, const void *w, void *y, int64_t ldy, int N, int H, int W,
+                                       int C, int OH, int OW, int K, int R, int S, int stride, int pad, int dil, int dtype,
+                                       float *stat_partial, int *stat_rows, void *stream) {
+    if (!stat_partial || !stat_rows) return DASS_ERR_ARG;
+    return conv_entry(x, ldx, w, y, ldy, nullptr, nullptr, nullptr, 0, nullptr, N, H, W, C, OH, OW, K, R, S, stride, pad, dil, 1,
+                      DASS_ACT_NONE, dtype, stream, stat_partial, stat_rows);
 }
 
 extern "C" int dass_conv2d_wgrad(const void *x, int64_t ldx, const void *dy, int64_t lddy, float *dw, int N, int H, int W, int C, int OH, int OW, int K, int R,
@@ -896,7 +952,7 @@ extern "C" int dass_conv2d_rowtap(const void *x, const void *w, void *y, int64_t
     if (R > 64 || S * Cin > 32 || stride < 1 || (long)N * OH * OW >= (1l << 31)) return DASS_ERR_ARG;
     ConvP p;
     p.x = (const char *)x; p.w = (const char *)w; p.y = (char *)y;
-    p.scale = nullptr; p.shift = nullptr; p.res = nullptr; p.in_scale = nullptr;
+    p.scale = nullptr; p.shift = nullptr; p.res = nullptr; p.in_scale = nullptr; p.stat_partial = nullptr;
     p.ldx = Cin; p.ldy = ldy; p.ldr = 0;
     p.wk_stride = (long)R * S * Cin;
     p.N = N; p.H = H; p.W = W; p.C = S * Cin; p.OH = OH; p.OW = OW; p.K = K; p.R = R; p.S = 1;

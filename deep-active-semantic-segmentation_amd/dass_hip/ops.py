@@ -151,8 +151,9 @@ def flush_bn_counters():
         torch._foreach_add_(pend, 1)
 
 
-def bn_train_state(x, ld, m, k, bn, rep=1.0):
-    partial, nrows = channel_stats(x, ld, m, k)
+def bn_train_state(x, ld, m, k, bn, rep=1.0, stats=None):
+    """stats: (partial, rows) already produced by the conv epilogue (dass_conv2d_igemm_stats)"""
+    partial, nrows = stats if stats is not None else channel_stats(x, ld, m, k)
     st = BNState(k, x.device)
     mom = -1.0
     rm = rv = None
@@ -367,9 +368,22 @@ class _ConvBnAct(torch.autograd.Function):
         else:
             assert k % 4 == 0, "BN epilogue needs K % 4 == 0"
             y_raw = new_act(n, k, oh, ow, dt, dev)
-            _conv_forward_raw(spec, xs, ldx, n, h, w, c, weight, y_raw, k, oh, ow)
+            fused_stats = None
+            if batch_stats and not spec.depthwise and not rowtap:
+                # train-mode BN: the conv epilogue also emits the per-tile channel sums (no second read of y_raw)
+                rmax = lib.dass_conv2d_igemm_stats_rows(m)
+                partial = torch.empty((rmax, 2, k), dtype=torch.float32, device=dev)
+                nrows = ctypes.c_int(0)
+                w_op = weight_operand(weight, 0, dt, cpad=c)
+                check(lib.dass_conv2d_igemm_stats(_p(xs), ldx, _p(w_op), _p(y_raw), k, n, h, w, c, oh, ow, k, r,
+                                                  weight.shape[3], spec.stride, spec.pad, spec.dil, _dt(y_raw), _p(partial),
+                                                  ctypes.byref(nrows), _stream()), "dass_conv2d_igemm_stats")
+                fused_stats = (partial, nrows.value)
+            else:
+                _conv_forward_raw(spec, xs, ldx, n, h, w, c, weight, y_raw, k, oh, ow)
             if bn is not None:
-                state = bn_train_state(y_raw, k, m, k, bn) if batch_stats else bn_eval_state(bn, k, dev)
+                state = (bn_train_state(y_raw, k, m, k, bn, stats=fused_stats) if batch_stats
+                         else bn_eval_state(bn, k, dev))
                 scale, shift = state.scale, state.shift
             else:
                 scale, shift = None, (bias.detach().float() if bias is not None else None)

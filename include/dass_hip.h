@@ -63,6 +63,16 @@ int dass_conv2d_igemm(const void *x, int64_t ldx, const void *w, void *y, int64_
                       int R, int S, int stride, int pad, int dil, int ustride,
                       int act, int dtype, void *stream);
 
+/* Forward conv for train-mode BN: same kernel, raw output (no epilogue), plus the batch statistics fused into the
+ * producer: stat_partial[row][0][k] = sum over the row's pixel tile of y[.,k], [row][1][k] = sum of squares.
+ * stat_partial must hold dass_conv2d_igemm_stats_rows(M) rows of 2*K floats; *stat_rows (HOST int) receives the
+ * number of rows actually written, to be handed to dass_bn_finalize. */
+int dass_conv2d_igemm_stats_rows(int64_t M);
+int dass_conv2d_igemm_stats(const void *x, int64_t ldx, const void *w, void *y, int64_t ldy,
+                            int N, int H, int W, int C, int OH, int OW, int K,
+                            int R, int S, int stride, int pad, int dil, int dtype,
+                            float *stat_partial, int *stat_rows, void *stream);
+
 /* dw[k][r][s][c] (f32, KRSC, ld = C) = sum_pixels dy[n,oh,ow,k] * x[n,iy,ix,c]*in_scale[n,c];
  * dw is zeroed inside (hipMemsetAsync on `stream`) then accumulated with f32 atomics.
  * Replaces the weight gradient of the same nn.Conv2d sites. */
