@@ -140,3 +140,36 @@ def test_evaluator_device_confusion_matrix_vs_reference_formulas():
         assert abs(getattr(dev, fn)() - getattr(ref, fn)()) < 1e-12
     dev.reset()
     assert dev.confusion_matrix.sum() == 0
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_overfit_one_batch_loss_goes_down(dtype):
+    """plumbing check of the whole training path (config 0 of BASELINE.json in spirit): SGD on one fixed synthetic
+    batch must drive the loss down, in both numerics modes"""
+    ops, O, S = _setup()
+    from models.deeplab import DeepLab
+    from utils.loss import SegmentationLosses
+
+    ops.set_compute_dtype(torch.float32 if dtype == "f32" else torch.bfloat16)
+    try:
+        torch.manual_seed(0)
+        model = DeepLab(backbone="mobilenet", num_classes=4, sync_bn=False, pretrained=False).cuda().train()
+        x = torch.randn(2, 3, 65, 65, generator=torch.Generator().manual_seed(1)).cuda()
+        y = torch.zeros(2, 65, 65)
+        y[:, 32:, :32], y[:, :32, 32:], y[:, 32:, 32:] = 1, 2, 3          # quadrant labels: learnable from position cues
+        y[:, :5] = 255
+        y = y.cuda()
+        crit = SegmentationLosses(cuda=True).build_loss("ce")
+        opt = torch.optim.SGD([{"params": model.get_1x_lr_params(), "lr": 0.01}, {"params": model.get_10x_lr_params(), "lr": 0.1}],
+                              momentum=0.9, weight_decay=5e-4)
+        losses = []
+        for _ in range(40):
+            opt.zero_grad()
+            loss = crit(model(x), y)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        print(dtype, "loss %.4f -> %.4f" % (losses[0], losses[-1]))
+        assert all(np.isfinite(losses)) and losses[-1] < 0.5 * losses[0]
+    finally:
+        ops.set_compute_dtype(torch.float32)
