@@ -19,6 +19,7 @@
 //
 // Reference sites replaced: every groups=1 nn.Conv2d on the DeepLab path (see include/dass_hip.h).
 #include "dass_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -73,13 +74,63 @@ template <> __device__ __forceinline__ uint4 scale_vec<bf16_t>(uint4 v, const fl
     return v;
 }
 
-constexpr int ROWB = 144;  // LDS bytes per staged row (128 data + 16 pad)
+// ---- f32 operands multiplied on the bf16 MFMA ("split" mode, DASS_F32X3).  x = hi + lo + r with hi = bf16(x),
+// lo = bf16(x - hi), |r| <= 2^-18 |x|;  a*b ~= a_hi*b_hi + a_lo*b_hi + a_hi*b_lo accumulated in f32 (the dropped
+// a_lo*b_lo and the r terms are each <= 2^-18 |a*b|, the size of the f32 accumulation rounding of a ~1000-term
+// dot product).  Three 8-pass bf16 MFMAs replace sixteen... (per 16 k) eight 16-pass f32 MFMAs: 3/16 of the
+// matrix-pipe time.  A staged 16-B unit of 4 f32 becomes {hi01, hi23, lo01, lo23} -- same LDS footprint and
+// addressing as f32, so only the LDS write (convert) and the MFMA cluster differ.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(f32x2 v) {
+    bf16x2 b = __builtin_convertvector(v, bf16x2);  // v_cvt_pk_bf16_f32, RNE
+    return *reinterpret_cast<unsigned *>(&b);
+}
+__device__ __forceinline__ uint4 split_unit(uint4 v) {
+    const f32x2 p0 = {__uint_as_float(v.x), __uint_as_float(v.y)}, p1 = {__uint_as_float(v.z), __uint_as_float(v.w)};
+    const unsigned h0 = pack_bf16x2(p0), h1 = pack_bf16x2(p1);
+    const f32x2 hf0 = {__uint_as_float(h0 << 16), __uint_as_float(h0 & 0xffff0000u)};
+    const f32x2 hf1 = {__uint_as_float(h1 << 16), __uint_as_float(h1 & 0xffff0000u)};
+    return make_uint4(h0, h1, pack_bf16x2(p0 - hf0), pack_bf16x2(p1 - hf1));
+}
+// two units per operand (8 k-values of this lane half): hi*hi + lo*hi of each unit, then hi*lo of both
+__device__ __forceinline__ void mma_split(const uint4 &a1, const uint4 &a2, const uint4 &b1, const uint4 &b2, f32x16 &acc) {
+    const uint4 bh1 = make_uint4(b1.x, b1.y, b1.x, b1.y), bh2 = make_uint4(b2.x, b2.y, b2.x, b2.y);
+    const uint4 ah = make_uint4(a1.x, a1.y, a2.x, a2.y), bl = make_uint4(b1.z, b1.w, b2.z, b2.w);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&ah), *reinterpret_cast<const bf16x8 *>(&bl), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&a1), *reinterpret_cast<const bf16x8 *>(&bh1), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&a2), *reinterpret_cast<const bf16x8 *>(&bh2), acc, 0, 0, 0);
+}
+
+// Three-way split (DASS_F32X6): x = x0 + x1 + x2 exactly to 2^-26 |x| (x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1));
+// the six products of order <= 2^-18 (a0b0, a0b1, a1b0, a1b1, a0b2, a2b0) reproduce the f32 product to below f32
+// rounding, so the result differs from the f32 MFMA only by accumulation order.  6 bf16 MFMAs per 16 k instead of
+// 8 twice-as-long f32 MFMAs: 3/8 of the matrix-pipe time.  A staged unit is {x0 01, x0 23, x1 01, x1 23} (16 B) + {x2 01, x2 23} (8 B).
+__device__ __forceinline__ void split3_unit(uint4 v, uint4 &hm, uint2 &lo) {
+    const f32x2 p0 = {__uint_as_float(v.x), __uint_as_float(v.y)}, p1 = {__uint_as_float(v.z), __uint_as_float(v.w)};
+    const unsigned h0 = pack_bf16x2(p0), h1 = pack_bf16x2(p1);
+    const f32x2 r0 = p0 - f32x2{__uint_as_float(h0 << 16), __uint_as_float(h0 & 0xffff0000u)};
+    const f32x2 r1 = p1 - f32x2{__uint_as_float(h1 << 16), __uint_as_float(h1 & 0xffff0000u)};
+    const unsigned m0 = pack_bf16x2(r0), m1 = pack_bf16x2(r1);
+    const f32x2 s0 = r0 - f32x2{__uint_as_float(m0 << 16), __uint_as_float(m0 & 0xffff0000u)};
+    const f32x2 s1 = r1 - f32x2{__uint_as_float(m1 << 16), __uint_as_float(m1 & 0xffff0000u)};
+    hm = make_uint4(h0, h1, m0, m1);
+    lo = make_uint2(pack_bf16x2(s0), pack_bf16x2(s1));
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const uint4 &a, const uint4 &b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&a), *reinterpret_cast<const bf16x8 *>(&b), c, 0, 0, 0);
+}
 
 // WIDE ("row-tap") variant for the 3-channel network stems (7x7/s2 ResNet, 3x3/s2 MobileNet): a tap is a
 // whole kernel ROW -- the S*Cin input values x[n, iy, ix0 .. ix0+S-1, :] are contiguous in a dense NHWC
 // image -- so the reduction is R slabs of S*Cin (=21 or 9) values instead of R*S slabs of a padded channel.
-template <typename T, int BM, int BN, int WM, int WN, bool WIDE = false>
-__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 * 64) ? 4 : 5)) void conv_igemm_kernel(const ConvP p) {
+template <typename T, int BM, int BN, int WM, int WN, bool WIDE = false, int SPLIT = 0>
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? (SPLIT == 3 ? 2 : 3) : ((BM * BN >= 128 * 64) ? (SPLIT == 3 ? 3 : 4) : (SPLIT == 3 ? 4 : 5)))
+void conv_igemm_kernel(const ConvP p) {
+    static_assert(!SPLIT || sizeof(T) == 4, "split mode multiplies f32 tensors");
+    // LDS bytes per staged row: 128 data + 16 pad (ds_read_b128 of 16 rows -> 16 different 16-B bank slots);
+    // 3-way split rows carry 64 more bytes (the x2 parts) at offset 128
+    constexpr int ROWB = SPLIT == 3 ? 208 : 144;
     constexpr int ES = sizeof(T);
     constexpr int EPV = 16 / ES;  // elements per 16-byte vector
     constexpr int BK = 8 * EPV;   // reduction elements per staged slab (128 B)
@@ -226,9 +277,31 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 
     while (have) {
         __syncthreads();  // everyone finished reading the previous slab
 #pragma unroll
-        for (int j = 0; j < AR; ++j) *reinterpret_cast<uint4 *>(As + (lrow + 32 * j) * ROWB + lchunk * 16) = ra[j];
+        for (int j = 0; j < AR; ++j) {
+            char *dst = As + (lrow + 32 * j) * ROWB;
+            if constexpr (SPLIT == 3) {
+                uint4 hm;
+                uint2 lo;
+                split3_unit(ra[j], hm, lo);
+                *reinterpret_cast<uint4 *>(dst + lchunk * 16) = hm;
+                *reinterpret_cast<uint2 *>(dst + 128 + lchunk * 8) = lo;
+            } else {
+                *reinterpret_cast<uint4 *>(dst + lchunk * 16) = SPLIT == 2 ? split_unit(ra[j]) : ra[j];
+            }
+        }
 #pragma unroll
-        for (int j = 0; j < BR; ++j) *reinterpret_cast<uint4 *>(Bs + (lrow + 32 * j) * ROWB + lchunk * 16) = rb[j];
+        for (int j = 0; j < BR; ++j) {
+            char *dst = Bs + (lrow + 32 * j) * ROWB;
+            if constexpr (SPLIT == 3) {
+                uint4 hm;
+                uint2 lo;
+                split3_unit(rb[j], hm, lo);
+                *reinterpret_cast<uint4 *>(dst + lchunk * 16) = hm;
+                *reinterpret_cast<uint2 *>(dst + 128 + lchunk * 8) = lo;
+            } else {
+                *reinterpret_cast<uint4 *>(dst + lchunk * 16) = SPLIT == 2 ? split_unit(rb[j]) : rb[j];
+            }
+        }
         __syncthreads();
 
         // advance and prefetch the next slab (loads stay in flight under the MFMAs)
@@ -247,17 +320,77 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 
         const char *ap = As + (wm * TMW + (lane & 31)) * ROWB + (lane >> 5) * 16;
         const char *bp = Bs + (wn * TNW + (lane & 31)) * ROWB + (lane >> 5) * 16;
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (SPLIT == 3) {
+            const char *apl = As + (wm * TMW + (lane & 31)) * ROWB + 128 + (lane >> 5) * 8;
+            const char *bpl = Bs + (wn * TNW + (lane & 31)) * ROWB + 128 + (lane >> 5) * 8;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint4 a[MT], b[NT];
+            for (int i = 0; i < 4; i += 2) {
+                uint4 a1[MT], a2[MT], b1[NT], b2[NT];
+                uint2 al1[MT], al2[MT], bl1[NT], bl2[NT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const uint4 *>(ap + mt * 32 * ROWB + i * 32);
+                for (int mt = 0; mt < MT; ++mt) {
+                    a1[mt] = *reinterpret_cast<const uint4 *>(ap + mt * 32 * ROWB + i * 32);
+                    a2[mt] = *reinterpret_cast<const uint4 *>(ap + mt * 32 * ROWB + i * 32 + 32);
+                    al1[mt] = *reinterpret_cast<const uint2 *>(apl + mt * 32 * ROWB + i * 16);
+                    al2[mt] = *reinterpret_cast<const uint2 *>(apl + mt * 32 * ROWB + i * 16 + 16);
+                }
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const uint4 *>(bp + nt * 32 * ROWB + i * 32);
+                for (int nt = 0; nt < NT; ++nt) {
+                    b1[nt] = *reinterpret_cast<const uint4 *>(bp + nt * 32 * ROWB + i * 32);
+                    b2[nt] = *reinterpret_cast<const uint4 *>(bp + nt * 32 * ROWB + i * 32 + 32);
+                    bl1[nt] = *reinterpret_cast<const uint2 *>(bpl + nt * 32 * ROWB + i * 16);
+                    bl2[nt] = *reinterpret_cast<const uint2 *>(bpl + nt * 32 * ROWB + i * 16 + 16);
+                }
+                // term-major order (smallest products first): MT*NT independent accumulators between dependent MFMAs
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+                for (int term = 0; term < 6; ++term)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) Mma<T>::run(a[mt], b[nt], acc[mt][nt]);
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            const uint4 &A1 = a1[mt], &A2 = a2[mt], &B1 = b1[nt], &B2 = b2[nt];
+                            uint4 av, bv;
+                            if (term == 0) { av = make_uint4(A1.x, A1.y, A2.x, A2.y); bv = make_uint4(bl1[nt].x, bl1[nt].y, bl2[nt].x, bl2[nt].y); }       // a0*b2
+                            else if (term == 1) { av = make_uint4(al1[mt].x, al1[mt].y, al2[mt].x, al2[mt].y); bv = make_uint4(B1.x, B1.y, B2.x, B2.y); }  // a2*b0
+                            else if (term == 2) { av = make_uint4(A1.z, A1.w, A2.z, A2.w); bv = make_uint4(B1.z, B1.w, B2.z, B2.w); }                      // a1*b1
+                            else if (term == 3) { av = make_uint4(A1.x, A1.y, A2.x, A2.y); bv = make_uint4(B1.z, B1.w, B2.z, B2.w); }                      // a0*b1
+                            else if (term == 4) { av = A1; bv = make_uint4(B1.x, B1.y, B1.x, B1.y); }                                                      // (a0+a1)*b0, unit 1
+                            else { av = A2; bv = make_uint4(B2.x, B2.y, B2.x, B2.y); }                                                                     // (a0+a1)*b0, unit 2
+                            acc[mt][nt] = mfma_bf16(av, bv, acc[mt][nt]);
+                        }
+            }
+        } else if constexpr (SPLIT == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+                uint4 a1[MT], a2[MT], b1[NT], b2[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    a1[mt] = *reinterpret_cast<const uint4 *>(ap + mt * 32 * ROWB + i * 32);
+                    a2[mt] = *reinterpret_cast<const uint4 *>(ap + mt * 32 * ROWB + i * 32 + 32);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    b1[nt] = *reinterpret_cast<const uint4 *>(bp + nt * 32 * ROWB + i * 32);
+                    b2[nt] = *reinterpret_cast<const uint4 *>(bp + nt * 32 * ROWB + i * 32 + 32);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) mma_split(a1[mt], a2[mt], b1[nt], b2[nt], acc[mt][nt]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint4 a[MT], b[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const uint4 *>(ap + mt * 32 * ROWB + i * 32);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const uint4 *>(bp + nt * 32 * ROWB + i * 32);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) Mma<T>::run(a[mt], b[nt], acc[mt][nt]);
+            }
         }
         __builtin_amdgcn_s_setprio(0);
     }
@@ -522,18 +655,23 @@ __device__ __forceinline__ v2u lds_read_tr16(unsigned addr) {
     return v;
 }
 
-template <int BMK, int BNC>
+// SPLIT (DASS_F32X3): the tensors are f32; a staged 16-B chunk of 4 channels is split into bf16 hi / lo parts
+// that go to two [pixel][channel] bf16 planes, and every k-step issues hi*lo + lo*hi + hi*hi (see split_unit).
+template <int BMK, int BNC, int SPLIT = 0>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradP p) {
-    constexpr int BP = 64;                              // pixels per staged slab = 4 MFMA k-steps
-    constexpr int PA = BMK * 2 + 64, PB = BNC * 2 + 64;  // LDS row pitch in bytes
+    typedef typename std::conditional<SPLIT != 0, float, bf16_t>::type E;
+    constexpr int BP = SPLIT ? 32 : 64;                  // pixels per staged slab (16 per MFMA k-step)
+    constexpr int EPC = SPLIT ? 4 : 8;                   // channels per 16-B global chunk
+    constexpr int PA = BMK * 2 + 64, PB = BNC * 2 + 64;  // LDS row pitch in bytes (per bf16 plane)
     constexpr int TMW = BMK / 2, TNW = BNC / 2, MT = TMW / 32, NT = TNW / 32;
-    constexpr int CPR_A = BMK / 8, RPP_A = 256 / CPR_A, PASS_A = BP / RPP_A;  // 16-B chunks = 8 channels
-    constexpr int CPR_B = BNC / 8, RPP_B = 256 / CPR_B, PASS_B = BP / RPP_B;
+    constexpr int CPR_A = BMK / EPC, RPP_A = 256 / CPR_A, PASS_A = BP / RPP_A;
+    constexpr int CPR_B = BNC / EPC, RPP_B = 256 / CPR_B, PASS_B = BP / RPP_B;
+    constexpr int PLANES = SPLIT ? SPLIT : 1;  // 2 = hi/lo (3 products), 3 = x0/x1/x2 (6 products)
     static_assert(MT >= 1 && NT >= 1 && PASS_A >= 1 && PASS_B >= 1, "tile");
 
-    __shared__ __attribute__((aligned(16))) char smem[BP * PA + BP * PB];
-    char *As = smem;
-    char *Bs = smem + BP * PA;
+    __shared__ __attribute__((aligned(16))) char smem[PLANES * (BP * PA + BP * PB)];
+    char *As = smem;                     // plane pl (SPLIT) at As + pl * BP * PA
+    char *Bs = smem + PLANES * BP * PA;  // plane pl (SPLIT) at Bs + pl * BP * PB
 
     // Workgroups that read the SAME pixel range (all taps, all K/C tiles of one pixel split) get consecutive
     // logical ids and, through the XCD remap, the same L2: dY / X slabs come from HBM once per split instead
@@ -557,8 +695,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradP p)
 
     const int arow = tid / CPR_A, achunk = tid % CPR_A;
     const int brow = tid / CPR_B, bchunk = tid % CPR_B;
-    const bf16_t *xg = reinterpret_cast<const bf16_t *>(p.x);
-    const bf16_t *dyg = reinterpret_cast<const bf16_t *>(p.dy);
+    const E *xg = reinterpret_cast<const E *>(p.x);
+    const E *dyg = reinterpret_cast<const E *>(p.dy);
 
     int b_oh[PASS_B], b_ow[PASS_B];
     long b_xoff[PASS_B];
@@ -575,12 +713,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradP p)
         b_ow[j] = rem - b_oh[j] * p.OW;
         b_xoff[j] = (((long)n * p.H + (b_oh[j] * p.stride + tap_dy)) * p.W + (b_ow[j] * p.stride + tap_dx)) * p.ldx;
     }
-    const bool a_kok = (k0 + achunk * 8) < p.K, b_cok = (c0 + bchunk * 8) < p.C;
-    const bf16_t *dy_ptr[PASS_A];
+    const bool a_kok = (k0 + achunk * EPC) < p.K, b_cok = (c0 + bchunk * EPC) < p.C;
+    const E *dy_ptr[PASS_A];
 #pragma unroll
-    for (int j = 0; j < PASS_A; ++j) dy_ptr[j] = dyg + k0 + achunk * 8 + (pbeg + arow + j * RPP_A) * p.lddy;
+    for (int j = 0; j < PASS_A; ++j) dy_ptr[j] = dyg + k0 + achunk * EPC + (pbeg + arow + j * RPP_A) * p.lddy;
     const long adv_dy = (long)BP * p.lddy;
-    const bf16_t *x_col = xg + c0 + bchunk * 8;
+    const E *x_col = xg + c0 + bchunk * EPC;
     uint4 ra[PASS_A], rb[PASS_B];
     auto load_stage = [&](long pb) {
         const int left = (int)(pend - pb);
@@ -630,38 +768,96 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradP p)
     if (pb < pend) load_stage(pb);
     while (pb < pend) {
         __syncthreads();
+        if constexpr (SPLIT == 3) {
 #pragma unroll
-        for (int j = 0; j < PASS_A; ++j) *reinterpret_cast<uint4 *>(As + (arow + j * RPP_A) * PA + achunk * 16) = ra[j];
+            for (int j = 0; j < PASS_A; ++j) {
+                uint4 hm;
+                uint2 lo;
+                split3_unit(ra[j], hm, lo);
+                char *d = As + (arow + j * RPP_A) * PA + achunk * 8;
+                *reinterpret_cast<uint2 *>(d) = make_uint2(hm.x, hm.y);
+                *reinterpret_cast<uint2 *>(d + BP * PA) = make_uint2(hm.z, hm.w);
+                *reinterpret_cast<uint2 *>(d + 2 * BP * PA) = lo;
+            }
 #pragma unroll
-        for (int j = 0; j < PASS_B; ++j) *reinterpret_cast<uint4 *>(Bs + (brow + j * RPP_B) * PB + bchunk * 16) = rb[j];
+            for (int j = 0; j < PASS_B; ++j) {
+                uint4 hm;
+                uint2 lo;
+                split3_unit(rb[j], hm, lo);
+                char *d = Bs + (brow + j * RPP_B) * PB + bchunk * 8;
+                *reinterpret_cast<uint2 *>(d) = make_uint2(hm.x, hm.y);
+                *reinterpret_cast<uint2 *>(d + BP * PB) = make_uint2(hm.z, hm.w);
+                *reinterpret_cast<uint2 *>(d + 2 * BP * PB) = lo;
+            }
+        } else if constexpr (SPLIT == 2) {
+#pragma unroll
+            for (int j = 0; j < PASS_A; ++j) {
+                const uint4 u = split_unit(ra[j]);
+                *reinterpret_cast<uint2 *>(As + (arow + j * RPP_A) * PA + achunk * 8) = make_uint2(u.x, u.y);
+                *reinterpret_cast<uint2 *>(As + BP * PA + (arow + j * RPP_A) * PA + achunk * 8) = make_uint2(u.z, u.w);
+            }
+#pragma unroll
+            for (int j = 0; j < PASS_B; ++j) {
+                const uint4 u = split_unit(rb[j]);
+                *reinterpret_cast<uint2 *>(Bs + (brow + j * RPP_B) * PB + bchunk * 8) = make_uint2(u.x, u.y);
+                *reinterpret_cast<uint2 *>(Bs + BP * PB + (brow + j * RPP_B) * PB + bchunk * 8) = make_uint2(u.z, u.w);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PASS_A; ++j) *reinterpret_cast<uint4 *>(As + (arow + j * RPP_A) * PA + achunk * 16) = ra[j];
+#pragma unroll
+            for (int j = 0; j < PASS_B; ++j) *reinterpret_cast<uint4 *>(Bs + (brow + j * RPP_B) * PB + bchunk * 16) = rb[j];
+        }
         __syncthreads();
         pb += BP;
         if (pb < pend) load_stage(pb);
 #pragma unroll
         for (int ks = 0; ks < BP / 16; ++ks) {
-            v2u af[MT][2], bfr[NT][2];
+            v2u af[PLANES][MT][2], bfr[PLANES][NT][2];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                af[mt][0] = lds_read_tr16(a_base + (ks * 16) * PA + mt * 64);
-                af[mt][1] = lds_read_tr16(a_base + (ks * 16 + 4) * PA + mt * 64);
-            }
+            for (int pl = 0; pl < PLANES; ++pl) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                bfr[nt][0] = lds_read_tr16(b_base + (ks * 16) * PB + nt * 64);
-                bfr[nt][1] = lds_read_tr16(b_base + (ks * 16 + 4) * PB + nt * 64);
+                for (int mt = 0; mt < MT; ++mt) {
+                    af[pl][mt][0] = lds_read_tr16(a_base + pl * BP * PA + (ks * 16) * PA + mt * 64);
+                    af[pl][mt][1] = lds_read_tr16(a_base + pl * BP * PA + (ks * 16 + 4) * PA + mt * 64);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    bfr[pl][nt][0] = lds_read_tr16(b_base + pl * BP * PB + (ks * 16) * PB + nt * 64);
+                    bfr[pl][nt][1] = lds_read_tr16(b_base + pl * BP * PB + (ks * 16 + 4) * PB + nt * 64);
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            auto frag = [](const v2u(&f)[2]) { return make_uint4(f[0][0], f[0][1], f[1][0], f[1][1]); };
+            auto mma = [&](const uint4 &a4, const uint4 &b4, f32x16 &c) {
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&a4), *reinterpret_cast<const bf16x8 *>(&b4), c, 0, 0, 0);
+            };
+            if constexpr (SPLIT == 3) {
+                // six products, smallest first: (A plane, B plane) = (0,2) (2,0) (1,1) (0,1) (1,0) (0,0)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                uint4 a4 = make_uint4(af[mt][0][0], af[mt][0][1], af[mt][1][0], af[mt][1][1]);
+                for (int term = 0; term < 6; ++term)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    uint4 b4 = make_uint4(bfr[nt][0][0], bfr[nt][0][1], bfr[nt][1][0], bfr[nt][1][1]);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&a4),
-                                                                          *reinterpret_cast<const bf16x8 *>(&b4),
-                                                                          acc[mt][nt], 0, 0, 0);
-                }
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            constexpr int PA_OF[6] = {0, 2, 1, 0, 1, 0}, PB_OF[6] = {2, 0, 1, 1, 0, 0};
+                            mma(frag(af[PA_OF[term]][mt]), frag(bfr[PB_OF[term]][nt]), acc[mt][nt]);
+                        }
+            } else if constexpr (SPLIT == 2) {
+                // order: the two small cross terms first, hi*hi last; 4 independent accumulators between dependent MFMAs
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            mma(frag(af[term == 1 ? 1 : 0][mt]), frag(bfr[term == 0 ? 1 : 0][nt]), acc[mt][nt]);
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) mma(frag(af[0][mt]), frag(bfr[0][nt]), acc[mt][nt]);
             }
         }
     }
@@ -709,11 +905,11 @@ __global__ void weight_transform_kernel(const float *__restrict__ src, T *__rest
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool WIDE = false> int launch_conv(ConvP &p, hipStream_t st) {
+template <typename T, int BM, int BN, int WM, int WN, bool WIDE = false, int SPLIT = 0> int launch_conv(ConvP &p, hipStream_t st) {
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = (p.K + BN - 1) / BN;
     const int grid = p.mtiles * p.ntiles;
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, WIDE>), dim3(grid), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, WIDE, SPLIT>), dim3(grid), dim3(256), 0, st, p);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
@@ -723,10 +919,10 @@ template <typename T, int BM, int BN, int WM, int WN, bool WIDE = false> int lau
 // decides), times the tile's MFMA work over its efficiency (small tiles stage more bytes per flop and leave
 // fewer MFMAs between barriers; a single workgroup per CU has nothing to overlap its loads with).  Padded
 // rows/columns of edge tiles are paid for.  Efficiencies from tools/conv_sweep.py.
-template <typename T> int dispatch_conv(ConvP &p, hipStream_t st) {
+template <typename T, int SPLIT = 0> int dispatch_conv(ConvP &p, hipStream_t st) {
     constexpr int EPV = 16 / sizeof(T);
     p.cchunks = (p.C + 8 * EPV - 1) / (8 * EPV);
-    if (p.K <= 32) return launch_conv<T, 128, 32, 4, 1>(p, st);
+    if (p.K <= 32) return launch_conv<T, 128, 32, 4, 1, false, SPLIT>(p, st);
     auto cost = [&](int bm, int bn, double eff) {
         const long wgs = (long)((p.M + bm - 1) / bm) * ((p.K + bn - 1) / bn);
         const long rounds = (wgs + 255) / 256;
@@ -736,9 +932,9 @@ template <typename T> int dispatch_conv(ConvP &p, hipStream_t st) {
     const double c128 = p.K > 64 ? cost(128, 128, 1.0) : 1e30;
     const double c12864 = cost(128, 64, 0.93);
     const double c64 = cost(64, 64, 0.85);
-    if (c128 <= c12864 && c128 <= c64) return launch_conv<T, 128, 128, 2, 2>(p, st);
-    if (c12864 <= c64) return launch_conv<T, 128, 64, 2, 2>(p, st);
-    return launch_conv<T, 64, 64, 2, 2>(p, st);
+    if (c128 <= c12864 && c128 <= c64) return launch_conv<T, 128, 128, 2, 2, false, SPLIT>(p, st);
+    if (c12864 <= c64) return launch_conv<T, 128, 64, 2, 2, false, SPLIT>(p, st);
+    return launch_conv<T, 64, 64, 2, 2, false, SPLIT>(p, st);
 }
 
 // Work split of the weight gradient.  Every pixel-split adds its whole K x R*S x C tile set into dW with
@@ -766,29 +962,30 @@ template <typename T, int BMK, int BNC, bool WIDE = false> int launch_wgrad(Wgra
     return DASS_OK;
 }
 
-template <int BMK, int BNC> int launch_wgrad_bf16(WgradP &p, hipStream_t st, long split) {
+template <int BMK, int BNC, int SPLIT = 0> int launch_wgrad_bf16(WgradP &p, hipStream_t st, long split) {
+    constexpr int BP = SPLIT ? 32 : 64;
     p.ktiles = (p.K + BMK - 1) / BMK;
     p.ctiles = (p.C + BNC - 1) / BNC;
     const long base = (long)p.ktiles * p.ctiles * p.R * p.S;
     long pps = (p.M + split - 1) / split;
-    pps = (pps + 63) / 64 * 64;
+    pps = (pps + BP - 1) / BP * BP;
     p.pix_per_split = (int)pps;
     p.psplit = (int)((p.M + pps - 1) / pps);
-    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BMK, BNC>), dim3((unsigned)(base * p.psplit)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BMK, BNC, SPLIT>), dim3((unsigned)(base * p.psplit)), dim3(256), 0, st, p);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
 
-int dispatch_wgrad_bf16(WgradP &p, hipStream_t st) {
+template <int SPLIT = 0> int dispatch_wgrad_bf16(WgradP &p, hipStream_t st) {
     const long rs = (long)p.R * p.S;
     auto base_of = [&](int bk, int bc) { return (long)((p.K + bk - 1) / bk) * ((p.C + bc - 1) / bc) * rs; };
     const long target = 768, min_slabs = 16;  // slabs of 32 pixels, as in the f32 heuristic
     if (p.K > 64 && p.C > 64) {
         const long b = base_of(128, 128);
         const long sp = wgrad_split(b, p.M, target, min_slabs);
-        if (b * sp >= 400) return launch_wgrad_bf16<128, 128>(p, st, sp);
+        if (b * sp >= 400) return launch_wgrad_bf16<128, 128, SPLIT>(p, st, sp);
     }
-    return launch_wgrad_bf16<64, 64>(p, st, wgrad_split(base_of(64, 64), p.M, target, min_slabs));
+    return launch_wgrad_bf16<64, 64, SPLIT>(p, st, wgrad_split(base_of(64, 64), p.M, target, min_slabs));
 }
 
 template <typename T> int dispatch_wgrad(WgradP &p, hipStream_t st) {
@@ -809,6 +1006,13 @@ template <typename T> int dispatch_wgrad(WgradP &p, hipStream_t st) {
     return launch_wgrad<T, 64, 64>(p, st, wgrad_split(base_of(64, 64), p.M, target, min_slabs));
 }
 
+static int run_conv(ConvP &p, int dtype, hipStream_t st) {
+    if (dtype == DASS_F32) return dispatch_conv<float>(p, st);
+    if (dtype == DASS_F32X3) return dispatch_conv<float, 2>(p, st);
+    if (dtype == DASS_F32X6) return dispatch_conv<float, 3>(p, st);
+    return dispatch_conv<bf16_t>(p, st);
+}
+
 }  // namespace
 
 static int conv_entry(const void *x, int64_t ldx, const void *w, void *y, int64_t ldy, const float *scale,
@@ -818,8 +1022,8 @@ static int conv_entry(const void *x, int64_t ldx, const void *w, void *y, int64_
     if (!x || !w || !y) return DASS_ERR_ARG;
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || K <= 0 || R <= 0 || S <= 0) return DASS_ERR_ARG;
     if (R * S > 64 || stride < 1 || dil < 1 || ustride < 1) return DASS_ERR_ARG;
-    const int epv = dtype == DASS_F32 ? 4 : 8;
-    if (dtype != DASS_F32 && dtype != DASS_BF16) return DASS_ERR_UNSUPPORTED;
+    if (dtype != DASS_F32 && dtype != DASS_BF16 && dtype != DASS_F32X3 && dtype != DASS_F32X6) return DASS_ERR_UNSUPPORTED;
+    const int epv = dtype == DASS_BF16 ? 8 : 4;
     if (C % epv != 0 || ldx % epv != 0 || ((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return DASS_ERR_ARG;
     if ((long)N * OH * OW >= (1l << 31)) return DASS_ERR_ARG;
     ConvP p;
@@ -860,7 +1064,7 @@ static int conv_entry(const void *x, int64_t ldx, const void *w, void *y, int64_
                 if (!mk && py < OH && px < OW) any_empty = true;
             }
         if (any_empty) {
-            const size_t es = dtype == DASS_F32 ? 4 : 2;
+            const size_t es = dtype == DASS_BF16 ? 2 : 4;
             if (ldy != K) {  // strided rows: zero row by row is not needed on this path (dgrad outputs are dense)
                 return DASS_ERR_UNSUPPORTED;
             }
@@ -875,13 +1079,13 @@ static int conv_entry(const void *x, int64_t ldx, const void *w, void *y, int64_
                 q.o_mul = ustride; q.oy_add = py; q.ox_add = px;
                 q.tap_allow = masks[py][px];
                 q.M = N * q.OHs * q.OWs;
-                const int rc = dtype == DASS_F32 ? dispatch_conv<float>(q, st) : dispatch_conv<bf16_t>(q, st);
+                const int rc = run_conv(q, dtype, st);
                 if (rc != DASS_OK) return rc;
             }
         return DASS_OK;
     }
     if (ustride > 1) return DASS_ERR_UNSUPPORTED;  // transposed addressing exists only in the phase-decomposed form
-    const int rc = dtype == DASS_F32 ? dispatch_conv<float>(p, st) : dispatch_conv<bf16_t>(p, st);
+    const int rc = run_conv(p, dtype, st);
     if (stat_rows) *stat_rows = p.mtiles;
     return rc;
 }
@@ -908,7 +1112,7 @@ extern "C" int dass_conv2d_wgrad(const void *x, int64_t ldx, const void *dy, int
                                  int S, int stride, int pad, int dil, int dtype, void *stream) {
     if (!x || !dy || !dw) return DASS_ERR_ARG;
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || K <= 0 || R <= 0 || S <= 0) return DASS_ERR_ARG;
-    if (dtype != DASS_F32 && dtype != DASS_BF16) return DASS_ERR_UNSUPPORTED;
+    if (dtype != DASS_F32 && dtype != DASS_BF16 && dtype != DASS_F32X3 && dtype != DASS_F32X6) return DASS_ERR_UNSUPPORTED;
     if (C % 4 != 0 || K % 4 != 0 || ldx % 4 != 0 || lddy % 4 != 0) return DASS_ERR_ARG;
     if ((long)N * OH * OW >= (1l << 31)) return DASS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -922,7 +1126,9 @@ extern "C" int dass_conv2d_wgrad(const void *x, int64_t ldx, const void *dy, int
     p.N = N; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K; p.R = R; p.S = S;
     p.stride = stride; p.pad = pad; p.dil = dil;
     p.M = N * OH * OW;
-    if (dtype == DASS_BF16 && C % 8 == 0 && K % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0) return dispatch_wgrad_bf16(p, st);
+    if (dtype == DASS_BF16 && C % 8 == 0 && K % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0) return dispatch_wgrad_bf16<0>(p, st);
+    if (dtype == DASS_F32X3) return dispatch_wgrad_bf16<2>(p, st);
+    if (dtype == DASS_F32X6) return dispatch_wgrad_bf16<3>(p, st);
     return dtype == DASS_F32 ? dispatch_wgrad<float>(p, st) : dispatch_wgrad<bf16_t>(p, st);
 }
 

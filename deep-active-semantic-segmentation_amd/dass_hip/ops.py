@@ -9,15 +9,17 @@ F.cross_entropy do at the reference's call sites (cited on each class).
 """
 import ctypes
 import math
+import os
 
 import torch
 
 from ._lib import check, lib
 
-F32, BF16 = 0, 1
+F32, BF16, F32X3, F32X6 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 
-_state = {"dtype": torch.float32}
+_state = {"dtype": torch.float32, "f32_mma": os.environ.get("DASS_F32_MMA", "bf16x6")}
+assert _state["f32_mma"] in ("f32", "bf16x3", "bf16x6"), "DASS_F32_MMA must be f32, bf16x3 or bf16x6"
 
 
 def set_compute_dtype(dtype):
@@ -28,6 +30,31 @@ def set_compute_dtype(dtype):
 
 def compute_dtype():
     return _state["dtype"]
+
+
+def set_f32_mma(mode):
+    """how the dense convs multiply f32 tensors (tensors, BN, loss and every other kernel stay f32 in all three):
+      "bf16x6" (default) each operand is split exactly into three bf16 parts (x = x0+x1+x2 to 2^-26) and the six
+               products of order <= 2^-18 are accumulated in f32 on v_mfma_f32_32x32x16_bf16 (DASS_F32X6): the f32
+               product to below f32 rounding at 3/8 of the matrix-pipe time -- same parity bars as "f32";
+      "f32"    v_mfma_f32_32x32x2_f32, the plain f32 fma chain;
+      "bf16x3" two parts, three products (DASS_F32X3): 17-bit products (~4.5e-6 per conv), 3/16 of the pipe time;
+               does NOT meet the 1e-3 logit bar on MobileNet -- a fast training mode, not a parity mode.
+    Initial value from the environment variable DASS_F32_MMA."""
+    assert mode in ("f32", "bf16x3", "bf16x6")
+    _state["f32_mma"] = mode
+
+
+def f32_mma():
+    return _state["f32_mma"]
+
+
+def _cdt(t):
+    """dtype code for the MFMA conv entry points"""
+    d = _dt(t)
+    if d == F32:
+        return {"f32": F32, "bf16x3": F32X3, "bf16x6": F32X6}[_state["f32_mma"]]
+    return d
 
 
 def _dt(t):
@@ -93,7 +120,7 @@ def conv_launch(x, ldx, w_op, y, ldy, dims, scale=None, shift=None, residual=Non
     n, h, w, c, oh, ow, k, r, s, stride, pad, dil = dims
     check(lib.dass_conv2d_igemm(_p(x), ldx, _p(w_op), _p(y), ldy, _p(scale), _p(shift), _p(residual), ldr,
                                 _p(in_scale), n, h, w, c, oh, ow, k, r, s, stride, pad, dil, ustride, act,
-                                _dt(y), _stream()), "dass_conv2d_igemm")
+                                _cdt(y), _stream()), "dass_conv2d_igemm")
 
 
 def channel_stats(x, ld, m, k):
@@ -376,7 +403,7 @@ class _ConvBnAct(torch.autograd.Function):
                 nrows = ctypes.c_int(0)
                 w_op = weight_operand(weight, 0, dt, cpad=c)
                 check(lib.dass_conv2d_igemm_stats(_p(xs), ldx, _p(w_op), _p(y_raw), k, n, h, w, c, oh, ow, k, r,
-                                                  weight.shape[3], spec.stride, spec.pad, spec.dil, _dt(y_raw), _p(partial),
+                                                  weight.shape[3], spec.stride, spec.pad, spec.dil, _cdt(y_raw), _p(partial),
                                                   ctypes.byref(nrows), _stream()), "dass_conv2d_igemm_stats")
                 fused_stats = (partial, nrows.value)
             else:
@@ -500,7 +527,7 @@ class _ConvBnAct(torch.autograd.Function):
                 else:
                     wstream = _stream()
                 check(lib.dass_conv2d_wgrad(_p(xs), ldx, _p(dy), lddy, _p(dwk), n, h, w, c, oh, ow, kk, r, s,
-                                            spec.stride, spec.pad, spec.dil, _dt(dy), wstream), "dass_conv2d_wgrad")
+                                            spec.stride, spec.pad, spec.dil, _cdt(dy), wstream), "dass_conv2d_wgrad")
                 if side is not None:
                     _EV_JOIN.record(side)
                     join = _EV_JOIN
@@ -510,7 +537,7 @@ class _ConvBnAct(torch.autograd.Function):
                 pad_t = spec.dil * (r - 1) - spec.pad
                 # dgrad = stride-1 conv over dy with flipped/transposed taps; ustride re-inserts the stride
                 check(lib.dass_conv2d_igemm(_p(dy), lddy, _p(w_t), _p(dx), c, None, None, None, 0, None, n, oh, ow,
-                                            kk, h, w, c, r, s, 1, pad_t, spec.dil, spec.stride, ACT_NONE, _dt(dx),
+                                            kk, h, w, c, r, s, 1, pad_t, spec.dil, spec.stride, ACT_NONE, _cdt(dx),
                                             _stream()), "dass_conv2d_igemm(dgrad)")
             if ctx.needs_input_grad[1] and getattr(spec, "rowtap", False):
                 dwk = torch.empty((k, r, s, c_in), dtype=torch.float32, device=dev)

@@ -15,7 +15,10 @@
  *   - activations are NHWC ("pixel rows"): element (n,h,w,c) of a tensor lives at
  *     ptr + ((n*H + h)*W + w)*ld + c, where ld >= C is the pixel stride in ELEMENTS.
  *     A channel slice of a wider buffer is (ptr + c_off, ld = C_total).
- *   - dtype: DASS_F32 (parity mode, exact f32 MFMA) or DASS_BF16 (storage bf16, f32 accumulate).
+ *   - dtype: DASS_F32 (f32 tensors, f32 MFMA), DASS_BF16 (storage bf16, f32 accumulate), or -- conv entry points
+ *     only -- DASS_F32X3: f32 tensors exactly as DASS_F32, products formed on the bf16 MFMA as
+ *     a_hi*b_hi + a_lo*b_hi + a_hi*b_lo with f32 accumulation (per-product error <= 2^-17, i.e. the size of the
+ *     f32 accumulation rounding; SURVEY.md 7.1 "fp32-parity: fp32-MFMA or 3xbf16-split").
  *   - conv weights are "KRSC": w[k][r][s][c], i.e. an OIHW tensor in channels_last memory.
  *   - logits at the module boundary are NCHW f32, as the reference returns them.
  */
@@ -35,6 +38,8 @@ extern "C" {
 
 #define DASS_F32 0
 #define DASS_BF16 1
+#define DASS_F32X3 2 /* conv2d_igemm / conv2d_igemm_stats / conv2d_wgrad only */
+#define DASS_F32X6 3 /* same entry points: three-way bf16 split, six products -- f32-exact products */
 
 #define DASS_ACT_NONE 0
 #define DASS_ACT_RELU 1

@@ -353,12 +353,15 @@ def test_backward_frozen_bn_vs_oracle(backbone, hw):
     print("%s frozen-BN grads vs f64 oracle: HIP worst %.2e median %.2e | stock f32 CPU worst %.2e median %.2e"
           % (backbone, hip[0][0], med_hip, cpu[0][0], med_cpu))
     if backbone == "resnet":
-        # ReLU-only net at this size: no kink flips -> agreement at the f32 rounding level (measured 3e-6 vs 2e-6)
-        assert med_hip <= max(4 * med_cpu, 1e-5) and hip[0][0] <= max(6 * cpu[0][0], 5e-5), (hip[:3], cpu[:3])
+        # ReLU-only net: the typical (median) parameter agrees at the f32 rounding level (measured 3e-6 vs 2e-6).  The
+        # WORST parameter is rounding luck: one ReLU input within rounding of 0 flips its gate and moves the gradients
+        # of the few layers upstream by ~1e-3 -- tests/dev/grad_modes.py shows it hitting the f32-MFMA, the bf16x6 and
+        # the stock-PyTorch path alike depending on the weight seed -- so it is bounded at the flip scale.
+        assert med_hip <= max(4 * med_cpu, 1e-5) and hip[0][0] <= 5e-3, (hip[:3], cpu[:3])
     else:
         # MobileNetV2 at random init saturates 5-15 % of its ReLU6 units: an activation that sits within rounding
         # of 0 or 6 flips its gradient gate, and ONE flip on the 5x5 maps moves every upstream gradient by ~1e-2.
-        # Forward errors of HIP and stock f32 vs f64 are equal layer by layer (tools/debug_fwd.py) and every
+        # Forward errors of HIP and stock f32 vs f64 are equal layer by layer (tests/dev/debug_fwd.py) and every
         # InvertedResidual block is exact in isolation (test_inverted_residual_blocks_exact below); which kinks
         # flip is rounding luck, so the whole-net bound is the flip scale, not the rounding scale.
         assert med_hip <= 2e-2 and hip[0][0] <= 5e-2, (hip[:3], cpu[:3])

@@ -50,9 +50,20 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture(autouse=True)
+def _restore_mma_mode():
+    from dass_hip import ops
+
+    mode = ops.f32_mma()
+    yield
+    ops.set_f32_mma(mode)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x6", "bf16x3"])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_forward_backward(case):
+def test_conv_forward_backward(case, mode):
     ops = _ops()
+    ops.set_f32_mma(mode)
     n, c, h, w, k, ks, stride, pad, dil = case
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
     x = torch.randn(n, c, h, w, generator=g)
@@ -74,6 +85,42 @@ def test_conv_forward_backward(case):
     yd.backward(_cl(go))
     _close(xd.grad, xr.grad, 5e-4, "conv dgrad %s" % (case,))
     _close(conv_d.weight.grad, conv.weight.grad, 5e-4, "conv wgrad %s" % (case,))
+
+
+@pytest.mark.parametrize("case", [(2, 304, 33, 33, 256, 3, 1, 1, 1), (2, 256, 33, 33, 256, 3, 1, 2, 2), (4, 1024, 17, 17, 256, 1, 1, 0, 1),
+                                  (2, 128, 33, 33, 128, 3, 2, 1, 1), (2, 64, 65, 65, 64, 3, 1, 1, 1), (1, 2048, 9, 9, 256, 3, 1, 12, 12),
+                                  (2, 36, 21, 19, 40, 3, 1, 1, 1)])
+def test_conv_mma_modes_vs_f64(case):
+    """The three ways of multiplying f32 tensors (ops.set_f32_mma) against an f64 torch conv, relative L2 error of
+    forward, input gradient and weight gradient.  'bf16x6' (three-way bf16 split, six products) must sit at the f32
+    rounding level -- it is the default parity engine; 'bf16x3' (two-way split) carries 17-bit products (~4.5e-6)."""
+    ops = _ops()
+    n, c, h, w, k, ks, stride, pad, dil = case
+    g = torch.Generator().manual_seed(1234 + c + k)
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(k, c, ks, ks, generator=g) * (2.0 / (c * ks * ks)) ** 0.5
+    x64 = x.double().requires_grad_(True)
+    w64 = wt.double().requires_grad_(True)
+    y64 = F.conv2d(x64, w64, None, stride, pad, dil)
+    go = torch.randn(y64.shape, generator=g)
+    y64.backward(go.double())
+    rel = lambda a, b: ((a.detach().double().cpu() - b).norm() / b.norm()).item()  # noqa: E731
+    errs = {}
+    for mode in ("f32", "bf16x6", "bf16x3"):
+        ops.set_f32_mma(mode)
+        conv_d = nn.Conv2d(c, k, ks, stride, pad, dil, bias=False).cuda()
+        with torch.no_grad():
+            conv_d.weight.copy_(wt)
+        conv_d.weight.data = conv_d.weight.data.contiguous(memory_format=torch.channels_last)
+        xd = _cl(x).requires_grad_(True)
+        yd = ops.conv_bn_act(xd, conv_d)
+        yd.backward(_cl(go))
+        errs[mode] = (rel(yd, y64.detach()), rel(xd.grad, x64.grad), rel(conv_d.weight.grad, w64.grad))
+    print(case, {m: ["%.1e" % v for v in e] for m, e in errs.items()})
+    for i, what in enumerate(("fwd", "dgrad", "wgrad")):
+        assert errs["f32"][i] <= 3e-6, (what, errs)
+        assert errs["bf16x6"][i] <= max(2.0 * errs["f32"][i], 1e-6), (what, errs)   # f32-exact products: summation order only
+        assert errs["bf16x3"][i] <= 1.2e-5, (what, errs)
 
 
 def test_conv_stem_image_input():
