@@ -197,6 +197,7 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
         w = (torch.randn((k_, 3, 3, c_), device=dev) * 0.02).to(tdt)
         y = torch.empty((n_, h_, h_, k_), device=dev, dtype=tdt)
         dims = (n_, h_, h_, c_, h_, h_, k_, 3, 3, 1, 1, 1)
+        w = ops.prepare_conv_weight(w)  # bf16x6 multiplies pre-split weights (once per optimizer step in training)
         for _ in range(3):
             ops.conv_launch(x, c_, w, y, k_, dims)
         reps = 20

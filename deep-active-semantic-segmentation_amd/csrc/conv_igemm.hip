@@ -20,6 +20,7 @@
 // Reference sites replaced: every groups=1 nn.Conv2d on the DeepLab path (see include/dass_hip.h).
 #include "dass_common.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -117,6 +118,25 @@ __device__ __forceinline__ void split3_unit(uint4 v, uint4 &hm, uint2 &lo) {
     hm = make_uint4(h0, h1, m0, m1);
     lo = make_uint2(pack_bf16x2(s0), pack_bf16x2(s1));
 }
+// eight f32 k-values of one lane (two 16-B LDS reads) -> the three 8 x bf16 MFMA operands x0, x1, x2
+__device__ __forceinline__ void split3_frag(const uint4 &lo4, const uint4 &hi4, uint4 &x0, uint4 &x1, uint4 &x2) {
+    const unsigned raw[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+    unsigned o0[4], o1[4], o2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x2 p = {__uint_as_float(raw[2 * j]), __uint_as_float(raw[2 * j + 1])};
+        const unsigned h = pack_bf16x2(p);
+        const f32x2 r = p - f32x2{__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+        const unsigned m = pack_bf16x2(r);
+        const f32x2 q = r - f32x2{__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+        o0[j] = h;
+        o1[j] = m;
+        o2[j] = pack_bf16x2(q);
+    }
+    x0 = make_uint4(o0[0], o0[1], o0[2], o0[3]);
+    x1 = make_uint4(o1[0], o1[1], o1[2], o1[3]);
+    x2 = make_uint4(o2[0], o2[1], o2[2], o2[3]);
+}
 __device__ __forceinline__ f32x16 mfma_bf16(const uint4 &a, const uint4 &b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&a), *reinterpret_cast<const bf16x8 *>(&b), c, 0, 0, 0);
 }
@@ -124,13 +144,19 @@ __device__ __forceinline__ f32x16 mfma_bf16(const uint4 &a, const uint4 &b, f32x
 // WIDE ("row-tap") variant for the 3-channel network stems (7x7/s2 ResNet, 3x3/s2 MobileNet): a tap is a
 // whole kernel ROW -- the S*Cin input values x[n, iy, ix0 .. ix0+S-1, :] are contiguous in a dense NHWC
 // image -- so the reduction is R slabs of S*Cin (=21 or 9) values instead of R*S slabs of a padded channel.
-template <typename T, int BM, int BN, int WM, int WN, bool WIDE = false, int SPLIT = 0>
-__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? (SPLIT == 3 ? 2 : 3) : ((BM * BN >= 128 * 64) ? (SPLIT == 3 ? 3 : 4) : (SPLIT == 3 ? 4 : 5)))
+// PF = slabs in flight per workgroup (register prefetch ring).  The bf16-pipe engines finish a slab's MFMAs in a
+// fraction of the ~1 us a global load takes even from L2, so with <= 2-4 resident workgroups per CU one slab of
+// prefetch leaves every iteration waiting for memory; small tiles (few staging registers) keep 2-3 slabs in flight.
+template <typename T, int BM, int BN, int WM, int WN, bool WIDE = false, int SPLIT = 0, int PF = 1>
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? (SPLIT == 3 ? 2 : 3) : ((BM * BN >= 128 * 64) ? (SPLIT == 3 ? (PF > 1 ? 2 : 3) : 4) : (SPLIT == 3 ? (PF > 1 ? 3 : 4) : 5)))
 void conv_igemm_kernel(const ConvP p) {
     static_assert(!SPLIT || sizeof(T) == 4, "split mode multiplies f32 tensors");
-    // LDS bytes per staged row: 128 data + 16 pad (ds_read_b128 of 16 rows -> 16 different 16-B bank slots);
-    // 3-way split rows carry 64 more bytes (the x2 parts) at offset 128
-    constexpr int ROWB = SPLIT == 3 ? 208 : 144;
+    // LDS bytes per staged row: 128 data + 16 pad (ds_read_b128 of 16 rows -> 16 different 16-B bank slots).
+    // SPLIT == 3: A rows stay raw f32 (converted by the wave that multiplies them, next to its MFMAs); B rows
+    // come PRE-SPLIT from dass_weight_transform(DASS_F32X6): three 64-B bf16 planes per 32-k slab, 192 + 16 pad.
+    constexpr int ROWB = 144;
+    constexpr int ROWB_B = SPLIT == 3 ? 208 : 144;
+    constexpr int NB = SPLIT == 3 ? (BN * 12 + 255) / 256 : BN / 32;  // 16-B chunks of B per thread and slab
     constexpr int ES = sizeof(T);
     constexpr int EPV = 16 / ES;  // elements per 16-byte vector
     constexpr int BK = 8 * EPV;   // reduction elements per staged slab (128 B)
@@ -139,7 +165,7 @@ void conv_igemm_kernel(const ConvP p) {
     static_assert(WM * WN == 4, "4 waves");
     static_assert(MT >= 1 && NT >= 1, "wave tile");
 
-    __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * ROWB];
+    __shared__ __attribute__((aligned(16))) char smem[BM * ROWB + BN * ROWB_B];
     char *As = smem;
     char *Bs = smem + BM * ROWB;
 
@@ -156,6 +182,7 @@ void conv_igemm_kernel(const ConvP p) {
     // validity bit per tap; the per-slab address is base + a wave-uniform tap delta + channel offset.
     //   forward conv         : by = oh*stride - pad, ey = r*dil
     //   phase of a dgrad     : by = ohs (sub-grid index), ey = (oy_add - pad + r*dil) / ustride  (exact)
+    const int ntaps_all = p.R * p.S;
     int a_by[AR], a_bx[AR], a_n[AR];
     long a_base[AR];
     unsigned long long a_vmask[AR];
@@ -181,7 +208,7 @@ void conv_igemm_kernel(const ConvP p) {
     auto tap_ex = [&](int s) -> int { return phase ? (p.ox_add - p.pad + s * p.dil) / p.ustride : s * p.dil; };
 
     // ---- which taps touch this tile at all (and, per row, which taps are inside the image)
-    const int ntaps = p.R * p.S;
+    const int ntaps = ntaps_all;
     unsigned long long tapmask = 0ull;
     for (int t = 0; t < ntaps; ++t) {
         if (!((p.tap_allow >> t) & 1ull)) continue;  // uniform: host-side phase filter
@@ -199,14 +226,25 @@ void conv_igemm_kernel(const ConvP p) {
         if (__syncthreads_or((int)any)) tapmask |= (1ull << t);
     }
 
-    long b_off[BR];
+    long b_off[NB];
+    int b_lds[NB];
 #pragma unroll
-    for (int j = 0; j < BR; ++j) {
-        const int k = n0 + lrow + 32 * j;
-        b_off[j] = k < p.K ? (long)k * p.wk_stride * ES : -1;
+    for (int j = 0; j < NB; ++j) {
+        if constexpr (SPLIT == 3) {
+            // chunk q of the tile's B slab: row q / 12 (out channel), 16-B chunk q % 12 of its 192-B split row
+            const int q = tid + 256 * j;
+            const int row = q / 12, ch = q - row * 12;
+            const int k = n0 + row;
+            b_off[j] = (row < BN && k < p.K) ? (long)k * ntaps_all * p.cchunks * 192 + ch * 16 : -1;
+            b_lds[j] = row < BN ? row * ROWB_B + ch * 16 : -1;
+        } else {
+            const int k = n0 + lrow + 32 * j;
+            b_off[j] = k < p.K ? (long)k * p.wk_stride * ES : -1;
+            b_lds[j] = (lrow + 32 * j) * ROWB_B + lchunk * 16;
+        }
     }
-    uint4 ra[AR], rb[BR];
-    auto load_stage = [&](int t, int cc) {
+    uint4 ra_[PF][AR], rb_[PF][NB];
+    auto load_stage = [&](uint4(&ra)[AR], uint4(&rb)[NB], int t, int cc) {
         const int r = t / p.S, s = t - r * p.S;
         const long tap_x_off = ((long)tap_ey(r) * p.W + tap_ex(s)) * p.ldx * ES;  // wave-uniform
         const long tap_w_off = (long)t * p.C * ES;
@@ -247,11 +285,21 @@ void conv_igemm_kernel(const ConvP p) {
             }
             ra[j] = v;
         }
+        if constexpr (SPLIT == 3) {
+            const long slab_off = ((long)t * p.cchunks + cc) * 192;
 #pragma unroll
-        for (int j = 0; j < BR; ++j) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (b_off[j] >= 0 && okc) v = *reinterpret_cast<const uint4 *>(p.w + b_off[j] + tap_w_off + cb);
-            rb[j] = v;
+            for (int j = 0; j < NB; ++j) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (b_off[j] >= 0) v = *reinterpret_cast<const uint4 *>(p.w + b_off[j] + slab_off);
+                rb[j] = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (b_off[j] >= 0 && okc) v = *reinterpret_cast<const uint4 *>(p.w + b_off[j] + tap_w_off + cb);
+                rb[j] = v;
+            }
         }
     };
 
@@ -265,98 +313,101 @@ void conv_igemm_kernel(const ConvP p) {
 
     // ---- reduction loop: channel slab OUTER, active taps INNER -- consecutive slabs re-read the same
     // (shifted) neighbourhood of the input, so the 9x tap re-reads are served by L1/L2 instead of the fabric
-    unsigned long long rem_mask = tapmask;
-    int cur_t = -1, cur_cc = 0;
-    bool have = false;
-    if (rem_mask) {
-        cur_t = __builtin_ctzll(rem_mask);
-        rem_mask &= rem_mask - 1;
-        have = true;
-        load_stage(cur_t, cur_cc);
+    unsigned long long it_mask = tapmask;
+    int it_cc = 0;
+    auto next_slab = [&](int &t, int &cc) -> bool {  // block-uniform
+        if (!it_mask) {
+            if (tapmask == 0ull || it_cc + 1 >= p.cchunks) return false;
+            ++it_cc;
+            it_mask = tapmask;
+        }
+        t = __builtin_ctzll(it_mask);
+        it_mask &= it_mask - 1;
+        cc = it_cc;
+        return true;
+    };
+    bool live[PF];
+#pragma unroll
+    for (int sg = 0; sg < PF; ++sg) {
+        int t, cc;
+        live[sg] = next_slab(t, cc);
+        if (live[sg]) load_stage(ra_[sg], rb_[sg], t, cc);
     }
-    while (have) {
+#ifdef DASS_STAMP  // `make stamp`: per-segment s_memtime instrumentation of this loop, read by tools/conv_stamp.py
+    auto stamp = [&]() -> unsigned long long {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return t;
+    };
+    unsigned long long seg[5] = {0, 0, 0, 0, 0};
+    const unsigned long long t_begin = stamp();
+    unsigned long long t0 = t_begin, t1;
+#define STAMP(i) { t1 = stamp(); seg[i] += t1 - t0; t0 = t1; }
+#else
+#define STAMP(i)
+#endif
+    bool more = true;
+    while (more) {
+#pragma unroll
+      for (int sg = 0; sg < PF; ++sg) {
+        if (!live[sg]) {
+            more = false;
+            break;
+        }
+        uint4(&ra)[AR] = ra_[sg];
+        uint4(&rb)[NB] = rb_[sg];
         __syncthreads();  // everyone finished reading the previous slab
+        STAMP(0)
 #pragma unroll
-        for (int j = 0; j < AR; ++j) {
-            char *dst = As + (lrow + 32 * j) * ROWB;
-            if constexpr (SPLIT == 3) {
-                uint4 hm;
-                uint2 lo;
-                split3_unit(ra[j], hm, lo);
-                *reinterpret_cast<uint4 *>(dst + lchunk * 16) = hm;
-                *reinterpret_cast<uint2 *>(dst + 128 + lchunk * 8) = lo;
-            } else {
-                *reinterpret_cast<uint4 *>(dst + lchunk * 16) = SPLIT == 2 ? split_unit(ra[j]) : ra[j];
-            }
-        }
+        for (int j = 0; j < AR; ++j)
+            *reinterpret_cast<uint4 *>(As + (lrow + 32 * j) * ROWB + lchunk * 16) = SPLIT == 2 ? split_unit(ra[j]) : ra[j];
 #pragma unroll
-        for (int j = 0; j < BR; ++j) {
-            char *dst = Bs + (lrow + 32 * j) * ROWB;
-            if constexpr (SPLIT == 3) {
-                uint4 hm;
-                uint2 lo;
-                split3_unit(rb[j], hm, lo);
-                *reinterpret_cast<uint4 *>(dst + lchunk * 16) = hm;
-                *reinterpret_cast<uint2 *>(dst + 128 + lchunk * 8) = lo;
-            } else {
-                *reinterpret_cast<uint4 *>(dst + lchunk * 16) = SPLIT == 2 ? split_unit(rb[j]) : rb[j];
-            }
-        }
+        for (int j = 0; j < NB; ++j)
+            if (SPLIT != 3 || b_lds[j] >= 0) *reinterpret_cast<uint4 *>(Bs + b_lds[j]) = SPLIT == 2 ? split_unit(rb[j]) : rb[j];
+        STAMP(1)
         __syncthreads();
+        STAMP(2)
 
-        // advance and prefetch the next slab (loads stay in flight under the MFMAs)
-        if (rem_mask) {
-            cur_t = __builtin_ctzll(rem_mask);
-            rem_mask &= rem_mask - 1;
-        } else if (++cur_cc < p.cchunks) {
-            rem_mask = tapmask;
-            cur_t = __builtin_ctzll(rem_mask);
-            rem_mask &= rem_mask - 1;
-        } else {
-            have = false;
+        // refill this register stage with the slab PF ahead (loads stay in flight under the MFMAs)
+        {
+            int t, cc;
+            live[sg] = next_slab(t, cc);
+            if (live[sg]) load_stage(ra, rb, t, cc);
         }
-        if (have) load_stage(cur_t, cur_cc);
+        STAMP(3)
 
         const char *ap = As + (wm * TMW + (lane & 31)) * ROWB + (lane >> 5) * 16;
-        const char *bp = Bs + (wn * TNW + (lane & 31)) * ROWB + (lane >> 5) * 16;
+        const char *bp = Bs + (wn * TNW + (lane & 31)) * ROWB_B + (lane >> 5) * 16;
         __builtin_amdgcn_s_setprio(1);
         if constexpr (SPLIT == 3) {
-            const char *apl = As + (wm * TMW + (lane & 31)) * ROWB + 128 + (lane >> 5) * 8;
-            const char *bpl = Bs + (wn * TNW + (lane & 31)) * ROWB + 128 + (lane >> 5) * 8;
+            const char *bp3 = Bs + (wn * TNW + (lane & 31)) * ROWB_B + (lane >> 5) * 16;
 #pragma unroll
-            for (int i = 0; i < 4; i += 2) {
-                uint4 a1[MT], a2[MT], b1[NT], b2[NT];
-                uint2 al1[MT], al2[MT], bl1[NT], bl2[NT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    a1[mt] = *reinterpret_cast<const uint4 *>(ap + mt * 32 * ROWB + i * 32);
-                    a2[mt] = *reinterpret_cast<const uint4 *>(ap + mt * 32 * ROWB + i * 32 + 32);
-                    al1[mt] = *reinterpret_cast<const uint2 *>(apl + mt * 32 * ROWB + i * 16);
-                    al2[mt] = *reinterpret_cast<const uint2 *>(apl + mt * 32 * ROWB + i * 16 + 16);
-                }
+            for (int st = 0; st < 2; ++st) {  // two k16 steps per 32-k slab; this lane half owns k = 16 st + 8 h .. + 7
+                uint4 a0[MT], a1[MT], a2[MT], b0[NT], b1[NT], b2[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    b1[nt] = *reinterpret_cast<const uint4 *>(bp + nt * 32 * ROWB + i * 32);
-                    b2[nt] = *reinterpret_cast<const uint4 *>(bp + nt * 32 * ROWB + i * 32 + 32);
-                    bl1[nt] = *reinterpret_cast<const uint2 *>(bpl + nt * 32 * ROWB + i * 16);
-                    bl2[nt] = *reinterpret_cast<const uint2 *>(bpl + nt * 32 * ROWB + i * 16 + 16);
+                    b0[nt] = *reinterpret_cast<const uint4 *>(bp3 + nt * 32 * ROWB_B + st * 32);
+                    b1[nt] = *reinterpret_cast<const uint4 *>(bp3 + nt * 32 * ROWB_B + 64 + st * 32);
+                    b2[nt] = *reinterpret_cast<const uint4 *>(bp3 + nt * 32 * ROWB_B + 128 + st * 32);
                 }
-                // term-major order (smallest products first): MT*NT independent accumulators between dependent MFMAs
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    // ap already carries (lane>>5)*16; the 8 f32 of this half are 32 B at (2 st + h) * 32
+                    const char *src = ap + mt * 32 * ROWB + st * 64 + (lane >> 5) * 16;
+                    split3_frag(*reinterpret_cast<const uint4 *>(src), *reinterpret_cast<const uint4 *>(src + 16), a0[mt], a1[mt], a2[mt]);
+                }
+                // six products, smallest first; MT*NT independent accumulators between dependent MFMAs
 #pragma unroll
                 for (int term = 0; term < 6; ++term)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
-                            const uint4 &A1 = a1[mt], &A2 = a2[mt], &B1 = b1[nt], &B2 = b2[nt];
-                            uint4 av, bv;
-                            if (term == 0) { av = make_uint4(A1.x, A1.y, A2.x, A2.y); bv = make_uint4(bl1[nt].x, bl1[nt].y, bl2[nt].x, bl2[nt].y); }       // a0*b2
-                            else if (term == 1) { av = make_uint4(al1[mt].x, al1[mt].y, al2[mt].x, al2[mt].y); bv = make_uint4(B1.x, B1.y, B2.x, B2.y); }  // a2*b0
-                            else if (term == 2) { av = make_uint4(A1.z, A1.w, A2.z, A2.w); bv = make_uint4(B1.z, B1.w, B2.z, B2.w); }                      // a1*b1
-                            else if (term == 3) { av = make_uint4(A1.x, A1.y, A2.x, A2.y); bv = make_uint4(B1.z, B1.w, B2.z, B2.w); }                      // a0*b1
-                            else if (term == 4) { av = A1; bv = make_uint4(B1.x, B1.y, B1.x, B1.y); }                                                      // (a0+a1)*b0, unit 1
-                            else { av = A2; bv = make_uint4(B2.x, B2.y, B2.x, B2.y); }                                                                     // (a0+a1)*b0, unit 2
-                            acc[mt][nt] = mfma_bf16(av, bv, acc[mt][nt]);
+                            const uint4 &av = term == 1 ? a2[mt] : ((term == 2 || term == 4) ? a1[mt] : a0[mt]);
+                            const uint4 &bv = term == 0 ? b2[nt] : ((term == 2 || term == 3) ? b1[nt] : b0[nt]);
+                            acc[mt][nt] = mfma_bf16(av, bv, acc[mt][nt]);  // (a0,b2) (a2,b0) (a1,b1) (a0,b1) (a1,b0) (a0,b0)
                         }
             }
         } else if constexpr (SPLIT == 2) {
@@ -393,7 +444,20 @@ void conv_igemm_kernel(const ConvP p) {
             }
         }
         __builtin_amdgcn_s_setprio(0);
+        STAMP(4)
+      }
     }
+#ifdef DASS_STAMP
+    if (p.stat_partial) {  // debug build: the "statistics" buffer receives wave 0's segment cycles of 8 sample workgroups
+        const int slot = (blockIdx.x * 8) / gridDim.x;
+        if (threadIdx.x == 0 && blockIdx.x == (slot * gridDim.x + 7) / 8) {
+            float *o = p.stat_partial + slot * 8;
+            o[0] = (float)(t0 - t_begin);
+            for (int i = 0; i < 5; ++i) o[1 + i] = (float)seg[i];
+        }
+        return;
+    }
+#endif
 
     if (p.stat_partial) {
         // BatchNorm batch statistics fused into the producer: per-channel sum and sum of squares of this tile's
@@ -905,11 +969,43 @@ __global__ void weight_transform_kernel(const float *__restrict__ src, T *__rest
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool WIDE = false, int SPLIT = 0> int launch_conv(ConvP &p, hipStream_t st) {
+// DASS_F32X6 weight operand: rows x taps x ceil(red/32) slabs of [3 parts][32 k] bf16 (192 B), zero padded.
+// mode 0: rows = K, reduction = C (forward);  mode 1: rows = C, reduction = K, taps flipped (dgrad).
+__global__ void weight_split3_kernel(const float *__restrict__ src, bf16_t *__restrict__ dst, int K, int R, int S, int Csrc,
+                                     int Cdst, int mode) {
+    const int rows = mode == 0 ? K : Csrc, red = mode == 0 ? Cdst : K, taps = R * S, cch = (red + 31) / 32;
+    const long total = (long)rows * taps * cch * 32;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 31);
+        long q = i >> 5;
+        const int cc = (int)(q % cch);
+        q /= cch;
+        const int t = (int)(q % taps);
+        const int row = (int)(q / taps);
+        const int r = t / S, s2 = t - r * S;
+        const int e = cc * 32 + j;
+        float v = 0.f;
+        if (mode == 0) {
+            if (e < Csrc) v = src[(((long)row * R + r) * S + s2) * Csrc + e];
+        } else if (e < K) {
+            v = src[(((long)e * R + (R - 1 - r)) * S + (S - 1 - s2)) * Csrc + row];
+        }
+        const bf16_t h = f32_to_bf16(v);
+        const float r1 = v - bf16_to_f32(h);
+        const bf16_t m = f32_to_bf16(r1);
+        const bf16_t l = f32_to_bf16(r1 - bf16_to_f32(m));
+        bf16_t *d = dst + (((long)row * taps + t) * cch + cc) * 96 + j;
+        d[0] = h;
+        d[32] = m;
+        d[64] = l;
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool WIDE = false, int SPLIT = 0, int PF = 1> int launch_conv(ConvP &p, hipStream_t st) {
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = (p.K + BN - 1) / BN;
     const int grid = p.mtiles * p.ntiles;
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, WIDE, SPLIT>), dim3(grid), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, WIDE, SPLIT, PF>), dim3(grid), dim3(256), 0, st, p);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
@@ -923,6 +1019,16 @@ template <typename T, int SPLIT = 0> int dispatch_conv(ConvP &p, hipStream_t st)
     constexpr int EPV = 16 / sizeof(T);
     p.cchunks = (p.C + 8 * EPV - 1) / (8 * EPV);
     if (p.K <= 32) return launch_conv<T, 128, 32, 4, 1, false, SPLIT>(p, st);
+    static const int force = getenv("DASS_CONV_TILE") ? atoi(getenv("DASS_CONV_TILE")) : 0;  // tuning knob (tools/conv_sweep.py)
+    static const int pf = getenv("DASS_CONV_PF") ? atoi(getenv("DASS_CONV_PF")) : 0;  // tuning knob, split-3 engine only
+    if (force == 1) return launch_conv<T, 128, 128, 2, 2, false, SPLIT>(p, st);
+    if constexpr (SPLIT == 3) {
+        if (force == 2 && pf == 2) return launch_conv<T, 128, 64, 2, 2, false, SPLIT, 2>(p, st);
+        if (force == 3 && pf == 2) return launch_conv<T, 64, 64, 2, 2, false, SPLIT, 2>(p, st);
+        if (force == 3 && pf == 3) return launch_conv<T, 64, 64, 2, 2, false, SPLIT, 3>(p, st);
+    }
+    if (force == 2) return launch_conv<T, 128, 64, 2, 2, false, SPLIT>(p, st);
+    if (force == 3) return launch_conv<T, 64, 64, 2, 2, false, SPLIT>(p, st);
     auto cost = [&](int bm, int bn, double eff) {
         const long wgs = (long)((p.M + bm - 1) / bm) * ((p.K + bn - 1) / bn);
         const long rounds = (wgs + 255) / 256;
@@ -1144,10 +1250,17 @@ extern "C" int dass_weight_transform(const float *src, void *dst, int K, int R, 
         hipLaunchKernelGGL(weight_transform_kernel<float>, dim3(grid), dim3(256), 0, st, src, (float *)dst, K, R, S, Csrc, Cdst, mode);
     else if (dtype == DASS_BF16)
         hipLaunchKernelGGL(weight_transform_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, src, (bf16_t *)dst, K, R, S, Csrc, Cdst, mode);
-    else
+    else if (dtype == DASS_F32X6) {
+        const long n6 = (long)(mode == 0 ? K : Csrc) * R * S * (((mode == 0 ? Cdst : K) + 31) / 32) * 32;
+        hipLaunchKernelGGL(weight_split3_kernel, dim3(dass_grid_1d(n6, 256)), dim3(256), 0, st, src, (bf16_t *)dst, K, R, S, Csrc, Cdst, mode);
+    } else
         return DASS_ERR_UNSUPPORTED;
     DASS_LAUNCH_CHECK();
     return DASS_OK;
+}
+
+extern "C" int64_t dass_weight_split_bytes(int rows, int R, int S, int red) {
+    return (int64_t)rows * R * S * ((red + 31) / 32) * 192;
 }
 
 extern "C" int dass_conv2d_rowtap(const void *x, const void *w, void *y, int64_t ldy, int N, int H, int W, int Cin, int OH,

@@ -12,7 +12,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 HEADER = os.path.join(_ROOT, "include", "dass_hip.h")
-LIB_PATH = os.path.join(_HERE, "libdass_hip.so")
+LIB_PATH = os.environ.get("DASS_HIP_LIB", os.path.join(_HERE, "libdass_hip.so"))  # DASS_HIP_LIB: an instrumented debug build
 
 _CTYPES = {
     "int": ctypes.c_int,
@@ -27,7 +27,7 @@ def parse_header(path=HEADER):
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\b(int|const char \*)\s*(dass_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(int64_t|int|const char \*)\s*(dass_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         argtypes = []
         if args and args != "void":
@@ -38,7 +38,7 @@ def parse_header(path=HEADER):
                 else:
                     base = a.replace("const", "").split()[0]
                     argtypes.append(_CTYPES[base])
-        restype = ctypes.c_int if ret == "int" else ctypes.c_char_p
+        restype = {"int": ctypes.c_int, "int64_t": ctypes.c_int64}.get(ret, ctypes.c_char_p)
         protos[name] = (restype, argtypes)
     return protos
 

@@ -268,12 +268,15 @@ def weight_operand(weight, mode, dtype, cpad=None):
     Cached on (storage, version) so eval / MC passes transform once."""
     k, c, r, s = weight.shape
     cdst = c if cpad is None else cpad
-    key = (weight.data_ptr(), weight._version, mode, dtype, cdst, tuple(weight.shape))
+    split6 = dtype == torch.float32 and _state["f32_mma"] == "bf16x6"
+    key = (weight.data_ptr(), weight._version, mode, dtype, cdst, tuple(weight.shape), split6)
     hit = _wcache.get((id(weight), mode))
     if hit is not None and hit[0] == key:
         return hit[1]
     master = _krsc_master(weight)
-    if mode == 0 and dtype == torch.float32 and cdst == c:
+    if split6:
+        op = _split6_operand(master, k, r, s, c, cdst, mode)
+    elif mode == 0 and dtype == torch.float32 and cdst == c:
         op = master
     else:
         if mode == 0:
@@ -284,6 +287,23 @@ def weight_operand(weight, mode, dtype, cpad=None):
                                         _stream()), "dass_weight_transform")
     _wcache[(id(weight), mode)] = (key, op, weight)
     return op
+
+
+def _split6_operand(master, k, r, s, c, cdst, mode):
+    """DASS_F32X6 conv operand: the three bf16 parts of every weight, slab-major (dass_weight_transform)"""
+    nbytes = lib.dass_weight_split_bytes(k if mode == 0 else c, r, s, cdst if mode == 0 else k)
+    op = torch.empty((nbytes,), dtype=torch.uint8, device=master.device)
+    check(lib.dass_weight_transform(_p(master), _p(op), k, r, s, c, cdst, mode, F32X6, _stream()), "dass_weight_transform")
+    return op
+
+
+def prepare_conv_weight(w_krsc, mode=0):
+    """tools / bench: the operand conv_launch() wants for a raw [K][R][S][C] f32 (or bf16) weight tensor in the
+    current engine (identity except for bf16x6, which multiplies pre-split weights)"""
+    if w_krsc.dtype == torch.float32 and _state["f32_mma"] == "bf16x6":
+        k, r, s, c = w_krsc.shape
+        return _split6_operand(w_krsc.contiguous(), k, r, s, c, c, mode)
+    return w_krsc
 
 
 def _pad_to(v, m):
@@ -581,6 +601,8 @@ def _side_stream(dev):
 def _dgrad_operand_uncached(wsrc, dtype):
     k, c, r, s = wsrc.shape
     master = _krsc_master(wsrc)
+    if dtype == torch.float32 and _state["f32_mma"] == "bf16x6":
+        return _split6_operand(master, k, r, s, c, c, 1)
     op = torch.empty((c, r, s, k), dtype=dtype, device=wsrc.device)
     check(lib.dass_weight_transform(_p(master), _p(op), k, r, s, c, c, 1, F32 if dtype == torch.float32 else BF16,
                                     _stream()), "dass_weight_transform")

@@ -97,9 +97,13 @@ int dass_conv2d_rowtap_wgrad(const void *x, const void *dy, int64_t lddy, float 
                              int R, int S, int stride, int pad, int dtype, void *stream);
 
 /* KRSC f32 master weights -> device operand.  mode 0: cast/copy [K][R][S][Csrc] -> [K][R][S][Cdst]
- * (zero pad or truncate channels); mode 1: dgrad operand [C][R][S][K] with taps flipped. */
+ * (zero pad or truncate channels); mode 1: dgrad operand [C][R][S][K] with taps flipped.
+ * dtype DASS_F32X6: the operand dass_conv2d_igemm(.., dtype = DASS_F32X6) REQUIRES as `w`: every weight split into
+ * its three bf16 parts, [rows][R*S][ceil(red/32)][3][32] bf16 (rows/red = K/Cdst for mode 0, C/K for mode 1),
+ * dass_weight_split_bytes(rows, R, S, red) bytes.  (DASS_F32X3 and DASS_F32 take the plain f32 operand.) */
 int dass_weight_transform(const float *src, void *dst, int K, int R, int S, int Csrc, int Cdst,
                           int mode, int dtype, void *stream);
+int64_t dass_weight_split_bytes(int rows, int R, int S, int red);
 
 /* depthwise 3x3 (MobileNetV2 InvertedResidual, mobilenet.py:49,59): w[c][3][3] f32 */
 int dass_dwconv3x3_fwd(const void *x, int64_t ldx, const float *w, void *y, int64_t ldy,

@@ -18,10 +18,11 @@ wt = torch.randn((k, ks, ks, c), device="cuda") * 0.05
 y = torch.empty((n, oh, ow, k), device="cuda")
 dy = torch.randn((n, oh, ow, k), device="cuda")
 dw = torch.empty((k, ks, ks, c), device="cuda")
+wop = ops.prepare_conv_weight(wt)
 for _ in range(reps):
     if mode == "fwd":
-        ops.conv_launch(x, c, wt, y, k, (n, h, w, c, oh, ow, k, ks, ks, st, pad, dil))
+        ops.conv_launch(x, c, wop, y, k, (n, h, w, c, oh, ow, k, ks, ks, st, pad, dil))
     else:
-        check(lib.dass_conv2d_wgrad(ops._p(x), c, ops._p(dy), k, ops._p(dw), n, h, w, c, oh, ow, k, ks, ks, st, pad, dil, 0, ops._stream()), "wgrad")
+        check(lib.dass_conv2d_wgrad(ops._p(x), c, ops._p(dy), k, ops._p(dw), n, h, w, c, oh, ow, k, ks, ks, st, pad, dil, ops._cdt(dy), ops._stream()), "wgrad")
 torch.cuda.synchronize()
 print("done", oh, ow)

@@ -11,7 +11,7 @@ import torch  # noqa: E402
 from dass_hip import ops  # noqa: E402
 from dass_hip._lib import check, lib  # noqa: E402
 
-PEAK = 157.3
+PEAK = {"f32": 157.3, "bf16x6": 2500.0 / 6, "bf16x3": 2500.0 / 3}[ops.f32_mma()]  # engine from DASS_F32_MMA
 
 
 def r101_shapes(batch=8, size=513):
@@ -80,12 +80,13 @@ def main():
         dw = torch.empty((k, ks, ks, c), device=dev)
         flops = 2.0 * n * oh * ow * k * ks * ks * c
         stream = ops._stream()
-        f_fwd = lambda: ops.conv_launch(x, c, wt, y, k, (n, h, w, c, oh, ow, k, ks, ks, st, pad, dil))  # noqa: E731
+        wop, wop_t = ops.prepare_conv_weight(wt), ops.prepare_conv_weight(wt_t)
+        f_fwd = lambda: ops.conv_launch(x, c, wop, y, k, (n, h, w, c, oh, ow, k, ks, ks, st, pad, dil))  # noqa: E731
         pad_t = dil * (ks - 1) - pad
-        f_dg = lambda: check(lib.dass_conv2d_igemm(ops._p(dy), k, ops._p(wt_t), ops._p(dx), c, None, None, None, 0, None, n, oh, ow, k,  # noqa: E731
-                                                   h, w, c, ks, ks, 1, pad_t, dil, st, 0, 0, stream), "dgrad")
+        f_dg = lambda: check(lib.dass_conv2d_igemm(ops._p(dy), k, ops._p(wop_t), ops._p(dx), c, None, None, None, 0, None, n, oh, ow, k,  # noqa: E731
+                                                   h, w, c, ks, ks, 1, pad_t, dil, st, 0, ops._cdt(dx), stream), "dgrad")
         f_wg = lambda: check(lib.dass_conv2d_wgrad(ops._p(x), c, ops._p(dy), k, ops._p(dw), n, h, w, c, oh, ow, k, ks, ks, st, pad,  # noqa: E731
-                                                   dil, 0, stream), "wgrad")
+                                                   dil, ops._cdt(dy), stream), "wgrad")
         res = {}
         for tag, f in (("fwd", f_fwd), ("dgrad", f_dg), ("wgrad", f_wg)):
             if tag == "dgrad" and name == "stem7x7":
@@ -95,6 +96,7 @@ def main():
             tot[tag] += ms * cnt
         totf += flops * cnt
         rows.append((name, cnt, n * oh * ow, c, k, ks, st, dil, flops / 1e9, res))
+    print("engine %s  DASS_CONV_TILE=%s" % (ops.f32_mma(), os.environ.get("DASS_CONV_TILE", "auto")))
     print("%-14s %3s %7s %5s %5s k s d %8s | %8s %6s | %8s %6s | %8s %6s" % ("layer", "cnt", "M", "C", "K", "GFLOP", "fwd ms", "TF/s", "dgrad ms", "TF/s", "wgrad ms", "TF/s"))
     for name, cnt, m, c, k, ks, st, dil, gf, res in rows:
         cells = []

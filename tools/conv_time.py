@@ -9,7 +9,8 @@ n, h, w, c, k, ks, st, pad, dil = [int(v) for v in sys.argv[1:10]]
 oh, ow = ops.conv_out_size(h, ks, st, pad, dil), ops.conv_out_size(w, ks, st, pad, dil)
 x = torch.randn((n, h, w, c), device="cuda"); wt = torch.randn((k, ks, ks, c), device="cuda") * 0.05
 y = torch.empty((n, oh, ow, k), device="cuda")
-f = lambda: ops.conv_launch(x, c, wt, y, k, (n, h, w, c, oh, ow, k, ks, ks, st, pad, dil))
+wop = ops.prepare_conv_weight(wt)
+f = lambda: ops.conv_launch(x, c, wop, y, k, (n, h, w, c, oh, ow, k, ks, ks, st, pad, dil))
 for _ in range(3): f()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 torch.cuda.synchronize(); e0.record()

@@ -1,0 +1,15 @@
+#!/usr/bin/env python
+"""per-kernel totals from a rocprofv3 rocpd sqlite file: rocpd_stats.py results.db [steps]  -> markdown table"""
+import sqlite3, sys, re
+db = sqlite3.connect(sys.argv[1])
+steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+cur = db.cursor()
+cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+rows = cur.execute("select %s, count(*), sum(end - start), avg(end - start) from kernels group by %s order by 3 desc" % (name_col, name_col)).fetchall()
+total = sum(r[2] for r in rows)
+print("total kernel time %.1f ms = %.2f ms/step" % (total / 1e6, total / 1e6 / steps))
+print("| kernel | calls | ms/step | avg us | % |\n|---|---|---|---|---|")
+for name, n, tot, avg in rows[:int(sys.argv[3]) if len(sys.argv) > 3 else 24]:
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    print("| `%s` | %d | %.2f | %.1f | %.2f |" % (name[:90], n, tot / 1e6 / steps, avg / 1e3, 100.0 * tot / total))

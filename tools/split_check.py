@@ -52,7 +52,8 @@ for (n, h, w, c, k, ks, st, pad, dil) in SHAPES:
     for mode in ("f32", "bf16x3", "bf16x6"):
         ops.set_f32_mma(mode)
         y = torch.empty((n, oh, ow, k), device="cuda")
-        f = lambda: ops.conv_launch(x, c, wt, y, k, (n, h, w, c, oh, ow, k, ks, ks, st, pad, dil))
+        wop = ops.prepare_conv_weight(wt)
+        f = lambda: ops.conv_launch(x, c, wop, y, k, (n, h, w, c, oh, ow, k, ks, ks, st, pad, dil))
         t = timeit(f)
         e = rel(y, ref_y)
         dw = torch.empty((k, ks, ks, c), device="cuda")
