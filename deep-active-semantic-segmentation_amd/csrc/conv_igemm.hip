@@ -971,33 +971,96 @@ __global__ void weight_transform_kernel(const float *__restrict__ src, T *__rest
 
 // DASS_F32X6 weight operand: rows x taps x ceil(red/32) slabs of [3 parts][32 k] bf16 (192 B), zero padded.
 // mode 0: rows = K, reduction = C (forward);  mode 1: rows = C, reduction = K, taps flipped (dgrad).
+__device__ __forceinline__ void weight_split3_item(const float *__restrict__ src, bf16_t *__restrict__ dst, int K, int R, int S,
+                                                   int Csrc, int Cdst, int mode, long i) {
+    const int red = mode == 0 ? Cdst : K, taps = R * S, cch = (red + 31) / 32;
+    const int j = (int)(i & 31);
+    long q = i >> 5;
+    const int cc = (int)(q % cch);
+    q /= cch;
+    const int t = (int)(q % taps);
+    const int row = (int)(q / taps);
+    const int r = t / S, s2 = t - r * S;
+    const int e = cc * 32 + j;
+    float v = 0.f;
+    if (mode == 0) {
+        if (e < Csrc) v = src[(((long)row * R + r) * S + s2) * Csrc + e];
+    } else if (e < K) {
+        v = src[(((long)e * R + (R - 1 - r)) * S + (S - 1 - s2)) * Csrc + row];
+    }
+    const bf16_t h = f32_to_bf16(v);
+    const float r1 = v - bf16_to_f32(h);
+    const bf16_t m = f32_to_bf16(r1);
+    const bf16_t l = f32_to_bf16(r1 - bf16_to_f32(m));
+    bf16_t *d = dst + (((long)row * taps + t) * cch + cc) * 96 + j;
+    d[0] = h;
+    d[32] = m;
+    d[64] = l;
+}
+
 __global__ void weight_split3_kernel(const float *__restrict__ src, bf16_t *__restrict__ dst, int K, int R, int S, int Csrc,
                                      int Cdst, int mode) {
-    const int rows = mode == 0 ? K : Csrc, red = mode == 0 ? Cdst : K, taps = R * S, cch = (red + 31) / 32;
-    const long total = (long)rows * taps * cch * 32;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int j = (int)(i & 31);
-        long q = i >> 5;
+    const int rows = mode == 0 ? K : Csrc, red = mode == 0 ? Cdst : K;
+    const long total = (long)rows * R * S * ((red + 31) / 32) * 32;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        weight_split3_item(src, dst, K, R, S, Csrc, Cdst, mode, i);
+}
+
+// every conv weight of a network in ONE launch (the optimizer step invalidates all of them at once).
+// desc[w] = {src, dst, K, R, S, Csrc, Cdst, mode} as 8 x int64; start[w] = first TILE of weight w, a tile being 32 operand
+// rows x one 32-wide reduction slab of one tap.  One 256-thread block per tile: the source is read along its contiguous
+// axis (c), transposed through LDS for the dgrad operand (mode 1), and written along the slab (coalesced both ways).
+__global__ __launch_bounds__(256) void weight_split3_batch_kernel(const long *__restrict__ desc, const long *__restrict__ start, int n,
+                                                                  long total_tiles) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (long tl = blockIdx.x; tl < total_tiles; tl += gridDim.x) {
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (start[mid] <= tl) lo = mid; else hi = mid - 1;
+        }
+        const long *d = desc + 8 * lo;
+        const float *src = reinterpret_cast<const float *>(d[0]);
+        bf16_t *dst = reinterpret_cast<bf16_t *>(d[1]);
+        const int K = (int)d[2], R = (int)d[3], S = (int)d[4], Csrc = (int)d[5], Cdst = (int)d[6], mode = (int)d[7];
+        const int rows = mode == 0 ? K : Csrc, red = mode == 0 ? Cdst : K, taps = R * S, cch = (red + 31) / 32;
+        long q = tl - start[lo];
         const int cc = (int)(q % cch);
         q /= cch;
         const int t = (int)(q % taps);
-        const int row = (int)(q / taps);
+        const int rb = (int)(q / taps);  // row block
         const int r = t / S, s2 = t - r * S;
-        const int e = cc * 32 + j;
-        float v = 0.f;
-        if (mode == 0) {
-            if (e < Csrc) v = src[(((long)row * R + r) * S + s2) * Csrc + e];
-        } else if (e < K) {
-            v = src[(((long)e * R + (R - 1 - r)) * S + (S - 1 - s2)) * Csrc + row];
+        __syncthreads();  // previous tile fully consumed
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int y = ty + 8 * p;
+            float v = 0.f;
+            if (mode == 0) {  // tile[row][e]: source rows are operand rows, contiguous along e = c
+                const int row = rb * 32 + y, e = cc * 32 + tx;
+                if (row < rows && e < Csrc) v = src[(((long)row * R + r) * S + s2) * Csrc + e];
+                tile[y][tx] = v;
+            } else {  // source row = reduction index k, contiguous along the operand row c: store transposed
+                const int e = cc * 32 + y, row = rb * 32 + tx;
+                if (e < K && row < rows) v = src[(((long)e * R + (R - 1 - r)) * S + (S - 1 - s2)) * Csrc + row];
+                tile[tx][y] = v;
+            }
         }
-        const bf16_t h = f32_to_bf16(v);
-        const float r1 = v - bf16_to_f32(h);
-        const bf16_t m = f32_to_bf16(r1);
-        const bf16_t l = f32_to_bf16(r1 - bf16_to_f32(m));
-        bf16_t *d = dst + (((long)row * taps + t) * cch + cc) * 96 + j;
-        d[0] = h;
-        d[32] = m;
-        d[64] = l;
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int y = ty + 8 * p, row = rb * 32 + y;
+            if (row >= rows) continue;
+            const float v = tile[y][tx];
+            const bf16_t h = f32_to_bf16(v);
+            const float r1 = v - bf16_to_f32(h);
+            const bf16_t m = f32_to_bf16(r1);
+            const bf16_t l = f32_to_bf16(r1 - bf16_to_f32(m));
+            bf16_t *o = dst + (((long)row * taps + t) * cch + cc) * 96 + tx;
+            o[0] = h;
+            o[32] = m;
+            o[64] = l;
+        }
     }
 }
 
@@ -1255,6 +1318,15 @@ extern "C" int dass_weight_transform(const float *src, void *dst, int K, int R, 
         hipLaunchKernelGGL(weight_split3_kernel, dim3(dass_grid_1d(n6, 256)), dim3(256), 0, st, src, (bf16_t *)dst, K, R, S, Csrc, Cdst, mode);
     } else
         return DASS_ERR_UNSUPPORTED;
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_weight_split_batch(const void *desc, const int64_t *start, int n, int64_t total, void *stream) {
+    if (!desc || !start || n <= 0 || total <= 0) return DASS_ERR_ARG;
+    const long grid = total < 256 * 32 ? total : 256 * 32;
+    hipLaunchKernelGGL(weight_split3_batch_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
+                       (const long *)desc, (const long *)start, n, (long)total);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }

@@ -10,6 +10,7 @@ F.cross_entropy do at the reference's call sites (cited on each class).
 import ctypes
 import math
 import os
+import weakref
 
 import torch
 
@@ -275,6 +276,8 @@ def weight_operand(weight, mode, dtype, cpad=None):
         return hit[1]
     master = _krsc_master(weight)
     if split6:
+        if master.data_ptr() == weight.data_ptr():  # zero-copy master: eligible for the one-launch refresh of all weights
+            return _split6_registered(weight, master, mode, cdst)
         op = _split6_operand(master, k, r, s, c, cdst, mode)
     elif mode == 0 and dtype == torch.float32 and cdst == c:
         op = master
@@ -287,6 +290,51 @@ def weight_operand(weight, mode, dtype, cpad=None):
                                         _stream()), "dass_weight_transform")
     _wcache[(id(weight), mode)] = (key, op, weight)
     return op
+
+
+class _SplitEntry(object):
+    __slots__ = ("weight", "master", "mode", "cdst", "op", "version", "items")
+
+
+_split_reg = {"entries": {}, "table_key": None, "table": None}
+
+
+def _split6_registered(weight, master, mode, cdst):
+    """bf16x6 operand of a parameter, refreshed together with every other registered conv weight in ONE launch when
+    its version went stale (an optimizer step bumps them all): dass_weight_split_batch."""
+    k, c, r, s = weight.shape
+    ent = _split_reg["entries"].get((id(weight), mode))
+    if ent is None or ent.weight() is not weight or ent.master.data_ptr() != master.data_ptr() or ent.cdst != cdst:
+        ent = _SplitEntry()
+        ent.weight, ent.master, ent.mode, ent.cdst, ent.version = weakref.ref(weight), master, mode, cdst, -1
+        rows, red = (k, cdst) if mode == 0 else (c, k)
+        ent.op = torch.empty((lib.dass_weight_split_bytes(rows, r, s, red),), dtype=torch.uint8, device=weight.device)
+        ent.items = ((rows + 31) // 32) * r * s * ((red + 31) // 32)  # tiles of 32 rows x one slab
+        _split_reg["entries"][(id(weight), mode)] = ent
+    if ent.version != weight._version:
+        dead = [kk for kk, e in _split_reg["entries"].items() if e.weight() is None]
+        for kk in dead:  # parameters that no longer exist: release their operands
+            del _split_reg["entries"][kk]
+        stale = []
+        for e in _split_reg["entries"].values():
+            wt = e.weight()
+            if e.version != wt._version and wt.device == weight.device and wt.data_ptr() == e.master.data_ptr():
+                stale.append((e, wt))
+        key = tuple((e.master.data_ptr(), e.mode, e.op.data_ptr()) for e, _ in stale)
+        if _split_reg["table_key"] != key:
+            rows_, start, acc = [], [], 0
+            for e, wt in stale:
+                kk, cc, rr, ss = wt.shape
+                rows_.append([e.master.data_ptr(), e.op.data_ptr(), kk, rr, ss, cc, e.cdst, e.mode])
+                start.append(acc)
+                acc += e.items
+            _split_reg["table"] = (torch.tensor(rows_, dtype=torch.int64).to(weight.device), torch.tensor(start, dtype=torch.int64).to(weight.device), acc)
+            _split_reg["table_key"] = key
+        desc, start_t, total = _split_reg["table"]
+        check(lib.dass_weight_split_batch(_p(desc), _p(start_t), len(stale), total, _stream()), "dass_weight_split_batch")
+        for e, wt in stale:
+            e.version = wt._version
+    return ent.op
 
 
 def _split6_operand(master, k, r, s, c, cdst, mode):

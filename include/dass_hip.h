@@ -104,6 +104,10 @@ int dass_conv2d_rowtap_wgrad(const void *x, const void *dy, int64_t lddy, float 
 int dass_weight_transform(const float *src, void *dst, int K, int R, int S, int Csrc, int Cdst,
                           int mode, int dtype, void *stream);
 int64_t dass_weight_split_bytes(int rows, int R, int S, int red);
+/* the DASS_F32X6 transform of n weights in one launch (after an optimizer step every conv weight is stale at once):
+ * desc = n x 8 int64 on the device {src ptr, dst ptr, K, R, S, Csrc, Cdst, mode}, start[w] = sum over earlier weights of
+ * their tiles ceil(rows/32)*R*S*ceil(red/32) (32 operand rows x one 32-wide slab), total = the sum over all n. */
+int dass_weight_split_batch(const void *desc, const int64_t *start, int n, int64_t total, void *stream);
 
 /* depthwise 3x3 (MobileNetV2 InvertedResidual, mobilenet.py:49,59): w[c][3][3] f32 */
 int dass_dwconv3x3_fwd(const void *x, int64_t ldx, const float *w, void *y, int64_t ldy,
