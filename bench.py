@@ -221,7 +221,7 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
                  "bf16x3": "float,128,128,2,2,split=2"}[engine]
         res["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel<%s> (3x3 304->256 @%dx%d, batch %d)" % (kname, h_, h_, n_),
                            "achieved": round(achieved, 2), "peak": peak, "peak_note": PEAK_NOTE[engine], "unit": "TFLOP/s",
-                           "frac": round(achieved / peak, 4),
+                           "frac": round(achieved / peak, 4), "frac_of_f32_mfma_peak": round(achieved / MFMA_PEAK_TFLOPS["f32"], 4) if engine != "bf16" else None,
                            "traffic": traffic, "launch_ms": round(ms, 4), "flops_per_launch": flops,
                            "train_step_frac": round(res["train_ips"] * TRAIN_GFLOP_PER_IMAGE / 1e3 / (peak * world), 4)}
     del model, optimizer

@@ -1148,11 +1148,14 @@ template <int BMK, int BNC, int SPLIT = 0> int launch_wgrad_bf16(WgradP &p, hipS
 template <int SPLIT = 0> int dispatch_wgrad_bf16(WgradP &p, hipStream_t st) {
     const long rs = (long)p.R * p.S;
     auto base_of = [&](int bk, int bc) { return (long)((p.K + bk - 1) / bk) * ((p.C + bc - 1) / bc) * rs; };
-    const long target = 768, min_slabs = 16;  // slabs of 32 pixels, as in the f32 heuristic
-    if (p.K > 64 && p.C > 64) {
+    // tuning knobs (tools/conv_sweep.py): workgroups to aim for, minimum 32-pixel slabs per workgroup, forced tile
+    static const long target = getenv("DASS_WGRAD_TARGET") ? atol(getenv("DASS_WGRAD_TARGET")) : 768;
+    static const long min_slabs = getenv("DASS_WGRAD_MINSLABS") ? atol(getenv("DASS_WGRAD_MINSLABS")) : 16;
+    static const int force = getenv("DASS_WGRAD_TILE") ? atoi(getenv("DASS_WGRAD_TILE")) : 0;
+    if (p.K > 64 && p.C > 64 && force != 3) {
         const long b = base_of(128, 128);
         const long sp = wgrad_split(b, p.M, target, min_slabs);
-        if (b * sp >= 400) return launch_wgrad_bf16<128, 128, SPLIT>(p, st, sp);
+        if (b * sp >= 400 || force == 1) return launch_wgrad_bf16<128, 128, SPLIT>(p, st, sp);
     }
     return launch_wgrad_bf16<64, 64, SPLIT>(p, st, wgrad_split(base_of(64, 64), p.M, target, min_slabs));
 }

@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""per-kernel totals from a rocprofv3 rocpd sqlite file: rocpd_stats.py results.db [steps]  -> markdown table"""
+"""per-kernel totals from a rocprofv3 rocpd sqlite file: rocpd_stats.py results.db [steps] [rows] [name-substring grid_x]
+-> markdown table; with a name substring and a grid size (threads) also the average duration of exactly those launches
+(bench.py's roofline leg launches the dominant kernel on ONE shape: grid_x = ceil(M/128)*ceil(K/128)*256)"""
 import sqlite3, sys, re
 db = sqlite3.connect(sys.argv[1])
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
@@ -13,3 +15,9 @@ print("| kernel | calls | ms/step | avg us | % |\n|---|---|---|---|---|")
 for name, n, tot, avg in rows[:int(sys.argv[3]) if len(sys.argv) > 3 else 24]:
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     print("| `%s` | %d | %.2f | %.1f | %.2f |" % (name[:90], n, tot / 1e6 / steps, avg / 1e3, 100.0 * tot / total))
+
+if len(sys.argv) > 5:
+    sub, gx = sys.argv[4], int(sys.argv[5])
+    r = cur.execute("select count(*), avg(end - start), min(end - start), max(end - start) from kernels where %s like ? and grid_x = ?" % name_col,
+                    ("%" + sub + "%", gx)).fetchone()
+    print("\nlaunches of *%s* with grid_x=%d: n=%d avg %.1f us (min %.1f, max %.1f)" % (sub, gx, r[0], r[1] / 1e3, r[2] / 1e3, r[3] / 1e3))
