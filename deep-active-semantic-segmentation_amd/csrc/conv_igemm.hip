@@ -1086,6 +1086,9 @@ template <typename T, int SPLIT = 0> int dispatch_conv(ConvP &p, hipStream_t st)
     static const int pf = getenv("DASS_CONV_PF") ? atoi(getenv("DASS_CONV_PF")) : 0;  // tuning knob, split-3 engine only
     if (force == 1) return launch_conv<T, 128, 128, 2, 2, false, SPLIT>(p, st);
     if constexpr (SPLIT == 3) {
+        if (force == 4) return launch_conv<T, 128, 128, 4, 1, false, SPLIT>(p, st);
+        if (force == 5) return launch_conv<T, 128, 64, 4, 1, false, SPLIT>(p, st);
+        if (force == 6) return launch_conv<T, 64, 128, 2, 2, false, SPLIT>(p, st);
         if (force == 2 && pf == 2) return launch_conv<T, 128, 64, 2, 2, false, SPLIT, 2>(p, st);
         if (force == 3 && pf == 2) return launch_conv<T, 64, 64, 2, 2, false, SPLIT, 2>(p, st);
         if (force == 3 && pf == 3) return launch_conv<T, 64, 64, 2, 2, false, SPLIT, 3>(p, st);
@@ -1098,6 +1101,20 @@ template <typename T, int SPLIT = 0> int dispatch_conv(ConvP &p, hipStream_t st)
         const double lonely = wgs < 256 ? 0.7 : 1.0;  // one workgroup per CU: no partner to hide latency
         return (double)rounds * bm * bn / (eff * lonely);
     };
+    if constexpr (SPLIT == 3) {
+        // bf16x6: the wave that multiplies an A fragment also converts it (36 VALU per 8-value fragment), so layouts
+        // whose waves span the whole tile width (WN = 1: one conversion feeds NT = 4 / 2 column blocks) or at least two
+        // column blocks win over square wave tiles wherever the grid still fills the chip; efficiencies measured with
+        // tools/conv_sweep.py (DASS_CONV_TILE = 3..6) on every DeepLab-R101 shape, forward and dgrad.
+        const double a = p.K > 64 ? cost(128, 128, 1.0) : 1e30;   // 128x128, waves 4x1 (32x128 each)
+        const double b = cost(128, 64, 0.93);                     // 128x64,  waves 4x1 (32x64)
+        const double c = p.K > 64 ? cost(64, 128, 0.91) : 1e30;   // 64x128,  waves 2x2 (32x64)
+        const double d = cost(64, 64, 0.72);                      // 64x64,   waves 2x2 (32x32)
+        if (a <= b && a <= c && a <= d) return launch_conv<T, 128, 128, 4, 1, false, SPLIT>(p, st);
+        if (b <= c && b <= d) return launch_conv<T, 128, 64, 4, 1, false, SPLIT>(p, st);
+        if (c <= d) return launch_conv<T, 64, 128, 2, 2, false, SPLIT>(p, st);
+        return launch_conv<T, 64, 64, 2, 2, false, SPLIT>(p, st);
+    }
     const double c128 = p.K > 64 ? cost(128, 128, 1.0) : 1e30;
     const double c12864 = cost(128, 64, 0.93);
     const double c64 = cost(64, 64, 0.85);

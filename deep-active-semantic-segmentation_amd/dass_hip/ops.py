@@ -624,7 +624,7 @@ class _ConvBnAct(torch.autograd.Function):
 
 
 _side = {}
-_overlap = {"on": False}  # measured: no gain on MI355X (67.6 vs 66.9 ms/step), kept as an experiment switch
+_overlap = {"on": os.environ.get("DASS_OVERLAP_WGRAD", "0") == "1"}  # measured: no gain on MI355X (67.6 vs 66.9 ms/step), kept as an experiment switch
 _EV_FORK = None
 _EV_JOIN = None
 

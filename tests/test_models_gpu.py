@@ -37,10 +37,23 @@ def _product(backbone, ncls, O, seed, randomize_bn_stats=True):
     return pm.cuda(), om
 
 
+@pytest.fixture(autouse=True)
+def _restore_mma_mode():
+    from dass_hip import ops
+
+    mode = ops.f32_mma()
+    yield
+    ops.set_f32_mma(mode)
+
+
+@pytest.mark.parametrize("engine", ["bf16x6", "f32"])
 @pytest.mark.parametrize("tag,backbone", [("mobilenet", "mobilenet"), ("resnet50", "resnet"), ("resnet101", "resnet101"),
                                           ("mobilenet_voc", "mobilenet")])
-def test_e2e_logits_vs_reference_golden(tag, backbone):
+def test_e2e_logits_vs_reference_golden(tag, backbone, engine):
+    """both parity-grade conv engines (exact three-way bf16 split on the bf16 MFMA pipe; plain f32 MFMA) against the
+    reference's own logits"""
     ops, O, S = _setup()
+    ops.set_f32_mma(engine)
     g = np.load(os.path.join(GOLD, "e2e_%s.npz" % tag))
     n, hw, ncls = [int(v) for v in g["meta"]]
     pm, _ = _product(backbone, ncls, O, seed=1)
@@ -65,8 +78,10 @@ def test_e2e_logits_vs_reference_golden(tag, backbone):
     assert (pooled - torch.from_numpy(g["feat_pooled"])).abs().max().item() <= 1e-3
 
 
-def test_mc_dropout_votes_and_entropy_vs_reference_golden():
+@pytest.mark.parametrize("engine", ["bf16x6", "f32"])
+def test_mc_dropout_votes_and_entropy_vs_reference_golden(engine):
     ops, O, S = _setup()
+    ops.set_f32_mma(engine)
     g = np.load(os.path.join(GOLD, "mc_dropout_mobilenet.npz"))
     n, hw, ncls, T = [int(v) for v in g["meta"]]
     pm, om = _product("mobilenet", ncls, O, seed=2)
