@@ -166,6 +166,7 @@ void conv_igemm_kernel(const ConvP p) {
     static_assert(MT >= 1 && NT >= 1, "wave tile");
 
     __shared__ __attribute__((aligned(16))) char smem[BM * ROWB + BN * ROWB_B];
+    __shared__ long tap_tab[64];  // per tap: byte offset of its input pixel relative to a row's base pixel (wave-uniform)
     char *As = smem;
     char *Bs = smem + BM * ROWB;
 
@@ -214,6 +215,7 @@ void conv_igemm_kernel(const ConvP p) {
         if (!((p.tap_allow >> t) & 1ull)) continue;  // uniform: host-side phase filter
         const int r = t / p.S, s = t - r * p.S;
         const int ey = tap_ey(r), ex = tap_ex(s);
+        if (tid == 0) tap_tab[t] = ((long)ey * p.W + ex) * p.ldx * ES;  // read after the barriers below
         bool any = false;
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
@@ -245,8 +247,8 @@ void conv_igemm_kernel(const ConvP p) {
     }
     uint4 ra_[PF][AR], rb_[PF][NB];
     auto load_stage = [&](uint4(&ra)[AR], uint4(&rb)[NB], int t, int cc) {
-        const int r = t / p.S, s = t - r * p.S;
-        const long tap_x_off = ((long)tap_ey(r) * p.W + tap_ex(s)) * p.ldx * ES;  // wave-uniform
+        // integer divisions of the tap decomposition are paid once per kernel (tap_tab), not once per slab
+        const long tap_x_off = WIDE ? ((long)tap_ey(t / p.S) * p.W + tap_ex(t % p.S)) * p.ldx * ES : tap_tab[t];  // wave-uniform
         const long tap_w_off = (long)t * p.C * ES;
         const int c = cc * BK + lchunk * EPV;
         const bool okc = c < p.C;
