@@ -217,7 +217,7 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
         tfile = os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % engine)
         if os.path.exists(tfile):  # HBM bytes per launch from the rocprofv3 --pmc passes (collected offline, see profiles/)
             traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-        kname = {"f32": "float,128,128,2,2", "bf16": "bf16,128,128,2,2", "bf16x6": "float,128,128,2,2,split=3",
+        kname = {"f32": "float,128,128,2,2", "bf16": "bf16,128,128,2,2", "bf16x6": "float,128,128,4,1,split=3",
                  "bf16x3": "float,128,128,2,2,split=2"}[engine]
         res["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel<%s> (3x3 304->256 @%dx%d, batch %d)" % (kname, h_, h_, n_),
                            "achieved": round(achieved, 2), "peak": peak, "peak_note": PEAK_NOTE[engine], "unit": "TFLOP/s",
