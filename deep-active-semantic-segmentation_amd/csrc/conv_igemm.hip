@@ -154,7 +154,10 @@ void conv_igemm_kernel(const ConvP p) {
     // LDS bytes per staged row: 128 data + 16 pad (ds_read_b128 of 16 rows -> 16 different 16-B bank slots).
     // SPLIT == 3: A rows stay raw f32 (converted by the wave that multiplies them, next to its MFMAs); B rows
     // come PRE-SPLIT from dass_weight_transform(DASS_F32X6): three 64-B bf16 planes per 32-k slab, 192 + 16 pad.
-    constexpr int ROWB = 144;
+    // ASTG: wave tiles of ONE column block (MT = NT = 1) would convert every A fragment for a single MFMA column, so
+    // there A is split once per element while it is staged instead (three 64-B planes per row, like B)
+    constexpr bool ASTG = SPLIT == 3 && (BM / WM) == 32 && (BN / WN) == 32;
+    constexpr int ROWB = ASTG ? 208 : 144;
     constexpr int ROWB_B = SPLIT == 3 ? 208 : 144;
     constexpr int NB = SPLIT == 3 ? (BN * 12 + 255) / 256 : BN / 32;  // 16-B chunks of B per thread and slab
     constexpr int ES = sizeof(T);
@@ -364,7 +367,17 @@ void conv_igemm_kernel(const ConvP p) {
         STAMP(0)
 #pragma unroll
         for (int j = 0; j < AR; ++j)
-            *reinterpret_cast<uint4 *>(As + (lrow + 32 * j) * ROWB + lchunk * 16) = SPLIT == 2 ? split_unit(ra[j]) : ra[j];
+            if constexpr (ASTG) {
+                uint4 hm;
+                uint2 lo;
+                split3_unit(ra[j], hm, lo);
+                char *d = As + (lrow + 32 * j) * ROWB + lchunk * 8;
+                *reinterpret_cast<uint2 *>(d) = make_uint2(hm.x, hm.y);
+                *reinterpret_cast<uint2 *>(d + 64) = make_uint2(hm.z, hm.w);
+                *reinterpret_cast<uint2 *>(d + 128) = lo;
+            } else {
+                *reinterpret_cast<uint4 *>(As + (lrow + 32 * j) * ROWB + lchunk * 16) = SPLIT == 2 ? split_unit(ra[j]) : ra[j];
+            }
 #pragma unroll
         for (int j = 0; j < NB; ++j)
             if (SPLIT != 3 || b_lds[j] >= 0) *reinterpret_cast<uint4 *>(Bs + b_lds[j]) = SPLIT == 2 ? split_unit(rb[j]) : rb[j];
@@ -397,8 +410,15 @@ void conv_igemm_kernel(const ConvP p) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     // ap already carries (lane>>5)*16; the 8 f32 of this half are 32 B at (2 st + h) * 32
-                    const char *src = ap + mt * 32 * ROWB + st * 64 + (lane >> 5) * 16;
-                    split3_frag(*reinterpret_cast<const uint4 *>(src), *reinterpret_cast<const uint4 *>(src + 16), a0[mt], a1[mt], a2[mt]);
+                    if constexpr (ASTG) {
+                        const char *src = ap + mt * 32 * ROWB + st * 32;  // ap carries (lane>>5)*16: plane p at + 64 p
+                        a0[mt] = *reinterpret_cast<const uint4 *>(src);
+                        a1[mt] = *reinterpret_cast<const uint4 *>(src + 64);
+                        a2[mt] = *reinterpret_cast<const uint4 *>(src + 128);
+                    } else {
+                        const char *src = ap + mt * 32 * ROWB + st * 64 + (lane >> 5) * 16;
+                        split3_frag(*reinterpret_cast<const uint4 *>(src), *reinterpret_cast<const uint4 *>(src + 16), a0[mt], a1[mt], a2[mt]);
+                    }
                 }
                 // six products, smallest first; MT*NT independent accumulators between dependent MFMAs
 #pragma unroll
