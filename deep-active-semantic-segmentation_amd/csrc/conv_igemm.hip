@@ -1319,15 +1319,15 @@ extern "C" int dass_conv2d_igemm_stats(const void *x, int64_t ldx, const void *w
                       DASS_ACT_NONE, dtype, stream, stat_partial, stat_rows);
 }
 
-extern "C" int dass_conv2d_wgrad(const void *x, int64_t ldx, const void *dy, int64_t lddy, float *dw, int N, int H, int W, int C, int OH, int OW, int K, int R,
-                                 int S, int stride, int pad, int dil, int dtype, void *stream) {
+static int wgrad_entry(const void *x, int64_t ldx, const void *dy, int64_t lddy, float *dw, int N, int H, int W, int C, int OH, int OW, int K, int R,
+                       int S, int stride, int pad, int dil, int dtype, void *stream, bool zero_first) {
     if (!x || !dy || !dw) return DASS_ERR_ARG;
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || K <= 0 || R <= 0 || S <= 0) return DASS_ERR_ARG;
     if (dtype != DASS_F32 && dtype != DASS_BF16 && dtype != DASS_F32X3 && dtype != DASS_F32X6) return DASS_ERR_UNSUPPORTED;
     if (C % 4 != 0 || K % 4 != 0 || ldx % 4 != 0 || lddy % 4 != 0) return DASS_ERR_ARG;
     if ((long)N * OH * OW >= (1l << 31)) return DASS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * R * S * C, st) != hipSuccess) return DASS_ERR_LAUNCH;
+    if (zero_first && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * R * S * C, st) != hipSuccess) return DASS_ERR_LAUNCH;
     WgradP p;
     p.x = (const char *)x;
     p.dy = (const char *)dy;
@@ -1341,6 +1341,16 @@ extern "C" int dass_conv2d_wgrad(const void *x, int64_t ldx, const void *dy, int
     if (dtype == DASS_F32X3) return dispatch_wgrad_bf16<2>(p, st);
     if (dtype == DASS_F32X6) return dispatch_wgrad_bf16<3>(p, st);
     return dtype == DASS_F32 ? dispatch_wgrad<float>(p, st) : dispatch_wgrad<bf16_t>(p, st);
+}
+
+extern "C" int dass_conv2d_wgrad(const void *x, int64_t ldx, const void *dy, int64_t lddy, float *dw, int N, int H, int W, int C, int OH, int OW, int K, int R,
+                                 int S, int stride, int pad, int dil, int dtype, void *stream) {
+    return wgrad_entry(x, ldx, dy, lddy, dw, N, H, W, C, OH, OW, K, R, S, stride, pad, dil, dtype, stream, true);
+}
+
+extern "C" int dass_conv2d_wgrad_acc(const void *x, int64_t ldx, const void *dy, int64_t lddy, float *dw, int N, int H, int W, int C, int OH, int OW, int K,
+                                     int R, int S, int stride, int pad, int dil, int dtype, void *stream) {
+    return wgrad_entry(x, ldx, dy, lddy, dw, N, H, W, C, OH, OW, K, R, S, stride, pad, dil, dtype, stream, false);
 }
 
 extern "C" int dass_weight_transform(const float *src, void *dst, int K, int R, int S, int Csrc, int Cdst, int mode,

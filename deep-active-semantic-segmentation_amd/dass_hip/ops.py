@@ -586,7 +586,7 @@ class _ConvBnAct(torch.autograd.Function):
             want_dx = ctx.needs_input_grad[0] and not ctx.image_input
             generic_dw = ctx.needs_input_grad[1] and not getattr(spec, "rowtap", False)
             if generic_dw:
-                dwk = torch.empty((kk, r, s, c), dtype=torch.float32, device=dev)
+                dwk = _zeroed_dw(kk * r * s * c, dev).view(kk, r, s, c)
                 side = _side_stream(dev) if want_dx else None
                 if side is not None:
                     _EV_FORK.record()
@@ -594,8 +594,8 @@ class _ConvBnAct(torch.autograd.Function):
                     wstream = ctypes.c_void_p(side.cuda_stream)
                 else:
                     wstream = _stream()
-                check(lib.dass_conv2d_wgrad(_p(xs), ldx, _p(dy), lddy, _p(dwk), n, h, w, c, oh, ow, kk, r, s,
-                                            spec.stride, spec.pad, spec.dil, _cdt(dy), wstream), "dass_conv2d_wgrad")
+                check(lib.dass_conv2d_wgrad_acc(_p(xs), ldx, _p(dy), lddy, _p(dwk), n, h, w, c, oh, ow, kk, r, s,
+                                                spec.stride, spec.pad, spec.dil, _cdt(dy), wstream), "dass_conv2d_wgrad_acc")
                 if side is not None:
                     _EV_JOIN.record(side)
                     join = _EV_JOIN
@@ -621,6 +621,26 @@ class _ConvBnAct(torch.autograd.Function):
         if dx is not None and ctx.x_dtype != dx.dtype:
             dx = dx.to(ctx.x_dtype)
         return dx, dw, dgamma, dbeta, dbias, dres, None, None, None
+
+
+_dw_arena = {"buf": None, "off": 0, "size": 1 << 21, "on": os.environ.get("DASS_DW_ARENA", "1") == "1"}
+
+
+def _zeroed_dw(numel, dev):
+    """a zeroed f32 slice for one conv weight gradient (the wgrad kernels accumulate with atomics).  Slices are cut from
+    an arena cleared by ONE memset instead of one per layer; an arena is never handed out twice -- parameters' .grad
+    tensors are views of it and keep it alive -- so gradient accumulation across steps stays correct."""
+    a = _dw_arena
+    if not a["on"]:
+        return torch.zeros((numel,), dtype=torch.float32, device=dev)
+    need = (numel + 63) // 64 * 64
+    if a["buf"] is None or a["buf"].device != dev or a["off"] + need > a["buf"].numel():
+        a["size"] = min(max(2 * a["size"], need), max(1 << 27, need))  # grows to >= one backward pass (R101: 59 M floats)
+        a["buf"] = torch.zeros((a["size"],), dtype=torch.float32, device=dev)
+        a["off"] = 0
+    out = a["buf"][a["off"]:a["off"] + numel]
+    a["off"] += need
+    return out
 
 
 _side = {}

@@ -84,6 +84,11 @@ int dass_conv2d_igemm_stats(const void *x, int64_t ldx, const void *w, void *y, 
 int dass_conv2d_wgrad(const void *x, int64_t ldx, const void *dy, int64_t lddy, float *dw,
                       int N, int H, int W, int C, int OH, int OW, int K,
                       int R, int S, int stride, int pad, int dil, int dtype, void *stream);
+/* same, ACCUMULATING into dw (dw += gradient; no zero fill): the caller hands a zeroed slice of one arena it cleared
+ * with a single memset for all layers of a backward pass, or a gradient buffer it is accumulating into */
+int dass_conv2d_wgrad_acc(const void *x, int64_t ldx, const void *dy, int64_t lddy, float *dw,
+                      int N, int H, int W, int C, int OH, int OW, int K,
+                      int R, int S, int stride, int pad, int dil, int dtype, void *stream);
 
 /* Network stems (resnet.py:65 7x7/s2, mobilenet.py:14 3x3/s2 over the 3-channel image): "row-tap" form of
  * the same implicit GEMM.  x is a DENSE NHWC image [N,H,W,Cin] (ld = Cin, no channel padding); a tap is a
