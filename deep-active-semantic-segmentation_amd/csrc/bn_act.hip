@@ -142,11 +142,20 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const T *__restric
                                                               const T *__restrict__ res, long ldr,
                                                               const float *__restrict__ nc_scale, long M, int K,
                                                               long rows_per_image, int act) {
+    // (row, 4-channel group) walked incrementally: the grid stride is decomposed once, so the loop has no 64-bit division
     const int kv = K >> 2;
-    const long total = M * kv;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long m = i / kv;
-        const int k = (int)(i - m * kv) << 2;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long dm = stride / kv;
+    const int dk = (int)(stride - dm * kv);
+    long m = i0 / kv;
+    int kq = (int)(i0 - m * kv);
+    for (; m < M; m += dm, kq += dk) {
+        if (kq >= kv) {
+            kq -= kv;
+            if (++m >= M) break;
+        }
+        const int k = kq << 2;
         f32x4 v = ld4<T>(x + m * ldx + k);
         if (scale) v *= *reinterpret_cast<const f32x4 *>(scale + k);
         if (shift) v += *reinterpret_cast<const f32x4 *>(shift + k);
@@ -171,10 +180,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
                                                            long lddx, T *__restrict__ dres, long lddr, long M, int K,
                                                            long rows_per_image, float inv_count, int train, int act) {
     const int kv = K >> 2;
-    const long total = M * kv;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long m = i / kv;
-        const int k = (int)(i - m * kv) << 2;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long dm = stride / kv;
+    const int dk = (int)(stride - dm * kv);
+    long m = i0 / kv;
+    int kq = (int)(i0 - m * kv);
+    for (; m < M; m += dm, kq += dk) {
+        if (kq >= kv) {
+            kq -= kv;
+            if (++m >= M) break;
+        }
+        const int k = kq << 2;
         f32x4 g = ld4<T>(dout + m * lddo + k);
         const f32x4 o = ld4<T>(out + m * ldo + k);
         if (nc_scale) g *= *reinterpret_cast<const f32x4 *>(nc_scale + (m / rows_per_image) * K + k);
