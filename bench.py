@@ -294,10 +294,10 @@ def main():
         k2 = max(3, args.steps // 2)
         if args.dtype == "f32":
             if args.f32_mma != "f32":
-                others["f32_mfma_mode"] = run_mode(args, env, "f32", k2, 2, "f32")
-            others["bf16_perf_mode"] = run_mode(args, env, "bf16", k2, 2)
+                others["f32_mfma_mode"] = run_mode(args, env, "f32", k2, 4, "f32")
+            others["bf16_perf_mode"] = run_mode(args, env, "bf16", k2, 4)  # 4 warm-up steps: the allocator re-grows after empty_cache()
         else:
-            others["f32_parity_mode"] = run_mode(args, env, "f32", k2, 2, args.f32_mma)
+            others["f32_parity_mode"] = run_mode(args, env, "f32", k2, 4, args.f32_mma)
     cpu = None
     if env.rank == 0 and env.world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
