@@ -475,3 +475,34 @@ def test_region_kernels():
             break
     got_regions, got_cnt = ops.square_nms(refn.clone().cuda(), r, 12)
     assert got_cnt == cnt and got_regions == regions
+
+
+def test_weight_split_operand_is_exact():
+    """DASS_F32X6 operand (dass_weight_transform / dass_weight_split_batch): every weight equals the sum of its three
+    bf16 parts to <= 2^-24 |w| (measured: exact for almost all values), for forward and dgrad layouts, including zero
+    padding of the 32-wide slabs, tiny and huge magnitudes."""
+    ops = _ops()
+    ops.set_f32_mma("bf16x6")
+    k, r, s, c = 40, 3, 3, 36  # neither multiple of 32: slabs are zero padded
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(k, r, s, c, generator=g)
+    w.view(-1)[:64] *= 1e-30
+    w.view(-1)[64:128] *= 1e30
+    w.view(-1)[128:136] = 0.0
+    wd = w.cuda()
+    for mode in (0, 1):
+        rows, red = (k, c) if mode == 0 else (c, k)
+        cch = (red + 31) // 32
+        op = ops.prepare_conv_weight(wd, mode)
+        assert op.numel() == rows * r * s * cch * 192
+        parts = op.view(torch.bfloat16).view(rows, r * s, cch, 3, 32).double().cpu()
+        recon = parts.sum(3).reshape(rows, r, s, cch * 32)
+        if mode == 0:
+            ref = torch.zeros(rows, r, s, cch * 32, dtype=torch.float64)
+            ref[..., :c] = w.double()
+        else:  # [c][r][s][k] with taps flipped
+            ref = torch.zeros(rows, r, s, cch * 32, dtype=torch.float64)
+            ref[..., :k] = w.double().permute(3, 1, 2, 0).flip(1, 2)
+        err = (recon - ref).abs()
+        assert (err <= ref.abs() * 2.0 ** -24).all(), err.max()
+        assert (recon[..., red:] == 0).all()
