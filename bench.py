@@ -98,7 +98,7 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
     from utils.loss import SegmentationLosses
     from active_selection.base import shard_bounds
     from active_selection.mc_dropout import ActiveSelectionMCDropout
-    from dass_hip.dist import average_gradients
+    from dass_hip.dist import GradientAverager, average_gradients
 
     rank, world, dev, dist = env.rank, env.world, env.dev, env.dist
     ops.set_compute_dtype(torch.float32 if dtype_name == "f32" else torch.bfloat16)
@@ -129,12 +129,18 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    # N > 1: bucketed RCCL all-reduce of the gradients, overlapped with backward through grad hooks
+    # (DASS_DDP_OVERLAP=0: the plain after-backward form)
+    averager = GradientAverager(params) if dist is not None and os.environ.get("DASS_DDP_OVERLAP", "1") == "1" else None
+
     def train_step():
         optimizer.zero_grad(set_to_none=True)
         out = model(image)
         loss = criterion(out, target)
         loss.backward()
-        if dist is not None:
+        if averager is not None:
+            averager.finish()
+        elif dist is not None:
             average_gradients(params)
         optimizer.step()
         return loss

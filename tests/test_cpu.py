@@ -285,3 +285,51 @@ def test_pool_sharding_world2_gloo(tmp_path):
     assert all(p.returncode == 0 for p in procs), outs
     assert "rank 0 ok" in outs[0] and "rank 1 ok" in outs[1]
     assert outs[0].split("ok")[1].strip() == outs[1].split("ok")[1].strip()
+
+
+_DDP_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from dass_hip.dist import GradientAverager, average_gradients
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+def net():
+    torch.manual_seed(3)
+    return torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 8, 3, padding=1), torch.nn.ReLU(),
+                               torch.nn.Conv2d(8, 5, 1), torch.nn.Conv2d(5, 5, 1))   # the last layer is left unused below
+g = torch.Generator().manual_seed(11)
+x = torch.randn(4, 3, 9, 9, generator=g); y = torch.randn(4, 5, 9, 9, generator=g)
+def loss_of(m, xs, ys):
+    return ((m[:5](xs) - ys) ** 2).mean()           # m[5] gets no gradient: its bucket must still go out on every rank
+ref = net(); loss_of(ref, x, y).backward()           # single process, whole batch
+for mode in ("post", "overlap", "overlap"):         # the overlapped averager is reused across steps
+    if mode == "post" or "m" not in globals() or mode != last:
+        m = net(); avg = GradientAverager(m.parameters(), bucket_bytes=1024) if mode == "overlap" else None
+    last = mode
+    m.zero_grad(set_to_none=True)
+    loss_of(m, x[rank * 2:rank * 2 + 2], y[rank * 2:rank * 2 + 2]).backward()
+    n = avg.finish() if avg is not None else average_gradients(list(m.parameters()), bucket_bytes=1024)
+    assert n >= 2, n
+    for (name, p), q in zip(m.named_parameters(), ref.parameters()):
+        if q.grad is None:
+            assert p.grad is None, name
+        else:
+            assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-7), (mode, name, (p.grad - q.grad).abs().max())
+print("rank %d ddp ok" % rank)
+dist.destroy_process_group()
+"""
+
+
+def test_gradient_averaging_world2_gloo(tmp_path):
+    """N>1 training path: per-rank half batches + bucketed all-reduce (after backward, and overlapped with backward through
+    grad hooks) reproduce the single-process whole-batch gradient, including a parameter that gets no gradient"""
+    script = tmp_path / "ddp_worker.py"
+    script.write_text(_DDP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        procs.append(subprocess.Popen([sys.executable, str(script), os.path.join(ROOT, "deep-active-semantic-segmentation_amd")],
+                                      env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "rank 0 ddp ok" in outs[0] and "rank 1 ddp ok" in outs[1]
