@@ -515,34 +515,66 @@ void conv_igemm_kernel(const ConvP p) {
         }
     }
 
-    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // ---- epilogue.  Accumulators sit in the MFMA C/D layout (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)): stored
+    // from there a lane would write single dwords (16 store instructions per 32x32 block).  Each wave instead bounces its
+    // block through a private LDS patch and re-reads it row-major, so every lane moves 16 contiguous bytes: 4x fewer
+    // store (and residual load) instructions, full 128-B lines per 8 lanes.
     T *y = reinterpret_cast<T *>(p.y);
     const T *res = reinterpret_cast<const T *>(p.res);
+    constexpr int PBLK = (NT >= 2 && 4 * 32 * 68 * 4 <= (int)sizeof(smem)) ? 2 : 1;  // 32-column blocks per pass
+    constexpr int PW = PBLK * 32, PITCH = PW + 4, C4 = PW / 4;
+    static_assert(4 * 32 * PITCH * 4 <= (int)sizeof(smem), "epilogue patches must fit the staging buffers");
+    static_assert(NT % PBLK == 0, "column blocks per pass");
+    __syncthreads();  // every wave is out of the main loop / statistics block: the stage is free
+    float *patch = reinterpret_cast<float *>(smem) + wave * 32 * PITCH;
+    const bool vec_ok = ((p.ldy & 3) == 0) && ((p.K & 3) == 0) && (!res || (p.ldr & 3) == 0);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int k = n0 + wn * TNW + nt * 32 + (lane & 31);
-        if (k >= p.K) continue;
-        const float sc = p.scale ? p.scale[k] : 1.f;
-        const float sh = p.shift ? p.shift[k] : 0.f;
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+        for (int ntp = 0; ntp < NT; ntp += PBLK) {
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            for (int q = 0; q < PBLK; ++q)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                    patch[row * PITCH + q * 32 + (lane & 31)] = acc[mt][ntp + q][reg];
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int it = 0; it < (32 * C4) / 64; ++it) {
+                const int idx = it * 64 + lane;
+                const int row = idx / C4, c4 = idx - row * C4;
                 const int m = m0 + wm * TMW + mt * 32 + row;
-                if (m < p.M) {
-                    long mo = m;  // output pixel index; differs from m only for a phase sub-grid
-                    if (p.o_mul != 1) {
-                        const int n = m / ohw, rem = m - n * ohw;
-                        const int ohs = rem / p.OWs;
-                        mo = ((long)n * p.OH + ohs * p.o_mul + p.oy_add) * p.OW + (rem - ohs * p.OWs) * p.o_mul + p.ox_add;
+                const int k = n0 + wn * TNW + ntp * 32 + c4 * 4;
+                if (m >= p.M || k >= p.K) continue;
+                long mo = m;  // output pixel index; differs from m only for a phase sub-grid
+                if (p.o_mul != 1) {
+                    const int n = m / ohw, rem = m - n * ohw;
+                    const int ohs = rem / p.OWs;
+                    mo = ((long)n * p.OH + ohs * p.o_mul + p.oy_add) * p.OW + (rem - ohs * p.OWs) * p.o_mul + p.ox_add;
+                }
+                f32x4 v = *reinterpret_cast<const f32x4 *>(patch + row * PITCH + c4 * 4);
+                if (vec_ok) {
+                    if (p.scale) v *= *reinterpret_cast<const f32x4 *>(p.scale + k);
+                    if (p.shift) v += *reinterpret_cast<const f32x4 *>(p.shift + k);
+                    if (res) v += ld4<T>(res + mo * p.ldr + k);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+                    st4<T>(y + mo * p.ldy + k, v);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (k + e >= p.K) break;
+                        float u = v[e] * (p.scale ? p.scale[k + e] : 1.f) + (p.shift ? p.shift[k + e] : 0.f);
+                        if (res) u += Elem<T>::ld(res + mo * p.ldr + k + e);
+                        Elem<T>::st(y + mo * p.ldy + k + e, apply_act(u, p.act));
                     }
-                    float v = acc[mt][nt][reg] * sc + sh;
-                    if (res) v += Elem<T>::ld(res + mo * p.ldr + k);
-                    v = apply_act(v, p.act);
-                    Elem<T>::st(y + mo * p.ldy + k, v);
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // the patch is rewritten by the next pass
         }
     }
 }
