@@ -1226,7 +1226,16 @@ template <int SPLIT = 0> int dispatch_wgrad_bf16(WgradP &p, hipStream_t st) {
     if (p.K > 64 && p.C > 64 && force != 3) {
         const long b = base_of(128, 128);
         const long sp = wgrad_split(b, p.M, target, min_slabs);
-        if (b * sp >= 400 || force == 1) return launch_wgrad_bf16<128, 128, SPLIT>(p, st, sp);
+        bool big = b * sp >= 400;
+        if (big && SPLIT == 3 && force == 0) {
+            // every pixel split adds its whole tile set into dW with f32 atomics (~1.3 TB/s chip-wide): with many splits the
+            // big tile's better MFMA rate (measured ~125 vs ~103 TFLOP/s, tools/conv_sweep.py) is eaten by the atomic tail
+            const long sp64 = wgrad_split(base_of(64, 64), p.M, target, min_slabs);
+            const double flops = 2.0 * p.M * p.K * p.C * (double)rs, dwb = 4.0 * p.K * p.C * (double)rs;
+            const double t128 = flops / 125e12 + dwb * sp / 1.3e12, t64 = flops / 103e12 + dwb * sp64 / 1.3e12;
+            big = t128 <= t64;
+        }
+        if (big || force == 1) return launch_wgrad_bf16<128, 128, SPLIT>(p, st, sp);
     }
     return launch_wgrad_bf16<64, 64, SPLIT>(p, st, wgrad_split(base_of(64, 64), p.M, target, min_slabs));
 }
