@@ -54,6 +54,49 @@ class Decoder(nn.Module):
         h = ops.conv_bn_act(h, lc[3], lc[4], ops.ACT_RELU, nc_scale=mask)
         return ops.conv_bn_act(h, lc[7])
 
+    # ---- MC-dropout scoring: last_conv[0] split along its input channels.  Only the 256 upsampled-ASPP channels carry a
+    # Dropout2d mask; the 48 low-level channels' share of the 3x3 304->256 conv (16 % of it) is the same in every pass,
+    # so it is computed once per batch -- already multiplied by the eval-BN scale -- and enters each pass as the
+    # residual of the 256-channel conv's epilogue:  relu((Wa*(m.xa) + Wb*xb)*s + b) = relu(Wa*(m.xa)*s + b + (Wb*xb)*s).
+    def _split_first_conv(self):
+        conv = self.last_conv[0]
+        wt = conv.weight
+        key = (wt.data_ptr(), wt._version, ops.f32_mma())
+        hit = self.__dict__.get("_dass_split_w")
+        if hit is None or hit[0] != key:
+            krsc = wt.detach().float().permute(0, 2, 3, 1)
+            wa = ops.prepare_conv_weight(krsc[..., :256].contiguous())
+            wb = ops.prepare_conv_weight(krsc[..., 256:].contiguous())
+            hit = self.__dict__["_dass_split_w"] = (key, wa, wb)
+        return hit[1], hit[2]
+
+    def head_mc_prepare(self, feats):
+        """-> state for head_mc_pass: operands + eval-BN vectors + the deterministic low-level share (f32 tensors only)"""
+        import torch
+
+        n, c, h, w = feats.shape
+        assert c == 304 and feats.dtype == torch.float32
+        wa, wb = self._split_first_conv()
+        st = ops.bn_eval_state(self.last_conv[1], 256, feats.device)
+        xb, ldb = ops.rows(feats[:, 256:])
+        yb = ops.new_act(n, 256, h, w, torch.float32, feats.device)
+        ops.conv_launch(xb, ldb, wb, yb, 256, (n, h, w, 48, h, w, 256, 3, 3, 1, 1, 1), scale=st.scale)
+        return wa, st, yb
+
+    def head_mc_pass(self, feats, prep, m1, m2):
+        """one stochastic pass of last_conv: masks m1 (ASPP Dropout2d, [N,256]) and m2 (last_conv[6]) folded into loaders"""
+        import torch
+
+        wa, st, yb = prep
+        n, c, h, w = feats.shape
+        lc = self.last_conv
+        xa, lda = ops.rows(feats[:, :256])
+        h1 = ops.new_act(n, 256, h, w, torch.float32, feats.device)
+        ops.conv_launch(xa, lda, wa, h1, 256, (n, h, w, 256, h, w, 256, 3, 3, 1, 1, 1), scale=st.scale, shift=st.shift,
+                        residual=yb, ldr=256, in_scale=m1.contiguous(), act=ops.ACT_RELU)
+        h2 = ops.conv_bn_act(h1, lc[3], lc[4], ops.ACT_RELU)
+        return ops.conv_bn_act(h2, lc[7], in_scale=m2)
+
     @ops.bn_counter_scope
     def forward(self, x, low_level_feat, dropout_mask=None):
         second_to_last_features = self.features(x, low_level_feat)

@@ -104,13 +104,18 @@ class DeepLab(nn.Module):
         p1, p2 = self.aspp.dropout.p, self.decoder.last_conv[6].p
         votes = torch.empty((n, steps, hh, ww), dtype=torch.uint8, device=dev)
         ones48 = torch.ones((n, 48), dtype=torch.float32, device=dev)
+        # f32 tensors: the unmasked low-level channels' share of last_conv[0] is hoisted out of the T passes as well
+        prep = self.decoder.head_mc_prepare(feats) if feats.dtype == torch.float32 and feats.shape[1] == 304 else None
         for t in range(steps):
             if masks is not None:
                 m1, m2 = masks[0][t].to(dev).float(), masks[1][t].to(dev).float()
             else:
                 m1 = ops.dropout2d_mask(n, 256, p1, dev, generator)
                 m2 = ops.dropout2d_mask(n, 256, p2, dev, generator)
-            low_res = self.decoder.head(feats, in_scale=torch.cat((m1, ones48), dim=1), mask_as_in_scale=m2)
+            if prep is not None:
+                low_res = self.decoder.head_mc_pass(feats, prep, m1, m2)
+            else:
+                low_res = self.decoder.head(feats, in_scale=torch.cat((m1, ones48), dim=1), mask_as_in_scale=m2)
             ops.upsample_argmax(low_res, hh, ww, votes, t)
         return votes
 
