@@ -12,7 +12,12 @@ torch.manual_seed(0)
 m = DeepLab(backbone="resnet101", output_stride=16, num_classes=19, sync_bn=False, freeze_bn=False, pretrained=False).cuda().train()
 crit = SegmentationLosses(cuda=True).build_loss("ce")
 opt = torch.optim.SGD([{"params": m.get_1x_lr_params(), "lr": 0.01}, {"params": m.get_10x_lr_params(), "lr": 0.1}], momentum=0.9, weight_decay=5e-4)
-x = torch.randn(8, 3, 513, 513, device="cuda"); y = torch.randint(0, 19, (8, 513, 513), device="cuda").float()
+x = torch.randn(8, 3, 513, 513, device="cuda")
+if "--learnable" in sys.argv:   # a target the net can fit: 19 vertical bands, brightened in the image
+    y = (torch.arange(513, device="cuda") * 19 // 513).float().view(1, 1, 513).expand(8, 513, 513).contiguous()
+    x = x * 0.3 + (y / 9.0 - 1.0).unsqueeze(1)
+else:
+    y = torch.randint(0, 19, (8, 513, 513), device="cuda").float()
 for i in range(60):
     opt.zero_grad(set_to_none=True)
     loss = crit(m(x), y); loss.backward(); opt.step()
