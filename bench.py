@@ -110,9 +110,12 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
                     freeze_bn=False, pretrained=False).to(dev)
     criterion = SegmentationLosses(cuda=True).build_loss("ce")
     lr = 0.01
-    optimizer = torch.optim.SGD([{"params": model.get_1x_lr_params(), "lr": lr},
-                                 {"params": model.get_10x_lr_params(), "lr": lr * 10}],
-                                momentum=0.9, weight_decay=5e-4, nesterov=False)
+    from dass_hip.optim import SGD  # torch.optim.SGD surface and state, update arithmetic in dass_sgd_step_multi
+
+    if os.environ.get("DASS_TORCH_SGD", "0") == "1":  # A/B knob: the stock foreach implementation
+        SGD = torch.optim.SGD
+    optimizer = SGD([{"params": model.get_1x_lr_params(), "lr": lr}, {"params": model.get_10x_lr_params(), "lr": lr * 10}],
+                    momentum=0.9, weight_decay=5e-4, nesterov=False)
     params = [p for g in optimizer.param_groups for p in g["params"]]
     b, s = args.batch, args.size
     image, target = synthetic_batch(b, s, s, args.classes, first_index=rank * b)

@@ -456,6 +456,53 @@ __global__ void sgd_kernel(float *__restrict__ p, const float *__restrict__ g, f
     }
 }
 
+// every parameter tensor of one optimizer step in a handful of launches: up to 64 tensors per launch travel in the kernel
+// argument itself (no device-side table, no host->device copy); a block owns 2048 consecutive elements of one tensor
+constexpr int SGD_PACK = 64, SGD_BLK = 2048;
+struct SgdPack {
+    float *p[SGD_PACK];
+    const float *g[SGD_PACK];
+    float *b[SGD_PACK];
+    long first_block[SGD_PACK + 1];
+    long numel[SGD_PACK];
+    float lr[SGD_PACK];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdPack pk, float momentum, float wd) {
+    const long blk = blockIdx.x;
+    int lo = 0, hi = pk.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (pk.first_block[mid] <= blk) lo = mid; else hi = mid - 1;
+    }
+    float *__restrict__ p = pk.p[lo];
+    const float *__restrict__ g = pk.g[lo];
+    float *__restrict__ b = pk.b[lo];
+    const float lr = pk.lr[lo];
+    const long n = pk.numel[lo];
+    const long e0 = (blk - pk.first_block[lo]) * SGD_BLK;
+    const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)b) & 15) == 0) && e0 + SGD_BLK <= n;
+    if (vec) {
+#pragma unroll
+        for (int r = 0; r < SGD_BLK / 1024; ++r) {
+            const long i = e0 + r * 1024 + threadIdx.x * 4;
+            f32x4 pv = *reinterpret_cast<const f32x4 *>(p + i);
+            const f32x4 gv = *reinterpret_cast<const f32x4 *>(g + i) + wd * pv;
+            const f32x4 bv = momentum * *reinterpret_cast<const f32x4 *>(b + i) + gv;
+            *reinterpret_cast<f32x4 *>(b + i) = bv;
+            *reinterpret_cast<f32x4 *>(p + i) = pv - lr * bv;
+        }
+    } else {
+        for (long i = e0 + threadIdx.x; i < n && i < e0 + SGD_BLK; i += 256) {
+            const float gi = g[i] + wd * p[i];
+            const float bi = momentum * b[i] + gi;
+            b[i] = bi;
+            p[i] = p[i] - lr * bi;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int dass_ce_blocks(int64_t npix) { return dass_grid_1d(npix, 256); }
@@ -605,6 +652,30 @@ extern "C" int dass_sgd_step(float *p, const float *g, float *buf, int64_t n, fl
     hipLaunchKernelGGL(sgd_kernel, dim3(dass_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, buf, (long)n, lr,
                        momentum, weight_decay, first_step);
     DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_sgd_step_multi(void *const *p, const void *const *g, void *const *buf, const int64_t *numel, const float *lr,
+                                   int n, float momentum, float weight_decay, void *stream) {
+    if (!p || !g || !buf || !numel || !lr || n <= 0) return DASS_ERR_ARG;
+    for (int base = 0; base < n; base += SGD_PACK) {
+        SgdPack pk;
+        pk.n = n - base < SGD_PACK ? n - base : SGD_PACK;
+        long blocks = 0;
+        for (int i = 0; i < pk.n; ++i) {
+            if (!p[base + i] || !g[base + i] || !buf[base + i] || numel[base + i] <= 0) return DASS_ERR_ARG;
+            pk.p[i] = (float *)p[base + i];
+            pk.g[i] = (const float *)g[base + i];
+            pk.b[i] = (float *)buf[base + i];
+            pk.numel[i] = numel[base + i];
+            pk.lr[i] = lr[base + i];
+            pk.first_block[i] = blocks;
+            blocks += (numel[base + i] + SGD_BLK - 1) / SGD_BLK;
+        }
+        pk.first_block[pk.n] = blocks;
+        hipLaunchKernelGGL(sgd_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pk, momentum, weight_decay);
+        DASS_LAUNCH_CHECK();
+    }
     return DASS_OK;
 }
 

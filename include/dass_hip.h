@@ -279,6 +279,11 @@ int dass_confusion_accumulate(const float *logits, const uint8_t *pred, const fl
  * (torch.optim.SGD as built at active_train.py:60): g += wd*p; buf = mom*buf + g; p -= lr*buf */
 int dass_sgd_step(float *p, const float *g, float *buf, int64_t n, float lr, float momentum,
                   float weight_decay, int first_step, void *stream);
+/* the same update for n tensors at once (the whole optimizer step: active_train.py:60-66 builds one SGD over two lr
+ * groups).  p, g, buf, numel, lr are HOST arrays of n device pointers / sizes / learning rates; tensors travel 64 per
+ * launch inside the kernel argument.  A momentum buffer that starts at zero reproduces torch's first-step copy. */
+int dass_sgd_step_multi(void *const *p, const void *const *g, void *const *buf, const int64_t *numel, const float *lr,
+                        int n, float momentum, float weight_decay, void *stream);
 
 #ifdef __cplusplus
 }

@@ -506,3 +506,35 @@ def test_weight_split_operand_is_exact():
         err = (recon - ref).abs()
         assert (err <= ref.abs() * 2.0 ** -24).all(), err.max()
         assert (recon[..., red:] == 0).all()
+
+
+def test_sgd_multi_matches_torch_sgd():
+    """dass_hip.optim.SGD (one multi-tensor kernel) against torch.optim.SGD over three steps: two lr groups, momentum,
+    weight decay, channels_last conv weights, tensors that are not a multiple of the 2048-element blocks, a parameter
+    without gradient, and state_dict interchange with the stock optimizer."""
+    _ops()
+    from dass_hip.optim import SGD
+
+    def make():
+        torch.manual_seed(4)
+        ws = [torch.randn(40, 36, 3, 3).cuda().contiguous(memory_format=torch.channels_last), torch.randn(5000).cuda(), torch.randn(7).cuda(),
+              torch.randn(64, 64, 1, 1).cuda().contiguous(memory_format=torch.channels_last), torch.randn(3).cuda()]
+        return [torch.nn.Parameter(w) for w in ws]
+
+    pa, pb = make(), make()
+    oa = torch.optim.SGD([{"params": pa[:2], "lr": 0.01}, {"params": pa[2:], "lr": 0.1}], momentum=0.9, weight_decay=5e-4)
+    ob = SGD([{"params": pb[:2], "lr": 0.01}, {"params": pb[2:], "lr": 0.1}], momentum=0.9, weight_decay=5e-4)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    for step in range(3):
+        for a, b in zip(pa[:4], pb[:4]):  # the last parameter never gets a gradient
+            gr = torch.randn(a.shape, device="cuda", generator=g).contiguous(memory_format=torch.channels_last if a.dim() == 4 else torch.contiguous_format)
+            a.grad, b.grad = gr.clone(memory_format=torch.preserve_format), gr.clone(memory_format=torch.preserve_format)
+        oa.step()
+        ob.step()
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            assert (a - b).abs().max().item() <= 2e-6 * max(1.0, a.abs().max().item()), (step, i)
+    assert all("momentum_buffer" in ob.state[q] for q in pb[:4])
+    sd = ob.state_dict()
+    oc = torch.optim.SGD([{"params": pa[:2], "lr": 0.01}, {"params": pa[2:], "lr": 0.1}], momentum=0.9, weight_decay=5e-4)
+    oc.load_state_dict(sd)  # same format as the stock optimizer's
+    assert torch.allclose(oc.state[pa[0]]["momentum_buffer"], ob.state[pb[0]]["momentum_buffer"])
