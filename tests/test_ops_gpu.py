@@ -538,3 +538,18 @@ def test_sgd_multi_matches_torch_sgd():
     oc = torch.optim.SGD([{"params": pa[:2], "lr": 0.01}, {"params": pa[2:], "lr": 0.1}], momentum=0.9, weight_decay=5e-4)
     oc.load_state_dict(sd)  # same format as the stock optimizer's
     assert torch.allclose(oc.state[pa[0]]["momentum_buffer"], ob.state[pb[0]]["momentum_buffer"])
+
+
+def test_conv_fuzz_random_shapes():
+    """tools/conv_fuzz.py: 60 random (channels, size, kernel, stride, padding, dilation) x (BN train/eval, bias, residual,
+    activation) cases in both parity engines against an f64 torch reference -- forward within 2e-5 rel-L2, every
+    gradient within the ReLU-kink scale"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "conv_fuzz.py"), "60", "3"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "CASE" not in out.stdout, out.stdout[-3000:]
+    assert "worst rel-L2" in out.stdout
