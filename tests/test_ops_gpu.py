@@ -553,3 +553,34 @@ def test_conv_fuzz_random_shapes():
     assert out.returncode == 0, out.stderr[-2000:]
     assert "CASE" not in out.stdout, out.stdout[-3000:]
     assert "worst rel-L2" in out.stdout
+
+
+def test_scoring_kernels_random_sizes():
+    """vote entropy and the three CEAL softmax scores on 12 random (N, T, C, H, W) against the oracle's reductions: ragged
+    sizes (non-multiples of every block dimension), T up to 40, C up to 60, ignore labels, single-pixel rows"""
+    import random
+
+    from oracle import selection_cpu as S
+
+    ops = _ops()
+    rng = random.Random(5)
+    for case in range(12):
+        n, t, c = rng.randint(1, 3), rng.choice([1, 2, 7, 10, 20, 40]), rng.choice([2, 4, 19, 21, 60])
+        h, w = rng.choice([1, 3, 17, 64, 129]), rng.choice([1, 5, 33, 100, 257])
+        g = torch.Generator().manual_seed(100 + case)
+        votes = torch.randint(0, c, (n, t, h, w), generator=g).to(torch.uint8)
+        label = torch.randint(0, c, (n, h, w), generator=g).float()
+        label[torch.rand(n, h, w, generator=g) < 0.1] = 255
+        emap, mean = ops.vote_entropy(votes.cuda(), label.cuda(), c)
+        ref = S.vote_entropy_maps(votes.long(), label, c)
+        ref = torch.stack([torch.as_tensor(r) for r in ref]).float() if not torch.is_tensor(ref) else ref.float()
+        assert (emap.cpu() - ref).abs().max().item() <= 2e-5, (case, n, t, c, h, w)
+        assert (mean.cpu() - ref.mean(dim=(1, 2))).abs().max().item() <= 2e-5
+        logits = torch.randn(n, c, h, w, generator=g) * 3
+        maps = S.softmax_score_maps(logits, label, c)
+        for mode in range(3):
+            smap, smean = ops.softmax_scores(logits.cuda(), label.cuda(), c, mode, want_map=True)
+            r = maps[mode] if isinstance(maps, (list, tuple)) else maps[:, mode]
+            r = torch.as_tensor(r).float()
+            assert (smap.cpu() - r).abs().max().item() <= 3e-5, (case, mode, n, t, c, h, w)
+            assert (smean.cpu() - r.mean(dim=(1, 2))).abs().max().item() <= 3e-5
