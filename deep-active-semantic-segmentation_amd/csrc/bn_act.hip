@@ -9,6 +9,14 @@ namespace {
 
 constexpr int SLAB = 128;  // pixel rows per partial-statistics row
 
+// the BN affine exactly as the forward applies it (one fma per element): forward and backward gates must agree bit for bit
+__device__ __forceinline__ f32x4 bn_affine(f32x4 v, f32x4 sc, f32x4 sh) {
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(v[e], sc[e], sh[e]);
+    return r;
+}
+
 // partial[slab][0][k] = sum f0, partial[slab][1][k] = sum f1 over the slab's rows.
 // MODE 0: f0 = x, f1 = x*x ; MODE 1: f0 = dact, f1 = dact*xhat
 template <typename T, int MODE>
@@ -16,7 +24,9 @@ __global__ __launch_bounds__(256) void colstat_kernel(const T *__restrict__ x, l
                                                       long lddo, const T *__restrict__ out, long ldo,
                                                       const float *__restrict__ mean, const float *__restrict__ invstd,
                                                       const float *__restrict__ nc_scale, long M, int K,
-                                                      long rows_per_image, int act, float *__restrict__ partial) {
+                                                      long rows_per_image, int act, float *__restrict__ partial,
+                                                      const float *__restrict__ gate_scale = nullptr,
+                                                      const float *__restrict__ gate_shift = nullptr) {
     __shared__ float red[2][16][64 + 1];
     const int tid = threadIdx.x;
     const int cx = tid & 15, ry = tid >> 4;
@@ -26,10 +36,14 @@ __global__ __launch_bounds__(256) void colstat_kernel(const T *__restrict__ x, l
     if (r1 > M) r1 = M;
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
     if (k < K) {
-        f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f};
+        f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f}, gsc = is, gsh = mu;
         if (MODE == 1) {
             mu = *reinterpret_cast<const f32x4 *>(mean + k);
             is = *reinterpret_cast<const f32x4 *>(invstd + k);
+            if (!out) {
+                gsc = *reinterpret_cast<const f32x4 *>(gate_scale + k);
+                gsh = *reinterpret_cast<const f32x4 *>(gate_shift + k);
+            }
         }
         for (long r = r0 + ry; r < r1; r += 16) {
             const f32x4 xv = ld4<T>(x + r * ldx + k);
@@ -38,7 +52,9 @@ __global__ __launch_bounds__(256) void colstat_kernel(const T *__restrict__ x, l
                 s1 += xv * xv;
             } else {
                 f32x4 g = ld4<T>(dout + r * lddo + k);
-                const f32x4 o = ld4<T>(out + r * ldo + k);
+                // activation gate from the stored output, or -- no residual, f32 -- re-derived from the conv output with
+                // the forward's own fma (bit-identical pre-activation), which saves reading `out`
+                const f32x4 o = out ? ld4<T>(out + r * ldo + k) : bn_affine(xv, gsc, gsh);
                 if (nc_scale) g *= *reinterpret_cast<const f32x4 *>(nc_scale + (r / rows_per_image) * K + k);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] *= act_grad_from_out(o[e], act);
@@ -157,8 +173,12 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const T *__restric
         }
         const int k = kq << 2;
         f32x4 v = ld4<T>(x + m * ldx + k);
-        if (scale) v *= *reinterpret_cast<const f32x4 *>(scale + k);
-        if (shift) v += *reinterpret_cast<const f32x4 *>(shift + k);
+        if (scale && shift) {
+            v = bn_affine(v, *reinterpret_cast<const f32x4 *>(scale + k), *reinterpret_cast<const f32x4 *>(shift + k));
+        } else {
+            if (scale) v *= *reinterpret_cast<const f32x4 *>(scale + k);
+            if (shift) v += *reinterpret_cast<const f32x4 *>(shift + k);
+        }
         if (res) v += ld4<T>(res + m * ldr + k);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
@@ -178,7 +198,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
                                                            const float *__restrict__ dgamma,
                                                            const float *__restrict__ nc_scale, T *__restrict__ dx,
                                                            long lddx, T *__restrict__ dres, long lddr, long M, int K,
-                                                           long rows_per_image, float inv_count, int train, int act) {
+                                                           long rows_per_image, float inv_count, int train, int act,
+                                                           const float *__restrict__ gate_scale = nullptr,
+                                                           const float *__restrict__ gate_shift = nullptr) {
     const int kv = K >> 2;
     const long stride = (long)gridDim.x * blockDim.x;
     const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -193,7 +215,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
         }
         const int k = kq << 2;
         f32x4 g = ld4<T>(dout + m * lddo + k);
-        const f32x4 o = ld4<T>(out + m * ldo + k);
+        f32x4 xin = {0.f, 0.f, 0.f, 0.f};
+        if (!out || (dx && train)) xin = ld4<T>(x + m * ldx + k);
+        const f32x4 o = out ? ld4<T>(out + m * ldo + k)
+                            : bn_affine(xin, *reinterpret_cast<const f32x4 *>(gate_scale + k), *reinterpret_cast<const f32x4 *>(gate_shift + k));
         if (nc_scale) g *= *reinterpret_cast<const f32x4 *>(nc_scale + (m / rows_per_image) * K + k);
 #pragma unroll
         for (int e = 0; e < 4; ++e) g[e] *= act_grad_from_out(o[e], act);
@@ -205,7 +230,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
             f32x4 r = g;
             if (train) {
                 const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + k);
-                const f32x4 xh = (ld4<T>(x + m * ldx + k) - mu) * is;
+                const f32x4 xh = (xin - mu) * is;
                 const f32x4 db = *reinterpret_cast<const f32x4 *>(dbeta + k);
                 const f32x4 dg = *reinterpret_cast<const f32x4 *>(dgamma + k);
                 r = g - (db + xh * dg) * inv_count;
@@ -299,6 +324,37 @@ extern "C" int dass_bn_bwd_reduce(const void *dout, int64_t lddo, const void *ou
                            rows_per_image, act, partial);
     else
         return DASS_ERR_UNSUPPORTED;
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_bn_bwd_reduce_gate(const void *dout, int64_t lddo, const void *x, int64_t ldx, const float *mean,
+                                       const float *invstd, const float *gate_scale, const float *gate_shift,
+                                       const float *nc_scale, int64_t M, int K, int64_t rows_per_image, int act, float *partial,
+                                       int dtype, void *stream) {
+    if (!dout || !x || !mean || !invstd || !gate_scale || !gate_shift || !partial || M <= 0 || !ok4(K, lddo, ldx) || rows_per_image <= 0)
+        return DASS_ERR_ARG;
+    if (dtype != DASS_F32) return DASS_ERR_UNSUPPORTED;  // a bf16 `out` is rounded: its gate is not the f32 pre-activation's
+    dim3 grid((unsigned)dass_stat_rows(M), (unsigned)((K + 63) / 64));
+    hipLaunchKernelGGL((colstat_kernel<float, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const float *)x, ldx, (const float *)dout, lddo,
+                       (const float *)nullptr, 0, mean, invstd, nc_scale, M, K, rows_per_image, act, partial, gate_scale, gate_shift);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_bn_bwd_apply_gate(const void *dout, int64_t lddo, const void *x, int64_t ldx, const float *mean, const float *invstd,
+                                      const float *gamma, const float *dbeta, const float *dgamma, const float *gate_scale,
+                                      const float *gate_shift, const float *nc_scale, void *dx, int64_t lddx, int64_t M, int K,
+                                      int64_t rows_per_image, double count, int train, int act, int dtype, void *stream) {
+    if (!dout || !x || !dx || !invstd || !gate_scale || !gate_shift || M <= 0 || !ok4(K, lddo, ldx, lddx) || rows_per_image <= 0)
+        return DASS_ERR_ARG;
+    if (train && (!mean || !dbeta || !dgamma || count <= 0)) return DASS_ERR_ARG;
+    if (dtype != DASS_F32) return DASS_ERR_UNSUPPORTED;
+    const int grid = dass_grid_1d(M * (K / 4), 256);
+    const float inv_count = train ? (float)(1.0 / count) : 0.f;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float *)dout, lddo, (const float *)nullptr, 0,
+                       (const float *)x, ldx, mean, invstd, gamma, dbeta, dgamma, nc_scale, (float *)dx, lddx, (float *)nullptr, 0, M, K,
+                       rows_per_image, inv_count, train, act, gate_scale, gate_shift);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }

@@ -505,12 +505,14 @@ class _ConvBnAct(torch.autograd.Function):
             ctx.x_dtype = x.dtype
             ctx.save_for_backward(xs, weight, gamma, y_raw, out, nc_scale,
                                   state.mean if state is not None else None,
-                                  state.invstd if state is not None else None)
+                                  state.invstd if state is not None else None,
+                                  state.scale if state is not None else None,
+                                  state.shift if state is not None else None)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        xs, weight, gamma, y_raw, out, nc_scale, mean, invstd = ctx.saved_tensors
+        xs, weight, gamma, y_raw, out, nc_scale, mean, invstd, bn_scale, bn_shift = ctx.saved_tensors
         spec = ctx.spec
         n, h, w, c, oh, ow, k, ldx, ldo, c_in = ctx.dims
         dt = out.dtype
@@ -548,12 +550,21 @@ class _ConvBnAct(torch.autograd.Function):
                 mean_v, invstd_v, gamma_v = mean, invstd, gamma
             db = dg = None
             need_red = ctx.has_bn or ctx.has_bias
+            # no residual, f32, conv output kept: the ReLU gate is re-derived from y_raw with the forward's own fma
+            # (bit-identical), so neither pass reads `out`
+            gate = (ctx.has_bn and not ctx.has_res and y_raw is not None and dt == torch.float32 and bn_scale is not None
+                    and spec.act != ACT_NONE)
             if need_red:
                 nrows = lib.dass_stat_rows(m)
                 partial = torch.empty((nrows, 2, k), dtype=torch.float32, device=dev)
-                check(lib.dass_bn_bwd_reduce(_p(dout_r), lddo, _p(out), ldo, _p(src), k, _p(mean_v), _p(invstd_v),
-                                             _p(nc_scale), m, k, oh * ow, spec.act, _p(partial), _dt(out), _stream()),
-                      "dass_bn_bwd_reduce")
+                if gate:
+                    check(lib.dass_bn_bwd_reduce_gate(_p(dout_r), lddo, _p(y_raw), k, _p(mean_v), _p(invstd_v), _p(bn_scale), _p(bn_shift),
+                                                      _p(nc_scale), m, k, oh * ow, spec.act, _p(partial), _dt(out), _stream()),
+                          "dass_bn_bwd_reduce_gate")
+                else:
+                    check(lib.dass_bn_bwd_reduce(_p(dout_r), lddo, _p(out), ldo, _p(src), k, _p(mean_v), _p(invstd_v),
+                                                 _p(nc_scale), m, k, oh * ow, spec.act, _p(partial), _dt(out), _stream()),
+                          "dass_bn_bwd_reduce")
                 sums = torch.empty((2, k), dtype=torch.float32, device=dev)
                 db, dg = sums[0], sums[1]
                 check(lib.dass_bn_bwd_finalize(_p(partial), nrows, k, _p(db), _p(dg), _stream()), "dass_bn_bwd_finalize")
@@ -563,11 +574,16 @@ class _ConvBnAct(torch.autograd.Function):
                     dbeta, dgamma = db, dg
                 else:
                     dbias = db
-            check(lib.dass_bn_bwd_apply(_p(dout_r), lddo, _p(out), ldo, _p(src), k, _p(mean_v), _p(invstd_v),
-                                        _p(gamma_v.detach() if gamma_v is not None else None), _p(db), _p(dg),
-                                        _p(nc_scale), _p(dy), lddy, _p(dres), k, m, k, oh * ow, float(m) * ctx.sync_world,
-                                        1 if ctx.train_stats else 0, spec.act, _dt(out), _stream()), "dass_bn_bwd_apply")
-        # ---- conv backward
+            if gate:
+                check(lib.dass_bn_bwd_apply_gate(_p(dout_r), lddo, _p(y_raw), k, _p(mean_v), _p(invstd_v), _p(gamma_v.detach()), _p(db), _p(dg),
+                                                 _p(bn_scale), _p(bn_shift), _p(nc_scale), _p(dy), lddy, m, k, oh * ow,
+                                                 float(m) * ctx.sync_world, 1 if ctx.train_stats else 0, spec.act, _dt(out), _stream()),
+                      "dass_bn_bwd_apply_gate")
+            else:
+                check(lib.dass_bn_bwd_apply(_p(dout_r), lddo, _p(out), ldo, _p(src), k, _p(mean_v), _p(invstd_v),
+                                            _p(gamma_v.detach() if gamma_v is not None else None), _p(db), _p(dg),
+                                            _p(nc_scale), _p(dy), lddy, _p(dres), k, m, k, oh * ow, float(m) * ctx.sync_world,
+                                            1 if ctx.train_stats else 0, spec.act, _dt(out), _stream()), "dass_bn_bwd_apply")
         dx = dw = None
         kk = kp if simple else k
         if spec.depthwise:

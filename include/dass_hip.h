@@ -170,6 +170,18 @@ int dass_bn_bwd_apply(const void *dout, int64_t lddo, const void *out, int64_t l
                       const float *nc_scale, void *dx, int64_t lddx, void *dres, int64_t lddr,
                       int64_t M, int K, int64_t rows_per_image, double count, int train,
                       int act, int dtype, void *stream);
+/* the two passes for a layer WITHOUT residual, f32: the activation gate is re-derived from the conv output as
+ * act'(fma(x, gate_scale, gate_shift)) -- the forward's own affine (dass_scale_shift_act applies exactly this fma), so the
+ * gate is bit-identical to the one of the stored output and `out` is not read (one HBM pass less in each). */
+int dass_bn_bwd_reduce_gate(const void *dout, int64_t lddo, const void *x, int64_t ldx,
+                            const float *mean, const float *invstd, const float *gate_scale, const float *gate_shift,
+                            const float *nc_scale, int64_t M, int K, int64_t rows_per_image,
+                            int act, float *partial, int dtype, void *stream);
+int dass_bn_bwd_apply_gate(const void *dout, int64_t lddo, const void *x, int64_t ldx,
+                           const float *mean, const float *invstd, const float *gamma, const float *dbeta, const float *dgamma,
+                           const float *gate_scale, const float *gate_shift, const float *nc_scale,
+                           void *dx, int64_t lddx, int64_t M, int K, int64_t rows_per_image, double count, int train,
+                           int act, int dtype, void *stream);
 /* column sums only: out[k] = sum_m x[m,k] (bias gradient of decoder.last_conv.7) */
 int dass_colsum(const void *x, int64_t ldx, int64_t M, int K, float *partial, float *out, int dtype, void *stream);
 
