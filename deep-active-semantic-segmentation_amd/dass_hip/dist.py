@@ -19,11 +19,68 @@ class ModuleWrapper(torch.nn.Module):
         return self.module(*args, **kwargs)
 
 
+def world_size():
+    import torch.distributed as dist
+
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class _SumOverRanks(torch.autograd.Function):
+    """y = sum over ranks of x (one all-reduce).  The true derivative dy/dx_r is 1; this backward returns
+    world * g because the gradients of every rank are AVERAGED afterwards (GradientAverager / average_gradients /
+    torch DDP all divide the all-reduced sum by world): (1/world) * sum_r J_r^T (world * g) = sum_r J_r^T g, the
+    single-process gradient."""
+
+    @staticmethod
+    def forward(ctx, x):
+        import torch.distributed as dist
+
+        y = x.detach().clone()
+        dist.all_reduce(y)
+        ctx.world = dist.get_world_size()
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.world
+
+
+def sum_over_ranks(x, differentiable=True):
+    """x summed over all ranks (identity without a process group).  differentiable=True: see _SumOverRanks."""
+    if world_size() == 1:
+        return x
+    if differentiable and x.requires_grad:
+        return _SumOverRanks.apply(x)
+    import torch.distributed as dist
+
+    y = x.detach().clone()
+    dist.all_reduce(y)
+    return y
+
+
+def global_batch_mean(local_sum, local_count, n_local):
+    """The reference computes its loss on device 0 over the GATHERED global batch (nn.DataParallel,
+    active_train.py:104-105): nn.CrossEntropyLoss(reduction='mean') over every valid pixel of every replica's
+    images, then `/ n` with n the GLOBAL batch size (utils/loss.py:39-51).  One process per GPU reproduces it from
+    each rank's numerator (sum of w*nll over its valid pixels), denominator (sum of w over them) and image count:
+    one all-reduce of three floats.  -> (mean over the global batch [same value on every rank; autograd],
+    global batch size).  Ranks may hold different numbers of valid pixels and of images."""
+    if world_size() == 1:
+        return local_sum / local_count, n_local
+    packed = torch.stack((local_count.detach().float().reshape(()),
+                          torch.as_tensor(float(n_local), dtype=torch.float32, device=local_sum.device)))
+    tot = sum_over_ranks(packed, differentiable=False)
+    total_sum = sum_over_ranks(local_sum)
+    return total_sum / tot[0], int(round(float(tot[1])))
+
+
 def average_gradients(params, bucket_bytes=64 << 20):
     """DDP-style gradient averaging after backward: gradients are packed into flat f32 buckets, every bucket is one
     asynchronous all-reduce (they pipeline on the RCCL stream), and the averaged values are scattered back in place.
-    Returns the number of buckets.  With per-GPU batches of equal size this reproduces the single-process gradient
-    of the reference's DataParallel step (loss averaged over the global batch)."""
+    Returns the number of buckets.  The average over ranks equals the reference's single-process DataParallel gradient
+    when the loss is the global-batch loss of utils.loss.SegmentationLosses (global_batch_mean above: numerators,
+    valid-pixel counts and batch sizes are exchanged, and its backward pre-multiplies by world).  Parameters without a
+    gradient on this rank contribute zeros, so bucket sizes never depend on which parameters fired."""
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -35,27 +92,49 @@ def average_gradients(params, bucket_bytes=64 << 20):
     def flush():
         nonlocal bucket, size
         if bucket:
-            flat = torch.cat([p.grad.reshape(-1) for p in bucket])
+            flat = _pack(bucket)
             works.append((dist.all_reduce(flat, async_op=True), flat, bucket))
             bucket, size = [], 0
 
     for p in params:
-        if p.grad is None:
+        if not p.requires_grad:
             continue
         bucket.append(p)
-        size += p.grad.numel()
+        size += p.numel()
         if size >= cap:
             flush()
     flush()
     for work, flat, ps in works:
         work.wait()
         flat.div_(world)
-        off = 0
-        for p in ps:
-            n = p.grad.numel()
-            p.grad.copy_(flat[off:off + n].view_as(p.grad))
-            off += n
+        _unpack(flat, ps)
     return len(works)
+
+
+def _pack(ps):
+    """flat f32 bucket of the gradients of ps, in order, followed by one "fired" flag per parameter.  A parameter that
+    received no gradient on this rank rides as zeros with flag 0, so every rank packs the same number of elements
+    whichever parameters fired locally (data-dependent branches, set_to_none=True)."""
+    dev = ps[0].device
+    parts = [(p.grad.reshape(-1).float() if p.grad is not None else torch.zeros((p.numel(),), dtype=torch.float32, device=dev))
+             for p in ps]
+    parts.append(torch.tensor([0.0 if p.grad is None else 1.0 for p in ps], dtype=torch.float32, device=dev))
+    return torch.cat(parts)
+
+
+def _unpack(flat, ps):
+    """flat: the all-reduced bucket already divided by world.  A parameter that fired on NO rank keeps grad None (the
+    optimizer skips it, as in the single-process step); one that fired elsewhere only receives the average."""
+    # the flags are read back (a device sync) only when some local gradient is missing: the common step never waits
+    fired = flat[flat.numel() - len(ps):].tolist() if any(p.grad is None for p in ps) else [1.0] * len(ps)
+    off = 0
+    for p, f in zip(ps, fired):
+        k = p.numel()
+        if p.grad is not None:
+            p.grad.copy_(flat[off:off + k].view_as(p.grad))
+        elif f > 0.0:
+            p.grad = flat[off:off + k].view_as(p).clone()
+        off += k
 
 
 class GradientAverager(object):
@@ -112,11 +191,8 @@ class GradientAverager(object):
             self.next += 1
 
     def _launch(self, bi):
-        ps = [p for p in self.buckets[bi] if p.grad is not None]
-        if not ps:
-            self.works.append(None)
-            return
-        flat = torch.cat([p.grad.reshape(-1).float() for p in ps])
+        ps = self.buckets[bi]
+        flat = _pack(ps)  # rank-invariant size: missing gradients ride as zeros
         self.works.append((self.dist.all_reduce(flat, async_op=True), flat, ps))
 
     def finish(self):
@@ -128,17 +204,10 @@ class GradientAverager(object):
             self._launch(self.next)
             self.next += 1
         n = 0
-        for item in self.works:
-            if item is None:
-                continue
-            work, flat, ps = item
+        for work, flat, ps in self.works:
             work.wait()
             flat.div_(self.world)
-            off = 0
-            for p in ps:
-                k = p.grad.numel()
-                p.grad.copy_(flat[off:off + k].view_as(p.grad))
-                off += k
+            _unpack(flat, ps)
             n += 1
         self._reset()
         return n

@@ -205,11 +205,21 @@ def bn_train_state(x, ld, m, k, bn, rep=1.0, stats=None):
         check(lib.dass_bn_finalize_sums(_p(sums), k, float(m) * rep * world, _p(bn.weight), _p(bn.bias), _p(rm), _p(rv), mom,
                                         float(bn.eps), 1, _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
                                         _stream()), "dass_bn_finalize_sums")
+        _running_stats_written(bn, rm, rv)
         return st
     check(lib.dass_bn_finalize(_p(partial), nrows, k, float(m) * rep, float(rep), _p(bn.weight), _p(bn.bias), _p(rm),
                                _p(rv), mom, float(bn.eps), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift),
                                _stream()), "dass_bn_finalize")
+    _running_stats_written(bn, rm, rv)
     return st
+
+
+def _running_stats_written(bn, rm, rv):
+    """the finalize kernels update running_mean / running_var through raw pointers: bump their version counters (the
+    eval-BN vector cache of bn_eval_state is keyed on them) and drop the cached eval vectors of this layer"""
+    if rm is not None:
+        torch.autograd.graph.increment_version([rm, rv])
+        bn.__dict__.pop("_dass_eval_state", None)
 
 
 def sync_bn_world(bn):
@@ -281,7 +291,7 @@ def weight_operand(weight, mode, dtype, cpad=None):
     split6 = dtype == torch.float32 and _state["f32_mma"] == "bf16x6"
     key = (weight.data_ptr(), weight._version, mode, dtype, cdst, tuple(weight.shape), split6)
     hit = _wcache.get((id(weight), mode))
-    if hit is not None and hit[0] == key:
+    if hit is not None and hit[0] == key and hit[2]() is weight:
         return hit[1]
     master = _krsc_master(weight)
     if split6:
@@ -297,7 +307,10 @@ def weight_operand(weight, mode, dtype, cpad=None):
             op = torch.empty((c, r, s, k), dtype=dtype, device=weight.device)
         check(lib.dass_weight_transform(_p(master), _p(op), k, r, s, c, cdst, mode, F32 if dtype == torch.float32 else BF16,
                                         _stream()), "dass_weight_transform")
-    _wcache[(id(weight), mode)] = (key, op, weight)
+    if len(_wcache) > 4096:  # entries of parameters that no longer exist
+        for kk in [kk for kk, v in _wcache.items() if v[2]() is None]:
+            del _wcache[kk]
+    _wcache[(id(weight), mode)] = (key, op, weakref.ref(weight))
     return op
 
 
@@ -470,6 +483,9 @@ class _ConvBnAct(torch.autograd.Function):
             if nc_scale is not None:
                 scale_shift_act(out, ldo, out, ldo, m, k, None, None, nc_scale=nc_scale, rows_per_image=oh * ow)
         else:
+            if getattr(spec, "in_scale", None) is not None:
+                raise RuntimeError("conv_bn_act(in_scale=...) folds a Dropout2d mask into an INFERENCE conv loader: it needs "
+                                   "eval-mode BN (or no BN), a dense non-stem conv and no gradient; this call would drop it")
             assert k % 4 == 0, "BN epilogue needs K % 4 == 0"
             y_raw = new_act(n, k, oh, ow, dt, dev)
             fused_stats = None
@@ -568,12 +584,16 @@ class _ConvBnAct(torch.autograd.Function):
                 sums = torch.empty((2, k), dtype=torch.float32, device=dev)
                 db, dg = sums[0], sums[1]
                 check(lib.dass_bn_bwd_finalize(_p(partial), nrows, k, _p(db), _p(dg), _stream()), "dass_bn_bwd_finalize")
-                if ctx.has_bn and ctx.train_stats:
-                    _allreduce_bn_grads(sums, ctx.sync_world)  # SyncBN: dbeta/dgamma are sums over the GLOBAL batch
                 if ctx.has_bn:
                     dbeta, dgamma = db, dg
                 else:
                     dbias = db
+                if ctx.has_bn and ctx.train_stats and ctx.sync_world > 1:
+                    # SyncBN: the dx formula needs the sums over the GLOBAL batch; the parameter gradients returned to
+                    # autograd stay this rank's LOCAL sums (like torch.nn.SyncBatchNorm), so that the gradient
+                    # averager scales BN affine gradients exactly like conv weight gradients
+                    dbeta, dgamma = db.clone(), dg.clone()
+                    _allreduce_bn_grads(sums, ctx.sync_world)
             if gate:
                 check(lib.dass_bn_bwd_apply_gate(_p(dout_r), lddo, _p(y_raw), k, _p(mean_v), _p(invstd_v), _p(gamma_v.detach()), _p(db), _p(dg),
                                                  _p(bn_scale), _p(bn_shift), _p(nc_scale), _p(dy), lddy, m, k, oh * ow,
@@ -871,13 +891,15 @@ class _BroadcastBN(torch.autograd.Function):
                                      _p(partial), _dt(gs), _stream()), "dass_bn_bwd_reduce")
         sums = torch.empty((2, c), dtype=torch.float32, device=gr.device)
         check(lib.dass_bn_bwd_finalize(_p(partial), nrows, c, _p(sums[0]), _p(sums[1]), _stream()), "dass_bn_bwd_finalize")
-        if ctx.train_stats:
+        dgamma, dbeta = sums[1], sums[0]
+        if ctx.train_stats and ctx.sync_world > 1:
+            dgamma, dbeta = sums[1].clone(), sums[0].clone()  # parameter gradients stay local sums (see _ConvBnAct.backward)
             _allreduce_bn_grads(sums, ctx.sync_world)
         dx = torch.empty((n, c), dtype=gs.dtype, device=gs.device)
         check(lib.dass_bn_bwd_apply(_p(gs), c, _p(yv), c, _p(xv), c, _p(mean), _p(invstd), _p(gamma.detach()),
                                     _p(sums[0]), _p(sums[1]), None, _p(dx), c, None, 0, n, c, 1, float(n) * ctx.sync_world,
                                     1 if ctx.train_stats else 0, ACT_NONE, _dt(dx), _stream()), "dass_bn_bwd_apply")
-        return dx.view(n, 1, 1, c).permute(0, 3, 1, 2), sums[1], sums[0], None, None, None
+        return dx.view(n, 1, 1, c).permute(0, 3, 1, 2), dgamma, dbeta, None, None, None
 
 
 def broadcast_bn(x, bn, h, w):
@@ -1031,10 +1053,12 @@ class _CrossEntropy(torch.autograd.Function):
             return acc[0] / acc[1]
         norm = torch.ones((2,), dtype=torch.float32, device=lg.device)  # backward divides by norm[1] = 1
         ctx.save_for_backward(lg, tgt, wt, norm)
-        return acc[0].clone()
+        count = acc[1].clone()
+        ctx.mark_non_differentiable(count)
+        return acc[0].clone(), count
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, *unused):
         lg, tgt, wt, acc = ctx.saved_tensors
         n, c, hw, is_float, ignore = ctx.meta
         gs = g.detach().float().reshape(1).contiguous()
@@ -1050,6 +1074,12 @@ def cross_entropy(logit, target, weight=None, ignore_index=255):
 
 def cross_entropy_sum(logit, target, weight=None, ignore_index=255):
     """sum over valid pixels of w[t]*nll (reduction='none' summed), used by the sample-weighted loss"""
+    return _CrossEntropy.apply(logit, target, weight, ignore_index, False)[0]
+
+
+def cross_entropy_parts(logit, target, weight=None, ignore_index=255):
+    """-> (sum over valid pixels of w[t]*nll  [autograd], sum of w[t] over valid pixels [no grad]): the numerator and
+    denominator of reduction='mean', kept apart so that ranks can exchange them (utils/loss.py under DDP)"""
     return _CrossEntropy.apply(logit, target, weight, ignore_index, False)
 
 

@@ -63,6 +63,10 @@ class SGD(torch.optim.SGD):
                 stream = ctypes.c_void_p(torch.cuda.current_stream(ps[0].device).cuda_stream)
                 check(lib.dass_sgd_step_multi(vp, vg, vb, vn, vl, n, float(group["momentum"]), float(group["weight_decay"]), stream),
                       "dass_sgd_step_multi")
+                # the kernel writes through raw pointers: tell autograd the tensors changed, or every cache keyed on
+                # (data_ptr, _version) -- split / transposed weight operands, eval-BN vectors -- keeps serving step-0 values
+                torch.autograd.graph.increment_version(ps)
+                torch.autograd.graph.increment_version(bs)
         if leftovers:  # stock arithmetic for what the kernel does not cover
             for group, p in leftovers:
                 g = p.grad

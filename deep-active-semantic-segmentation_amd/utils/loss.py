@@ -8,6 +8,7 @@ exactly as the reference composes it on top of the CE scalar.
 import torch
 
 from dass_hip import ops
+from dass_hip.dist import global_batch_mean, sum_over_ranks, world_size
 
 
 class SegmentationLosses(object):
@@ -33,7 +34,15 @@ class SegmentationLosses(object):
         return w.to(device=device, dtype=torch.float32)
 
     def _ce_mean(self, logit, target):
-        return ops.cross_entropy(logit, target, self._weight_on(logit.device), self.ignore_index)
+        """-> (CE mean over the valid pixels of the GLOBAL batch, global batch size).  The reference evaluates the loss
+        on the gathered logits of all DataParallel replicas (active_train.py:104-105), so under one-process-per-GPU the
+        ranks exchange numerator, valid-pixel count and image count (dass_hip/dist.py:global_batch_mean); a single
+        process takes the fused mean kernel path unchanged."""
+        n = logit.size(0)
+        if world_size() == 1:
+            return ops.cross_entropy(logit, target, self._weight_on(logit.device), self.ignore_index), n
+        s, cnt = ops.cross_entropy_parts(logit, target, self._weight_on(logit.device), self.ignore_index)
+        return global_batch_mean(s, cnt, n)
 
     def SampleWeightedCrossEntropyLoss(self, logit, target, sample_weights):
         n, c, h, w = logit.size()
@@ -41,21 +50,25 @@ class SegmentationLosses(object):
         # reduction='none' then .mean(-1).mean(-1): ignored pixels count as zeros in the H*W mean
         per_image = torch.stack([ops.cross_entropy_sum(logit[i:i + 1], target[i:i + 1], self._weight_on(logit.device),
                                                        self.ignore_index) for i in range(n)]) / float(h * w)
-        loss = torch.mean(torch.mul(per_image, weights))
+        if world_size() > 1:  # mean over the GLOBAL batch (the reference sees the gathered batch on device 0)
+            ng = int(round(float(sum_over_ranks(torch.tensor(float(n), device=logit.device), differentiable=False))))
+            loss = sum_over_ranks(torch.sum(torch.mul(per_image, weights))) / ng
+            n = ng
+        else:
+            loss = torch.mean(torch.mul(per_image, weights))
         if self.batch_average:
             loss /= n
         return loss
 
     def CrossEntropyLoss(self, logit, target):
-        n, c, h, w = logit.size()
-        loss = self._ce_mean(logit, target)
+        loss, n = self._ce_mean(logit, target)
         if self.batch_average:
             loss = loss / n
         return loss
 
     def FocalLoss(self, logit, target, gamma=2, alpha=0.5):
-        n, c, h, w = logit.size()
-        logpt = -self._ce_mean(logit, target)
+        ce, n = self._ce_mean(logit, target)
+        logpt = -ce
         pt = torch.exp(logpt)
         if alpha is not None:
             logpt = logpt * alpha

@@ -315,6 +315,18 @@ for mode in ("post", "overlap", "overlap"):         # the overlapped averager is
             assert p.grad is None, name
         else:
             assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-7), (mode, name, (p.grad - q.grad).abs().max())
+# ranks that differ in WHICH parameters fired: rank 0 also uses the last layer, rank 1 does not -> bucket sizes must
+# not depend on the local grad mask, and rank 1 receives the average for the parameter it never touched
+m = net(); avg = GradientAverager(m.parameters(), bucket_bytes=1024)
+ref = net()
+(loss_of(ref, x[0:2], y[0:2]) * 0.5 + (ref(x[0:2]) ** 2).mean() * 0.5 + loss_of(ref, x[2:4], y[2:4]) * 0.5).backward()
+if rank == 0:
+    (loss_of(m, x[0:2], y[0:2]) + (m(x[0:2]) ** 2).mean()).backward()
+else:
+    loss_of(m, x[2:4], y[2:4]).backward()
+avg.finish()
+for (name, p), q in zip(m.named_parameters(), ref.parameters()):
+    assert p.grad is not None and torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-7), ("uneven", name)
 print("rank %d ddp ok" % rank)
 dist.destroy_process_group()
 """
@@ -333,3 +345,65 @@ def test_gradient_averaging_world2_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "rank 0 ddp ok" in outs[0] and "rank 1 ddp ok" in outs[1]
+
+
+_LOSS_WORKER = r"""
+import os, sys, torch, torch.distributed as dist, torch.nn.functional as F
+sys.path.insert(0, sys.argv[1])
+from dass_hip.dist import GradientAverager, global_batch_mean, sum_over_ranks
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+def net():
+    torch.manual_seed(5)
+    return torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 6, 1))
+g = torch.Generator().manual_seed(21)
+x = torch.randn(5, 3, 9, 9, generator=g)
+t = torch.randint(0, 6, (5, 9, 9), generator=g)
+t[0, :7] = 255; t[1, :1] = 255; t[3] = 255; t[4, :, :4] = 255       # very unequal valid-pixel counts per image
+cw = torch.tensor([1.0, 2.0, 0.5, 1.0, 3.0, 1.5])
+# the reference: CrossEntropyLoss(weight, ignore_index=255, reduction='mean') over the GATHERED batch, then / global n
+# (utils/loss.py:39-51 on DataParallel's gathered logits)
+for mode in ("ce", "focal"):
+    ref = net()
+    ce = F.cross_entropy(ref(x), t, weight=cw, ignore_index=255)
+    if mode == "focal":
+        logpt = -ce; pt = torch.exp(logpt); full = -((1 - pt) ** 2) * (logpt * 0.5) / 5
+    else:
+        full = ce / 5
+    full.backward()
+    # two ranks with UNEQUAL batch sizes (3 + 2 images) and unequal ignore masks
+    sl = slice(0, 3) if rank == 0 else slice(3, 5)
+    m = net(); avg = GradientAverager(m.parameters(), bucket_bytes=512)
+    out = m(x[sl])
+    s_loc = F.cross_entropy(out, t[sl], weight=cw, ignore_index=255, reduction="sum")
+    cnt = cw[t[sl][t[sl] != 255]].sum()
+    mean, n = global_batch_mean(s_loc, cnt, out.shape[0])
+    assert n == 5, n
+    if mode == "focal":
+        logpt = -mean; pt = torch.exp(logpt); loss = -((1 - pt) ** 2) * (logpt * 0.5) / n
+    else:
+        loss = mean / n
+    assert abs(float(loss) - float(full)) <= 1e-6 * abs(float(full)), (mode, float(loss), float(full))   # same VALUE on every rank
+    loss.backward()
+    avg.finish()
+    for (name, p), q in zip(m.named_parameters(), ref.parameters()):
+        assert torch.allclose(p.grad, q.grad, rtol=2e-5, atol=1e-8), (mode, name, (p.grad - q.grad).abs().max())
+print("rank %d loss ok" % rank)
+dist.destroy_process_group()
+"""
+
+
+def test_global_batch_loss_world2_gloo(tmp_path):
+    """DDP loss semantics: per-rank numerators / valid-pixel counts / batch sizes are exchanged so that
+    loss value AND averaged gradients equal one process running the whole batch through the reference's
+    CrossEntropyLoss(mean over valid pixels) / global n -- with unequal ignore masks and unequal per-rank batch sizes"""
+    script = tmp_path / "loss_worker.py"
+    script.write_text(_LOSS_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        procs.append(subprocess.Popen([sys.executable, str(script), os.path.join(ROOT, "deep-active-semantic-segmentation_amd")],
+                                      env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "rank 0 loss ok" in outs[0] and "rank 1 loss ok" in outs[1]

@@ -1,0 +1,170 @@
+"""Round-2 regression tests of the host logic around the kernels: caches keyed on tensor versions must see the updates
+the HIP optimizer / BN finalize kernels make through raw pointers; the image-level MC-dropout selector against the
+oracle's stable top-k with tied scores."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup():
+    from dass_hip import ops
+
+    ops.set_compute_dtype(torch.float32)
+    from oracle import deeplab_cpu as O
+    from oracle import selection_cpu as S
+
+    return ops, O, S
+
+
+@pytest.fixture(autouse=True)
+def _restore_modes():
+    from dass_hip import ops
+
+    mode, dt = ops.f32_mma(), ops.compute_dtype()
+    yield
+    ops.set_f32_mma(mode)
+    ops.set_compute_dtype(dt)
+
+
+@pytest.mark.parametrize("engine", ["bf16x6", "f32", "bf16"])
+def test_hip_sgd_refreshes_weight_operands(engine):
+    """dass_hip.optim.SGD writes parameters through raw pointers; the split / transposed / bf16 weight operands and the
+    eval-BN vectors are cached on (data_ptr, _version).  Three train steps + an eval forward with the HIP optimizer
+    must track the same model stepped by torch.optim.SGD (which bumps versions itself)."""
+    ops, O, S = _setup()
+    from dass_hip.optim import SGD
+    from models.deeplab import DeepLab
+    from utils.loss import SegmentationLosses
+
+    if engine == "bf16":
+        ops.set_compute_dtype(torch.bfloat16)
+    else:
+        ops.set_f32_mma(engine)
+    ncls, n, hw = 19, 2, 65
+    x, lab = O.synthetic_batch(n, hw, hw, ncls, first_index=40)
+    x, lab = x.cuda(), lab.cuda()
+    m1, m2 = O.dropout_masks(n, 3, seed=9)
+    crit = SegmentationLosses(cuda=True).build_loss("ce")
+    runs = {}
+    for name, opt_cls in (("torch", torch.optim.SGD), ("hip", SGD)):
+        torch.manual_seed(77)
+        pm = DeepLab(backbone="resnet", output_stride=16, num_classes=ncls, sync_bn=False, pretrained=False).cuda()
+        opt = opt_cls([{"params": pm.get_1x_lr_params(), "lr": 0.02}, {"params": pm.get_10x_lr_params(), "lr": 0.2}],
+                      momentum=0.9, weight_decay=5e-4)
+        pm.train()
+        losses = []
+        for step in range(3):
+            opt.zero_grad(set_to_none=True)
+            loss = crit(pm(x, dropout_masks=(m1[step].cuda(), m2[step].cuda())), lab)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        pm.eval()
+        with torch.no_grad():
+            logits = pm(x).float().cpu()
+        runs[name] = (losses, logits, pm.backbone.layer1[0].conv1.weight.detach().float().cpu().clone())
+    lt, lh = runs["torch"][0], runs["hip"][0]
+    # large learning rates: a stale step-0 operand in step 1 or 2 moves the loss by O(1)
+    tol = 2e-2 if engine == "bf16" else 2e-3
+    assert abs(lt[0] - lh[0]) <= 1e-6 * abs(lt[0]) + 1e-6
+    assert abs(lt[1] - lh[1]) <= tol * abs(lt[1]) and abs(lt[2] - lh[2]) <= tol * abs(lt[2]), (lt, lh)
+    print(engine, "losses torch", lt, "hip", lh)
+    assert abs(lt[0] - lt[2]) > 3 * tol * abs(lt[0]), "the steps must move the loss for this test to mean anything: %s" % lt
+    scale = runs["torch"][1].abs().max().item()
+    assert (runs["torch"][1] - runs["hip"][1]).abs().max().item() <= (5e-2 if engine == "bf16" else 5e-3) * scale
+    wt, wh = runs["torch"][2], runs["hip"][2]
+    assert (wt - wh).abs().max().item() <= 1e-3 * wt.abs().max().item()
+
+
+def test_bn_eval_cache_sees_running_stat_updates():
+    """dass_bn_finalize updates running_mean / running_var through raw pointers: a train-mode forward with NO write to
+    the affine parameters in between (frozen affine, BN recalibration) followed by eval() must normalise with the NEW
+    running statistics."""
+    ops, O, S = _setup()
+    import torch.nn as nn
+
+    conv = nn.Conv2d(16, 32, 3, 1, 1, bias=False).cuda()
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+    bn = nn.BatchNorm2d(32).cuda()
+    x = (torch.randn(2, 16, 9, 9, generator=torch.Generator().manual_seed(1)) * 3 + 1).cuda()
+    ref_bn = nn.BatchNorm2d(32)
+    with torch.no_grad():
+        bn.eval()
+        y0 = ops.conv_bn_act(x, conv, bn, ops.ACT_NONE).float().cpu()       # caches the eval vectors of the initial stats
+        for _ in range(3):                                                   # recalibration: train-mode forwards only
+            bn.train()
+            ops.conv_bn_act(x, conv, bn, ops.ACT_NONE)
+            ref_bn.train()
+            ref_bn(torch.nn.functional.conv2d(x.cpu(), conv.weight.detach().cpu(), padding=1))
+        bn.eval()
+        ref_bn.eval()
+        y1 = ops.conv_bn_act(x, conv, bn, ops.ACT_NONE).float().cpu()
+        want = ref_bn(torch.nn.functional.conv2d(x.cpu(), conv.weight.detach().cpu(), padding=1))
+    assert (y1 - y0).abs().max().item() > 1e-2, "running statistics did move"
+    assert (y1 - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+    # in_scale outside its inference-only path must not be dropped silently
+    bn.train()
+    with pytest.raises((RuntimeError, AssertionError)):
+        ops.conv_bn_act(x, conv, bn, ops.ACT_NONE, in_scale=torch.ones(2, 16, device="cuda"))
+
+
+def test_get_vote_entropy_for_images_vs_oracle_topk_with_ties():
+    """a9 (mc_dropout.py:173-196): loader loop -> T stochastic passes -> vote entropy -> per-image mean over ALL pixels ->
+    Python stable sort descending -> first k keys.  Duplicate images in the pool give exactly tied scores: the
+    selection must keep the original list order among them, like the reference's sorted(...)."""
+    ops, O, S = _setup()
+    import constants
+    from active_selection.mc_dropout import ActiveSelectionMCDropout
+
+    ncls, hw, T = 19, 65, 6
+    from models.deeplab import DeepLab
+
+    om = O.ODeepLab("mobilenet", 16, ncls)
+    O.fill_state_dict(om, seed=14)
+    pm = DeepLab(backbone="mobilenet", output_stride=16, num_classes=ncls, sync_bn=False, pretrained=False)
+    pm.load_state_dict(om.state_dict())
+    pm = pm.cuda()
+    pm.eval()
+    base = [O.synthetic_batch(1, hw, hw, ncls, first_index=800 + i) for i in range(4)]
+    order = [0, 1, 0, 2, 1, 3, 0]                                   # images 0 and 1 appear several times: tied scores
+    keys = [("img_%03d" % i).encode("ascii") for i in range(len(order))]
+    pool = {k: base[j] for k, j in zip(keys, order)}
+
+    class FixedMasks(ActiveSelectionMCDropout):
+        """the same dropout masks for every image (what makes duplicates tie), recorded for the oracle"""
+
+        def _votes(self, model, image_batch, steps, masks=None):
+            n = image_batch.shape[0]
+            m1, m2 = O.dropout_masks(1, steps, seed=33)
+            return super()._votes(model, image_batch, steps, masks=(m1.expand(steps, n, 256), m2.expand(steps, n, 256)))
+
+    def factory(images, include_labels, bs=3):
+        for i in range(0, len(images), bs):
+            chunk = images[i:i + bs]
+            yield {"image": torch.cat([pool[k][0] for k in chunk]), "label": torch.cat([pool[k][1] for k in chunk])}
+
+    sel = FixedMasks(ncls, None, hw, 3, loader_factory=factory)
+    got = sel.get_vote_entropy_for_images(pm, keys, 4, steps=T)
+    assert all(not m.training for m in pm.modules() if isinstance(m, torch.nn.Dropout2d)), "model.eval() on exit"
+    # oracle: the same reduction on the CPU model with the same masks
+    om.eval()
+    m1, m2 = O.dropout_masks(1, T, seed=33)
+    scores = []
+    for k in keys:
+        img, lab = pool[k]
+        votes = S.mc_votes(om, img, (m1, m2))
+        scores.append(float(S.vote_entropy_maps(votes, lab, ncls)[0].mean()))
+    assert scores[0] == scores[2] == scores[6] and scores[1] == scores[4]
+    want = S.select_top(scores, keys, 4, reverse=True)
+    assert list(got) == list(want), (got, want, scores)
+    dev_scores = sel._image_scores(pm, keys, T).cpu().numpy()
+    assert np.abs(dev_scores - np.array(scores)).max() <= 1e-3
+    assert dev_scores[0] == dev_scores[2] == dev_scores[6], "duplicates must score bit-identically whatever their batch slot"
+    # T defaults to constants.MC_STEPS read at call time
+    constants.MC_STEPS = 3
+    try:
+        assert len(sel.get_vote_entropy_for_images(pm, keys[:2], 1)) == 1
+    finally:
+        constants.MC_STEPS = 20

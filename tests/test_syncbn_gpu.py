@@ -59,9 +59,37 @@ close(bn.running_mean, 0.1 * mean, 1e-4, "running_mean")
 for t in (conv.weight.grad, bn.weight.grad, bn.bias.grad):
     pass
 wg = conv.weight.grad.clone(); dist.all_reduce(wg); close(wg, wr.grad, 1e-3, "dw (summed over ranks)")
-# dgamma / dbeta were all-reduced inside the BN backward (they are needed for dx): every rank holds the global value
-close(bn.weight.grad, gr.grad, 1e-3, "dgamma")
-close(bn.bias.grad, br.grad, 1e-3, "dbeta")
+# dgamma / dbeta: the global sums are used inside the BN backward (dx needs them), but the PARAMETER gradients handed to
+# autograd are this rank's local sums, like conv weights (torch.nn.SyncBatchNorm does the same): sum over ranks
+dgs = bn.weight.grad.clone(); dist.all_reduce(dgs); close(dgs, gr.grad, 1e-3, "dgamma (summed over ranks)")
+dbs = bn.bias.grad.clone(); dist.all_reduce(dbs); close(dbs, br.grad, 1e-3, "dbeta (summed over ranks)")
+assert (bn.weight.grad.cpu() - gr.grad).abs().max().item() > 1e-3 * gr.grad.abs().max().item(), "local, not global, sums"
+
+# ---- SyncBN + GradientAverager + the global-batch loss == ONE process stepping the whole batch (SURVEY 8e row 4):
+# every parameter (conv weight, BN gamma / beta) must come out of the averager equal to the single-process gradient
+from dass_hip.dist import GradientAverager
+from utils.loss import SegmentationLosses
+lab = torch.randint(0, K, (N, H, H), generator=g).float()
+lab[0, :6] = 255; lab[3, :, :2] = 255                      # unequal valid-pixel counts on the two ranks
+for t_ in (xr, wr, gr, br):
+    t_.grad = None
+y = F.conv2d(xr, wr, padding=1)
+mean = y.mean(dim=(0, 2, 3)); var = y.var(dim=(0, 2, 3), unbiased=False)
+logits = (y - mean[None, :, None, None]) * (var.clamp(min=eps) ** -0.5 * gr)[None, :, None, None] + br[None, :, None, None]
+ref_loss = F.cross_entropy(logits, lab.long(), ignore_index=255) / N      # utils/loss.py:39-51 on the gathered batch
+ref_loss.backward()
+conv.zero_grad(); bn.zero_grad()
+params = [conv.weight, bn.weight, bn.bias]
+avg = GradientAverager(params, bucket_bytes=4096)
+xd2 = x[sl].cuda().contiguous(memory_format=torch.channels_last)
+lg = ops.conv_bn_act(xd2, conv, bn, ops.ACT_NONE)
+loss = SegmentationLosses(cuda=True).build_loss("ce")(lg.float().contiguous(), lab[sl].cuda())
+assert abs(loss.item() - ref_loss.item()) <= 1e-5 * abs(ref_loss.item()), (loss.item(), ref_loss.item())
+loss.backward()
+assert avg.finish() >= 1
+close(conv.weight.grad, wr.grad, 2e-3, "averaged dw vs single process")
+close(bn.weight.grad, gr.grad, 2e-3, "averaged dgamma vs single process")
+close(bn.bias.grad, br.grad, 2e-3, "averaged dbeta vs single process")
 # plain BatchNorm2d must NOT synchronise
 bn2 = nn.BatchNorm2d(K).cuda()
 assert ops.sync_bn_world(bn2) == 1 and ops.sync_bn_world(bn) == 2
