@@ -29,7 +29,18 @@ class ActiveSelectionCoreSet(ActiveSelectionBase):
         return new_batch
 
     def _updated_distances(self, cluster_centers, features, min_distances):
-        raise NotImplementedError("folded into dass_kcenter_update; use _select_batch")
+        """core_set.py:32-38: distance of every row to its nearest centre among `cluster_centers`, folded into the running
+        minimum (None = first call) -- one dass_kcenter_update launch per centre.  -> float64 numpy [N, 1] like the
+        reference.  (_select_batch keeps the whole greedy loop on the device and does not go through the host here.)"""
+        feats = features if torch.is_tensor(features) else torch.as_tensor(np.asarray(features, dtype=np.float32))
+        feats = (feats if feats.is_cuda else feats.cuda()).contiguous().float()
+        n = feats.shape[0]
+        if min_distances is None:
+            md = torch.full((n,), float("inf"), dtype=torch.float64, device=feats.device)
+        else:
+            md = torch.as_tensor(np.asarray(min_distances, dtype=np.float64).reshape(-1)).to(feats.device)
+        ops.kcenter_update(feats, list(cluster_centers), md)
+        return md.cpu().numpy().reshape(-1, 1)
 
     def _features(self, model, paths):
         core = self.unwrap(model)

@@ -4,7 +4,9 @@ Same reduction as MC-dropout (votes of T argmax maps -> per-class fractions -> -
 -> per-image sum / (H*W)), with the stochasticity coming from gaussian input noise (sigma 0.125, mc_noise.py:24),
 from the model's own feature noise (DeepLab.set_noisy_features, deeplab.py:39-56) or from both noise and dropout.
 T = constants.MC_STEPS read at call time.  Noise draws come from torch's device RNG (the reference uses numpy on
-the host), so these selectors are distribution-equivalent, not stream-equivalent; every pass is a full forward.
+the host), so these selectors are distribution-equivalent by default; with `noise_source=draw(shape, sigma)` (and the
+same hook on the model, DeepLab.noise_source) the draws are supplied by the caller -- the tests replay numpy's seeded
+stream and compare votes and entropy maps with the reference's (tests/golden/mc_noise.npz).  Every pass is a full forward.
 """
 import torch
 
@@ -16,9 +18,10 @@ from dass_hip import ops
 
 class ActiveSelectionMCNoise(ActiveSelectionBase):
 
-    def __init__(self, num_classes, dataset_lmdb_env, crop_size, dataloader_batch_size, **kw):
+    def __init__(self, num_classes, dataset_lmdb_env, crop_size, dataloader_batch_size, noise_source=None, **kw):
         super(ActiveSelectionMCNoise, self).__init__(dataset_lmdb_env, crop_size, dataloader_batch_size, **kw)
         self.dataset_num_classes = num_classes
+        self.noise_source = noise_source
 
     def _vote_maps(self, model, image_batch, label_batch, perturb=None):
         steps = constants.MC_STEPS
@@ -32,16 +35,24 @@ class ActiveSelectionMCNoise(ActiveSelectionBase):
         return [emap[i] for i in range(n)]
 
     def _get_vote_entropy_for_batch_with_input_noise(self, model, image_batch, label_batch):
-        return self._vote_maps(model, image_batch, label_batch,
-                               perturb=lambda x: x + torch.randn_like(x) * 0.125)
+        def perturb(x):  # mc_noise.py:24-25: N(0, 0.125) on the normalised image
+            if self.noise_source is not None:
+                return x + self.noise_source(tuple(x.shape), 0.125).to(device=x.device, dtype=x.dtype)
+            return x + torch.randn_like(x) * 0.125
+
+        return self._vote_maps(model, image_batch, label_batch, perturb=perturb)
 
     def _get_vote_entropy_for_batch_with_feature_noise(self, model, image_batch, label_batch):
         core = self.unwrap(model)
         core.set_noisy_features(True)
+        saved = getattr(core, "noise_source", None)
+        if self.noise_source is not None:
+            core.noise_source = self.noise_source
         try:
             return self._vote_maps(model, image_batch, label_batch)
         finally:
             core.set_noisy_features(False)
+            core.noise_source = saved
 
     def _get_vote_entropy_for_batch_with_mc_dropout(self, model, image_batch, label_batch):
         model.apply(_turn_on_dropout)

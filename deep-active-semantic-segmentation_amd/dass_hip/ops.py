@@ -1171,6 +1171,15 @@ def kcenter_greedy(features, selected, count):
     return picks[:count], min_dist
 
 
+def kcenter_update(feats, centers, min_dist):
+    """min_dist[i] = min(min_dist[i], ||f_i - f_c||) for every c in centers, in place (f64; core_set.py:32-38)"""
+    idx = torch.as_tensor(list(centers), dtype=torch.int64, device=feats.device)
+    n, d = feats.shape
+    for i in range(idx.numel()):
+        check(lib.dass_kcenter_update(_p(feats), n, d, _p(idx[i:i + 1]), _p(min_dist), 0, _stream()), "dass_kcenter_update")
+    return min_dist
+
+
 def box_sum(maps, r):
     n, h, w = maps.shape
     out = torch.empty((n, h - r + 1, w - r + 1), dtype=torch.float32, device=maps.device)

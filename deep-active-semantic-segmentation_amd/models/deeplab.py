@@ -39,6 +39,7 @@ class DeepLab(nn.Module):
         self.noisy_features = False
         self.model_name = 'deeplab'
         self.num_classes = num_classes
+        self.noise_source = None  # optional draw(shape, sigma) -> tensor replacing the device RNG (reproducible noise passes)
         if freeze_bn:
             self.freeze_bn()
 
@@ -48,10 +49,13 @@ class DeepLab(nn.Module):
     def set_noisy_features(self, noisy_features):
         self.noisy_features = noisy_features
 
-    @staticmethod
-    def _noise_like(t, frac):
-        # deeplab.py:39-56 draws numpy gaussians on the host; same distribution drawn on the device here
-        return torch.randn_like(t.float()) * abs(float(t.float().mean()) * frac)
+    def _noise_like(self, t, frac):
+        # deeplab.py:39-56 draws numpy gaussians on the host (sigma = |mean| * frac); the same distribution is drawn on
+        # the device here, or taken from `noise_source(shape, sigma)` when one is set (tests replay numpy's stream)
+        sigma = abs(float(t.float().mean()) * frac)
+        if self.noise_source is not None:
+            return self.noise_source(tuple(t.shape), sigma).to(device=t.device, dtype=torch.float32)
+        return torch.randn_like(t.float()) * sigma
 
     @ops.bn_counter_scope
     def forward(self, input, dropout_masks=None):

@@ -192,11 +192,21 @@ class ODeepLab(nn.Module):
         self.decoder = ODecoder(num_classes, backbone)
         self.return_features = False
 
-    def forward(self, x, masks=None):
-        """masks: None (dropout inactive) or (aspp_mask [N,256], decoder_mask [N,256]) multipliers."""
+    def forward(self, x, masks=None, noise=None):
+        """masks: None (dropout inactive) or (aspp_mask [N,256], decoder_mask [N,256]) multipliers.
+        noise: None or draw(shape, scale) -> tensor: the gaussian feature noise of deeplab.py:39-56
+        (input: |mean| * 0.05; backbone output, low-level features and ASPP output: |mean| * 0.5), drawn in that order."""
         m1, m2 = masks if masks is not None else (None, None)
+        if noise is not None:
+            x = x + noise(tuple(x.shape), abs(float(x.mean()) * 0.05))
         hi, low = self.backbone(x)
-        low_res, feats = self.decoder(self.aspp(hi, m1), low, m2)
+        if noise is not None:
+            hi = hi + noise(tuple(hi.shape), abs(float(hi.mean()) * 0.5))
+            low = low + noise(tuple(low.shape), abs(float(low.mean()) * 0.5))
+        a = self.aspp(hi, m1)
+        if noise is not None:
+            a = a + noise(tuple(a.shape), abs(float(a.mean()) * 0.5))
+        low_res, feats = self.decoder(a, low, m2)
         out = _bilinear(low_res, x.shape[2:])
         return (out, feats) if self.return_features else out
 

@@ -7,6 +7,8 @@ TEST INFRASTRUCTURE (see oracle/__init__.py).  Restates, with T and the dropout 
   active_selection/mc_dropout.py:189-195  per-image mean + stable descending sort + top-k
   active_selection/ceal.py:34-39,82-95,111-123,158-164   confidence / margin / entropy / weak labels
   active_selection/core_set.py:17-38,56-63 feature pooling + k-center greedy (sklearn fp64 distances)
+  active_selection/max_subset.py:17-39,49-113  greedy facility location, region features
+  utils/metrics.py:6-49                   confusion matrix + the four metrics
 """
 import math
 
@@ -172,3 +174,52 @@ def max_representative_samples(image_features, candidate_features, selection_cou
         picked.append(best_j)
         mind = best_mind
     return picked
+
+
+# ------------------------------------------------------------------ region features (max_subset.py:49-71,91-113)
+def region_grid_features(feats, region_size, crop_size):
+    """_get_features_for_image_regions: the feature map is cut into a grid of h x w cells (h = floor(region * H / crop)) and
+    every cell becomes ONE C-vector.  The reference pools the cell with F.avg_pool2d(cell, (H, W)) -- a kernel of the FULL
+    map size over an h x w crop, which PyTorch rejects ("Output size is too small", max_subset.py:62-63 as written can
+    never have run); the evident intent, one average per cell, is what is restated here.  -> [B * rows * cols, C] f64"""
+    b, c, hh, ww = feats.shape
+    h = math.floor(region_size * hh / crop_size)
+    w = math.floor(region_size * ww / crop_size)
+    rows_, cols_ = math.floor(hh / h), math.floor(ww / w)
+    out = []
+    for i in range(b):
+        for r in range(rows_):
+            for q in range(cols_):
+                out.append(feats[i, :, r * h:r * h + h, q * w:q * w + w].double().mean(dim=(1, 2)).numpy())
+    return np.stack(out) if out else np.zeros((0, c))
+
+
+def region_features(feats, regions, crop_size):
+    """_get_features_for_regions (max_subset.py:91-113): region (r, c, h, w) in image pixels -> feature-map crop
+    [floor(r * H / crop) : + floor(h * H / crop)] -> one C-vector (same remark about the pooling kernel)."""
+    out = []
+    for i, (r0, c0, h0, w0) in enumerate(regions):
+        rr, rc = feats.shape[2] / crop_size, feats.shape[3] / crop_size
+        r, c, h, w = math.floor(r0 * rr), math.floor(c0 * rc), math.floor(h0 * rr), math.floor(w0 * rc)
+        out.append(feats[i, :, r:r + h, c:c + w].double().mean(dim=(1, 2)).numpy())
+    return np.stack(out)
+
+
+# ------------------------------------------------------------------ confusion-matrix metrics (utils/metrics.py:6-49)
+def confusion_matrix(gt, pred, num_class):
+    """rows = ground truth, columns = prediction, pixels with gt outside [0, num_class) dropped (metrics.py:37-42)"""
+    gt = np.asarray(gt)
+    pred = np.asarray(pred)
+    keep = (gt >= 0) & (gt < num_class)
+    idx = gt[keep].astype(np.int64) * num_class + pred[keep].astype(np.int64)
+    return np.bincount(idx, minlength=num_class * num_class).reshape(num_class, num_class).astype(np.float64)
+
+
+def confusion_metrics(cm):
+    """-> dict(pixel_acc, class_acc, miou, fwiou) with the reference's nan conventions (metrics.py:13-35)"""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        diag, rows_, cols_, tot = np.diag(cm), cm.sum(axis=1), cm.sum(axis=0), cm.sum()
+        iou = diag / (rows_ + cols_ - diag)
+        freq = rows_ / tot
+        return dict(pixel_acc=diag.sum() / tot, class_acc=np.nanmean(diag / rows_), miou=np.nanmean(iou),
+                    fwiou=(freq[freq > 0] * iou[freq > 0]).sum())

@@ -118,6 +118,46 @@ def test_oracle_softmax_scores_kcenter_nms_golden():
     assert regions[0][0] == (18, 72, 127, 127)
 
 
+def test_oracle_metrics_and_noise_goldens():
+    """round-2 fixtures written by oracle/make_goldens_r2.py from the reference's Evaluator (utils/metrics.py:6-49) and
+    its noise selectors (active_selection/mc_noise.py:21-44,62-84): the oracle restatements reproduce them"""
+    gm = np.load(os.path.join(GOLD, "metrics.npz"))
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(3, 19, 33, 41, generator=g)
+    target = torch.randint(0, 19, (3, 33, 41), generator=g).float()
+    target[:, :4] = 255
+    target[0, 5] = -1
+    logits2 = torch.randn(3, 19, 33, 41, generator=g)
+    cm1 = S.confusion_matrix(target.numpy(), np.argmax(logits.numpy(), axis=1), 19)
+    cm2 = cm1 + S.confusion_matrix(target.numpy(), np.argmax(logits2.numpy(), axis=1), 19)
+    assert np.array_equal(cm1, gm["cm1"]) and np.array_equal(cm2, gm["cm2"])
+    for cm, key in ((cm2, "vals"), (gm["cm3"], "vals3")):
+        m = S.confusion_metrics(cm)
+        assert np.abs(np.array([m[k] for k in ("pixel_acc", "class_acc", "miou", "fwiou")]) - gm[key]).max() < 1e-14
+    gn = np.load(os.path.join(GOLD, "mc_noise.npz"))
+    n, hw, ncls, T = [int(v) for v in gn["meta"]]
+    om = O.ODeepLab("mobilenet", 16, ncls)
+    O.fill_state_dict(om, seed=15)
+    om.eval()
+    x, lab = O.synthetic_batch(n, hw, hw, ncls, first_index=60)
+
+    def np_draw(shape, sigma):
+        return torch.from_numpy(np.random.normal(loc=0.0, scale=sigma, size=shape).astype(np.float32))
+
+    np.random.seed(502)
+    with torch.no_grad():
+        votes = torch.stack([torch.argmax(om(x, noise=np_draw), dim=1) for _ in range(T)], 1)
+    safe = torch.from_numpy(gn["feature_margin"].astype(np.float32)) > 1e-3
+    assert torch.equal(votes[safe], torch.from_numpy(gn["feature_votes"]).long()[safe])
+    ent = torch.stack(S.vote_entropy_maps(torch.from_numpy(gn["feature_votes"]).long(), lab, ncls))
+    assert (ent - torch.from_numpy(gn["feature_entropy"])).abs().max().item() == 0.0
+    # region features: grid cells tile the map, a full-size "region" is the global mean
+    f = torch.rand(2, 8, 12, 12, generator=torch.Generator().manual_seed(1))
+    grid = S.region_grid_features(f, 16, 48)   # 4x4 cells -> 3x3 grid
+    assert grid.shape == (2 * 9, 8) and abs(grid[0, 0] - float(f[0, 0, :4, :4].double().mean())) < 1e-12
+    assert np.abs(S.region_features(f, [(0, 0, 48, 48), (0, 0, 48, 48)], 48) - f.double().mean(dim=(2, 3)).numpy()).max() < 1e-12
+
+
 def test_hash_fill_is_stable():
     u = O._hash_uniform(5, 7)
     assert u.dtype == np.float32 and np.all((u >= 0) & (u < 1))

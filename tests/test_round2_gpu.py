@@ -61,9 +61,17 @@ def test_hip_sgd_refreshes_weight_operands(engine):
             loss.backward()
             opt.step()
             losses.append(loss.item())
-        pm.eval()
+        # every operand / eval-BN cache of `pm` must describe its CURRENT tensors: a deep copy (new parameter objects, so
+        # no cache entry can match) must compute the same logits bit for bit, in train- and in eval-mode BN
+        import copy
+
+        fresh = copy.deepcopy(pm)
         with torch.no_grad():
-            logits = pm(x).float().cpu()
+            logits = pm(x, dropout_masks=(m1[0].cuda(), m2[0].cuda())).float().cpu()
+            assert torch.equal(logits, fresh(x, dropout_masks=(m1[0].cuda(), m2[0].cuda())).float().cpu()), name
+            pm.eval()
+            fresh.eval()
+            assert torch.equal(pm(x).float().cpu(), fresh(x).float().cpu()), name
         runs[name] = (losses, logits, pm.backbone.layer1[0].conv1.weight.detach().float().cpu().clone())
     lt, lh = runs["torch"][0], runs["hip"][0]
     # large learning rates: a stale step-0 operand in step 1 or 2 moves the loss by O(1)
@@ -73,7 +81,8 @@ def test_hip_sgd_refreshes_weight_operands(engine):
     print(engine, "losses torch", lt, "hip", lh)
     assert abs(lt[0] - lt[2]) > 3 * tol * abs(lt[0]), "the steps must move the loss for this test to mean anything: %s" % lt
     scale = runs["torch"][1].abs().max().item()
-    assert (runs["torch"][1] - runs["hip"][1]).abs().max().item() <= (5e-2 if engine == "bf16" else 5e-3) * scale
+    # train-mode (batch statistics) logits of the two trajectories after 3 steps
+    assert (runs["torch"][1] - runs["hip"][1]).abs().max().item() <= (1e-1 if engine == "bf16" else 2e-2) * scale
     wt, wh = runs["torch"][2], runs["hip"][2]
     assert (wt - wh).abs().max().item() <= 1e-3 * wt.abs().max().item()
 
