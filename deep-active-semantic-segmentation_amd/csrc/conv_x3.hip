@@ -1,0 +1,565 @@
+// Pipelined implicit-GEMM convolution on PRE-SPLIT operands ("x3" rows) for gfx950.
+//
+// The parity engine multiplies f32 tensors exactly on the bf16 matrix pipe: x = x0 + x1 + x2 (three bf16 parts), six
+// products per pair.  conv_igemm.hip converts the activation operand inside its MFMA loop (3.4 VALU per MFMA, two
+// barriers per 32-k slab, register staging).  Here BOTH operands arrive already split -- activations as
+//   x3[pixel][C/32][3 parts][32 ch] bf16   (192 B per pixel and 32-channel slab; row `rows` is an all-zero row)
+// written by the producing pass (dass_split3_rows, the BN-apply / BN-backward kernels), weights as the existing
+//   w3[k][tap][C/32][3][32]                (dass_weight_transform(DASS_F32X6) / dass_weight_split_batch) --
+// so the main loop is a pure copy + MFMA pipeline:
+//   * global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction, no VGPR staging, no VALU
+//     conversion); the implicit-GEMM gather and the zero padding live in the per-lane SOURCE offset (a padded tap
+//     reads the zero row), the bank swizzle too (the LDS destination of a DMA is lane-linear);
+//   * an NSTAGE-deep LDS ring with ONE s_barrier per 32-k slab and counted s_waitcnt vmcnt(N): the loads of the next
+//     NSTAGE-1 slabs stay in flight under the MFMAs (cdna_hip_programming.md 5, "Pipelining across barriers");
+//   * 16-row x 64-B pieces, XOR-swizzled at 16-B granularity: every ds_read_b128 of a 32x32x16 fragment is
+//     conflict-free, every DMA instruction fetches 16 rows x 64 contiguous bytes.
+// The epilogue is the one of conv_igemm.hip (accumulators bounced through wave-private LDS patches, 16-B stores, fused
+// scale/shift/residual/activation, per-tile BatchNorm partial sums) and can emit the result as x3 rows as well.
+// dgrad = the same kernel over dy (x3) and the transposed weight operand, phase-decomposed for strided convs.
+//
+// Reference sites replaced: every dense nn.Conv2d of the DeepLab path with C % 32 handled by zero padding
+// (models/backbone/resnet.py:11-15, models/aspp.py:13-14,57-68, models/decoder.py:23-36).
+#include "dass_common.h"
+#include <cstdlib>
+
+namespace {
+
+struct X3P {
+    const char *x3;
+    const char *w3;
+    char *y;    // f32 rows [M][ldy] (nullable when y3 is set)
+    char *y3;   // optional: the result as x3 rows [M + 1][cc_out][192] (row M zeroed)
+    const float *scale;
+    const float *shift;
+    const char *res;
+    float *stat_partial;
+    long ldy, ldr;
+    unsigned x3_bytes, w3_bytes, zero_off, row_pitch;  // row_pitch = CC * 192
+    int cc_out;
+    int N, H, W, CC, OH, OW, K, R, S, stride, pad, dil, act;
+    int M, mtiles, ntiles;
+    int OHs, OWs, o_mul, oy_add, ox_add, ustride;
+    unsigned long long tap_allow;
+};
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// One LDS-DMA instruction: lane l's 16 bytes at (buffer base + voff) land at LDS byte address lds + 16 * l.
+// Issued through inline asm ON PURPOSE: hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of the first ds_read that
+// follows a __builtin_amdgcn_raw_ptr_buffer_load_lds it cannot prove disjoint -- every ring read here -- which drains the
+// pipeline each slab (seen in the .s of the builtin version).  Hidden from the compiler, the DMAs are counted by hand
+// (wait_vmcnt below); M0 (the DMA's LDS base) is saved and restored inside the statement (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void dma16(v4i rsrc, unsigned lds, unsigned voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds), "s"(rsrc)
+                 : "memory");
+}
+
+__device__ __forceinline__ v4i make_srd(const void *base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    v4i r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));  // stride 0
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);                              // num_records (bytes)
+    r[3] = 0x00020000;                                                              // raw buffer, 32-bit data format
+    return r;
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ f32x16 mfma16(const uint4 &a, const uint4 &b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&a), *reinterpret_cast<const bf16x8 *>(&b), c, 0, 0, 0);
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_bf16(f32x2 v) {
+    bf16x2v b = __builtin_convertvector(v, bf16x2v);
+    return *reinterpret_cast<unsigned *>(&b);
+}
+// four f32 -> the three bf16 parts (x0, x1, x2), 8 B each
+__device__ __forceinline__ void split3_4(f32x4 v, uint2 &p0, uint2 &p1, uint2 &p2) {
+    const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    const unsigned h0 = pk_bf16(a), h1 = pk_bf16(b);
+    const f32x2 ra = a - f32x2{__uint_as_float(h0 << 16), __uint_as_float(h0 & 0xffff0000u)};
+    const f32x2 rb = b - f32x2{__uint_as_float(h1 << 16), __uint_as_float(h1 & 0xffff0000u)};
+    const unsigned m0 = pk_bf16(ra), m1 = pk_bf16(rb);
+    const f32x2 sa = ra - f32x2{__uint_as_float(m0 << 16), __uint_as_float(m0 & 0xffff0000u)};
+    const f32x2 sb = rb - f32x2{__uint_as_float(m1 << 16), __uint_as_float(m1 & 0xffff0000u)};
+    p0 = make_uint2(h0, h1);
+    p1 = make_uint2(m0, m1);
+    p2 = make_uint2(pk_bf16(sa), pk_bf16(sb));
+}
+
+// LDS image of one operand stage: rowgroup g (16 rows), part pl -> a 1 KiB piece at (g * 3 + pl) * 1024; inside a piece
+// row r16 / 16-B chunk c sits at r16 * 64 + ((c ^ ((r16 >> 2) & 3)) * 16).
+template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE>
+__global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(const X3P p) {
+    constexpr int NW = WARPS_M * WARPS_N;
+    constexpr int TMW = BM / WARPS_M, TNW = BN / WARPS_N, MT = TMW / 32, NT = TNW / 32;
+    constexpr int AG = BM / 16, BG = BN / 16, RG = (AG + BG) / NW;
+    static_assert((AG + BG) % NW == 0, "rowgroups must divide over the waves");
+    static_assert(MT >= 1 && NT >= 1 && NSTAGE >= 2 && NSTAGE <= 4, "tile");
+    constexpr int A_BYTES = AG * 3072, B_BYTES = BG * 3072, STAGE = A_BYTES + B_BYTES;
+    constexpr int G = RG * 3;  // DMA instructions per wave and slab
+    static_assert(G * (NSTAGE - 2) <= 63, "vmcnt range");
+    constexpr int RING = NSTAGE * STAGE;
+    // ONE shared object (a second one beside a DMA-filled array makes hipcc drain vmcnt before every ds_read)
+    __shared__ __attribute__((aligned(16))) char smem[RING + 64 * 4];
+    unsigned *tap_delta = reinterpret_cast<unsigned *>(smem + RING);
+
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt_i = wg / p.ntiles, nt_i = wg - mt_i * p.ntiles;
+    const int m0 = mt_i * BM, n0 = nt_i * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WARPS_N, wn = wave - wm * WARPS_N;
+
+    const v4i rsa = make_srd(p.x3, p.x3_bytes), rsb = make_srd(p.w3, p.w3_bytes);
+    const unsigned smem_base = (unsigned)(size_t)smem;  // LDS byte address of the ring
+
+    // ---- loader roles: this lane fetches row r16 = lane >> 2 of each of the wave's RG rowgroups, the 16-B chunk that
+    // lands (lane-linear) at slot lane & 3 of that row, i.e. source chunk (lane & 3) ^ ((r16 >> 2) & 3)
+    const int r16 = lane >> 2;
+    const unsigned chunk_off = (unsigned)(((lane & 3) ^ ((r16 >> 2) & 3)) * 16);
+    const int ntaps = p.R * p.S;
+    const int ohw = p.OHs * p.OWs;
+    const bool phase = p.o_mul != 1;
+    auto tap_ey = [&](int r) -> int { return phase ? (p.oy_add - p.pad + r * p.dil) / p.ustride : r * p.dil; };
+    auto tap_ex = [&](int s) -> int { return phase ? (p.ox_add - p.pad + s * p.dil) / p.ustride : s * p.dil; };
+
+    unsigned rb_off[RG];
+    unsigned long long vmask[RG];
+    int a_by[RG], a_bx[RG];
+    bool a_ok[RG];
+#pragma unroll
+    for (int j = 0; j < RG; ++j) {
+        const int q = wave + j * NW;
+        vmask[j] = 0ull;
+        a_by[j] = a_bx[j] = 0;
+        a_ok[j] = false;
+        if (q < AG) {
+            const int m = m0 + q * 16 + r16;
+            a_ok[j] = m < p.M;
+            const int mm = a_ok[j] ? m : 0;
+            const int n = mm / ohw;
+            const int rem = mm - n * ohw;
+            const int ohs = rem / p.OWs;
+            const int ows = rem - ohs * p.OWs;
+            a_by[j] = phase ? ohs : ohs * p.stride - p.pad;
+            a_bx[j] = phase ? ows : ows * p.stride - p.pad;
+            rb_off[j] = (unsigned)(((long)n * p.H + a_by[j]) * p.W + a_bx[j]) * p.row_pitch + chunk_off;  // wraps for border rows; only valid taps use it
+        } else {
+            int k = n0 + (q - AG) * 16 + r16;
+            if (k >= p.K) k = p.K - 1;  // columns >= K are never stored: any finite row will do
+            rb_off[j] = (unsigned)k * (unsigned)(ntaps * p.CC * 192) + chunk_off;
+        }
+    }
+
+    // ---- taps that touch this tile at all; per A row the taps that fall inside the image
+    unsigned long long tapmask = 0ull;
+    for (int t = 0; t < ntaps; ++t) {
+        if (!((p.tap_allow >> t) & 1ull)) continue;
+        const int r = t / p.S, s = t - r * p.S;
+        const int ey = tap_ey(r), ex = tap_ex(s);
+        if (tid == 0) tap_delta[t] = (unsigned)(ey * p.W + ex) * p.row_pitch;
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < RG; ++j) {
+            const int iy = a_by[j] + ey, ix = a_bx[j] + ex;
+            const bool ok = a_ok[j] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            if (ok) vmask[j] |= (1ull << t);
+            any = any || ok;
+        }
+        if (__syncthreads_or((int)any)) tapmask |= (1ull << t);
+    }
+    __syncthreads();  // tap_delta visible
+
+    const int total = __builtin_popcountll(tapmask) * p.CC;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // ---- slab iterator of the LOADER (channel slab outer, active taps inner: the 9 taps of a 3x3 re-read the same
+    // neighbourhood back to back, so the re-reads are L2 hits)
+    unsigned long long it_mask = tapmask;
+    int it_cc = 0;
+    auto issue_next = [&](int stage) {
+        if (!it_mask) {
+            ++it_cc;
+            it_mask = tapmask;
+        }
+        const int t = __builtin_ctzll(it_mask);
+        it_mask &= it_mask - 1;
+        const unsigned st = smem_base + (unsigned)(stage * STAGE);
+        const unsigned a_uni = tap_delta[t] + (unsigned)(it_cc * 192);
+        const unsigned b_uni = (unsigned)((t * p.CC + it_cc) * 192);
+#pragma unroll
+        for (int j = 0; j < RG; ++j) {
+            const int q = wave + j * NW;
+            if (q < AG) {
+                const bool valid = (vmask[j] >> t) & 1ull;
+                const unsigned voff = valid ? rb_off[j] + a_uni : p.zero_off + chunk_off;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(st + q * 3072);
+                dma16(rsa, dst, voff);
+                dma16(rsa, dst + 1024, voff + 64);
+                dma16(rsa, dst + 2048, voff + 128);
+            } else {
+                const unsigned voff = rb_off[j] + b_uni;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(st + A_BYTES + (q - AG) * 3072);
+                dma16(rsb, dst, voff);
+                dma16(rsb, dst + 1024, voff + 64);
+                dma16(rsb, dst + 2048, voff + 128);
+            }
+        }
+    };
+
+    // ---- fragment addresses: lane (r = lane & 31, h = lane >> 5) reads row r, chunk 2 ks + h of each part
+    const int fr = lane & 31, fh = lane >> 5;
+    const int fsw = ((fr & 15) >> 2) & 3;
+    const int f_row = (fr >> 4) * 3072 + (fr & 15) * 64;
+    const int a_lane0 = (wm * (TMW / 16)) * 3072 + f_row + (((0 + fh) ^ fsw) * 16);
+    const int a_lane1 = (wm * (TMW / 16)) * 3072 + f_row + (((2 + fh) ^ fsw) * 16);
+    const int b_lane0 = A_BYTES + (wn * (TNW / 16)) * 3072 + f_row + (((0 + fh) ^ fsw) * 16);
+    const int b_lane1 = A_BYTES + (wn * (TNW / 16)) * 3072 + f_row + (((2 + fh) ^ fsw) * 16);
+
+    // ---- prologue: NSTAGE - 1 slabs in flight
+    int issued = 0;
+#pragma unroll
+    for (int sg = 0; sg < NSTAGE - 1; ++sg)
+        if (issued < total) {
+            issue_next(sg);
+            ++issued;
+        }
+
+    int cur = 0, nxt = NSTAGE - 1;  // stage being computed / stage the next issue goes to
+    for (int s = 0; s < total; ++s) {
+        // slab s has landed once at most (slabs issued after it) * G of this wave's DMAs are still outstanding
+        const int later = issued - s - 1;
+        if (NSTAGE >= 4 && later >= 2) wait_vmcnt<(NSTAGE >= 4 ? 2 * G : 0)>();
+        else if (NSTAGE >= 3 && later >= 1) wait_vmcnt<(NSTAGE >= 3 ? G : 0)>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();  // everyone's slab-s pieces landed; everyone is done reading slab s-1
+        if (issued < total) {
+            issue_next(nxt);  // into the stage slab s-1 occupied
+            ++issued;
+        }
+        const char *st = smem + cur * STAGE;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 a[3][MT], b[3][NT];
+            const char *ap = st + (ks ? a_lane1 : a_lane0);
+            const char *bp = st + (ks ? b_lane1 : b_lane0);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b[pl][nt] = *reinterpret_cast<const uint4 *>(bp + nt * 6144 + pl * 1024);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[pl][mt] = *reinterpret_cast<const uint4 *>(ap + mt * 6144 + pl * 1024);
+            }
+            // six products, smallest first: (a0,b2) (a2,b0) (a1,b1) (a0,b1) (a1,b0) (a0,b0)
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        constexpr int PA_OF[6] = {0, 2, 1, 0, 1, 0}, PB_OF[6] = {2, 0, 1, 1, 0, 0};
+                        acc[mt][nt] = mfma16(a[PA_OF[term]][mt], b[PB_OF[term]][nt], acc[mt][nt]);
+                    }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+        nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
+    }
+    wait_vmcnt<0>();
+    __syncthreads();  // all waves out of the main loop: the ring is free for the epilogue
+
+    if (p.stat_partial) {
+        // BatchNorm batch statistics of the RAW output, one partial row per M-tile (rows >= M are zero: their taps all
+        // read the zero row)
+        float *red = reinterpret_cast<float *>(smem);  // [WARPS_M][2][BN]
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const float v = acc[mt][nt][reg];
+                    s1 += v;
+                    s2 += v * v;
+                }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 32) {
+                red[(wm * 2 + 0) * BN + wn * TNW + nt * 32 + lane] = s1;
+                red[(wm * 2 + 1) * BN + wn * TNW + nt * 32 + lane] = s2;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * BN; i += 64 * NW) {
+            const int which = i / BN, col = i - which * BN;
+            float a = 0.f;
+#pragma unroll
+            for (int q = 0; q < WARPS_M; ++q) a += red[(q * 2 + which) * BN + col];
+            if (n0 + col < p.K) p.stat_partial[((long)mt_i * 2 + which) * p.K + n0 + col] = a;
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: every wave bounces its 32 x 32 accumulator blocks through a private LDS patch and stores 16 B per lane
+    float *y = reinterpret_cast<float *>(p.y);
+    const float *res = reinterpret_cast<const float *>(p.res);
+    constexpr int PBLK = (NT >= 2) ? 2 : 1;
+    constexpr int PW = PBLK * 32, PITCH = PW + 4, C4 = PW / 4;
+    static_assert(NW * 32 * PITCH * 4 <= RING, "epilogue patches must fit the ring");
+    static_assert(NT % PBLK == 0, "column blocks per pass");
+    float *patch = reinterpret_cast<float *>(smem) + wave * 32 * PITCH;
+    const bool vec_ok = (!y || (p.ldy & 3) == 0) && ((p.K & 3) == 0) && (!res || (p.ldr & 3) == 0);
+    if (p.y3 && wg == 0)  // the zero row consumers point padded taps at
+        for (int i = tid; i < p.cc_out * 12; i += 64 * NW)
+            *reinterpret_cast<uint4 *>(p.y3 + (long)p.M * p.cc_out * 192 + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int ntp = 0; ntp < NT; ntp += PBLK) {
+#pragma unroll
+            for (int q = 0; q < PBLK; ++q)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                    patch[row * PITCH + q * 32 + (lane & 31)] = acc[mt][ntp + q][reg];
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int it = 0; it < (32 * C4) / 64; ++it) {
+                const int idx = it * 64 + lane;
+                const int row = idx / C4, c4 = idx - row * C4;
+                const int m = m0 + wm * TMW + mt * 32 + row;
+                const int k = n0 + wn * TNW + ntp * 32 + c4 * 4;
+                if (m >= p.M || k >= p.K) continue;
+                long mo = m;
+                if (p.o_mul != 1) {
+                    const int n = m / ohw, rem = m - n * ohw;
+                    const int ohs = rem / p.OWs;
+                    mo = ((long)n * p.OH + ohs * p.o_mul + p.oy_add) * p.OW + (rem - ohs * p.OWs) * p.o_mul + p.ox_add;
+                }
+                f32x4 v = *reinterpret_cast<const f32x4 *>(patch + row * PITCH + c4 * 4);
+                if (vec_ok) {
+                    if (p.scale) v *= *reinterpret_cast<const f32x4 *>(p.scale + k);
+                    if (p.shift) v += *reinterpret_cast<const f32x4 *>(p.shift + k);
+                    if (res) v += *reinterpret_cast<const f32x4 *>(res + mo * p.ldr + k);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+                    if (y) *reinterpret_cast<f32x4 *>(y + mo * p.ldy + k) = v;
+                    if (p.y3) {
+                        uint2 q0, q1, q2;
+                        split3_4(v, q0, q1, q2);
+                        char *d = p.y3 + (mo * p.cc_out + (k >> 5)) * 192 + (k & 31) * 2;
+                        *reinterpret_cast<uint2 *>(d) = q0;
+                        *reinterpret_cast<uint2 *>(d + 64) = q1;
+                        *reinterpret_cast<uint2 *>(d + 128) = q2;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (k + e >= p.K) break;
+                        float u = v[e] * (p.scale ? p.scale[k + e] : 1.f) + (p.shift ? p.shift[k + e] : 0.f);
+                        if (res) u += res[mo * p.ldr + k + e];
+                        y[mo * p.ldy + k + e] = apply_act(u, p.act);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// f32 rows [M][ld] (C real channels) -> x3 rows [M + 1][CC][192]; channels >= C and row M are zero.
+// One thread per 8 channels: two 16-B loads, three 16-B stores.  HBM-bound: 4 B read + 6 B written per element.
+__global__ __launch_bounds__(256) void split3_rows_kernel(const float *__restrict__ x, long ld, char *__restrict__ out, long M, int C, int CC,
+                                                          const float *__restrict__ nc_scale, long rows_per_image) {
+    const long units = (M + 1) * CC * 4;  // 8-channel units
+    for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (long)gridDim.x * blockDim.x) {
+        const int oct = (int)(u & 3);
+        const long rc = u >> 2;
+        const int cc = (int)(rc % CC);
+        const long m = rc / CC;
+        const int c = cc * 32 + oct * 8;
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+        if (m < M) {
+            const float *src = x + m * ld + c;
+            if (c + 4 <= C) v0 = *reinterpret_cast<const f32x4 *>(src);
+            else
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < C) v0[e] = src[e];
+            if (c + 8 <= C) v1 = *reinterpret_cast<const f32x4 *>(src + 4);
+            else
+                for (int e = 0; e < 4; ++e)
+                    if (c + 4 + e < C) v1[e] = src[4 + e];
+            if (nc_scale) {  // Dropout2d mask of the producer: per (image, channel) multipliers {0, 1/(1-p)}
+                const float *sc = nc_scale + (m / rows_per_image) * C + c;
+                for (int e = 0; e < 4; ++e) {
+                    if (c + e < C) v0[e] *= sc[e];
+                    if (c + 4 + e < C) v1[e] *= sc[4 + e];
+                }
+            }
+        }
+        uint2 a0, a1, a2, b0, b1, b2;
+        split3_4(v0, a0, a1, a2);
+        split3_4(v1, b0, b1, b2);
+        char *d = out + (m * CC + cc) * 192 + oct * 16;
+        *reinterpret_cast<uint4 *>(d) = make_uint4(a0.x, a0.y, b0.x, b0.y);
+        *reinterpret_cast<uint4 *>(d + 64) = make_uint4(a1.x, a1.y, b1.x, b1.y);
+        *reinterpret_cast<uint4 *>(d + 128) = make_uint4(a2.x, a2.y, b2.x, b2.y);
+    }
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE> int launch_x3(X3P &p, hipStream_t st) {
+    p.mtiles = (p.M + BM - 1) / BM;
+    p.ntiles = (p.K + BN - 1) / BN;
+    hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE>), dim3(p.mtiles * p.ntiles), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+// tile choice: the same wave-quantisation cost model as conv_igemm.hip (workgroups are dealt over 256 CUs, the busiest CU
+// decides); efficiencies from tools/conv_sweep.py --x3
+static int g_x3_force = -1;  // tuning / test knob: dass_x3_force_tile(); -1 = take DASS_X3_TILE from the environment once
+
+static int dispatch_x3(X3P &p, hipStream_t st) {
+    if (g_x3_force < 0) g_x3_force = getenv("DASS_X3_TILE") ? atoi(getenv("DASS_X3_TILE")) : 0;
+    const int force = g_x3_force;
+    auto cost = [&](int bm, int bn, double eff, int per_cu) {
+        const long wgs = (long)((p.M + bm - 1) / bm) * ((p.K + bn - 1) / bn);
+        const long rounds = (wgs + 256 * per_cu - 1) / (256 * per_cu);
+        return (double)rounds * per_cu * bm * bn / eff;
+    };
+    int pick = force;
+    if (!pick) {
+        const double c1 = p.K > 64 ? cost(256, 128, 1.0, 1) : 1e30;
+        const double c2 = p.K > 64 ? cost(128, 128, 0.95, 1) : 1e30;
+        const double c3 = cost(128, 64, 0.85, 2);
+        const double c4 = cost(64, 64, 0.75, 2);
+        pick = 1;
+        double best = c1;
+        if (c2 < best) { best = c2; pick = 2; }
+        if (c3 < best) { best = c3; pick = 3; }
+        if (c4 < best) { best = c4; pick = 4; }
+    }
+    switch (pick) {
+    case 1: return launch_x3<256, 128, 4, 2, 2>(p, st);
+    case 2: return launch_x3<128, 128, 4, 2, 3>(p, st);
+    case 3: return launch_x3<128, 64, 4, 1, 2>(p, st);
+    case 5: return launch_x3<128, 128, 2, 2, 3>(p, st);
+    case 6: return launch_x3<64, 64, 2, 2, 3>(p, st);
+    case 7: return launch_x3<128, 128, 4, 2, 2>(p, st);
+    default: return launch_x3<64, 64, 2, 2, 2>(p, st);
+    }
+}
+
+}  // namespace
+
+extern "C" int dass_x3_force_tile(int tile) {
+    g_x3_force = tile < 0 ? 0 : tile;
+    return DASS_OK;
+}
+
+extern "C" int64_t dass_x3_bytes(int64_t rows, int C) { return (rows + 1) * ((C + 31) / 32) * 192; }
+
+extern "C" int dass_split3_rows(const float *x, int64_t ld, void *out, int64_t M, int C, const float *nc_scale, int64_t rows_per_image,
+                                void *stream) {
+    if (!x || !out || M <= 0 || C <= 0 || ld < C) return DASS_ERR_ARG;
+    if ((ld & 3) || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return DASS_ERR_ARG;
+    if (nc_scale && (rows_per_image <= 0 || (C & 3))) return DASS_ERR_ARG;
+    const int CC = (C + 31) / 32;
+    hipLaunchKernelGGL(split3_rows_kernel, dim3(dass_grid_1d((M + 1) * CC * 4, 256)), dim3(256), 0, (hipStream_t)stream, x, (long)ld,
+                       (char *)out, (long)M, C, CC, nc_scale, (long)rows_per_image);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_conv2d_x3(const void *x3, const void *w3, void *y, int64_t ldy, void *y3, const float *scale, const float *shift,
+                              const void *residual, int64_t ldr, int N, int H, int W, int C, int OH, int OW, int K, int R, int S,
+                              int stride, int pad, int dil, int ustride, int act, float *stat_partial, int *stat_rows, void *stream) {
+    if (!x3 || !w3 || (!y && !y3)) return DASS_ERR_ARG;
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || K <= 0 || R <= 0 || S <= 0) return DASS_ERR_ARG;
+    if (R * S > 64 || stride < 1 || dil < 1 || ustride < 1 || ustride > 8) return DASS_ERR_ARG;
+    if (((uintptr_t)x3 & 15) || ((uintptr_t)w3 & 15) || ((uintptr_t)y3 & 15)) return DASS_ERR_ARG;
+    if ((long)N * OH * OW >= (1l << 31)) return DASS_ERR_ARG;
+    const int CC = (C + 31) / 32;
+    const long xbytes = ((long)N * H * W + 1) * CC * 192, wbytes = (long)K * R * S * CC * 192;
+    if (xbytes >= (1l << 32) || wbytes >= (1l << 32)) return DASS_ERR_UNSUPPORTED;  // 32-bit buffer offsets
+    if (y3 && (K & 3)) return DASS_ERR_ARG;
+    if (!y && residual && (ldr & 3)) return DASS_ERR_ARG;
+    X3P p;
+    p.x3 = (const char *)x3;
+    p.w3 = (const char *)w3;
+    p.y = (char *)y;
+    p.y3 = (char *)y3;
+    p.scale = scale;
+    p.shift = shift;
+    p.res = (const char *)residual;
+    p.stat_partial = stat_partial;
+    p.ldy = ldy;
+    p.ldr = ldr;
+    p.x3_bytes = (unsigned)xbytes;
+    p.w3_bytes = (unsigned)wbytes;
+    p.zero_off = (unsigned)((long)N * H * W * CC * 192);
+    p.row_pitch = (unsigned)(CC * 192);
+    p.cc_out = (K + 31) / 32;
+    p.N = N; p.H = H; p.W = W; p.CC = CC; p.OH = OH; p.OW = OW; p.K = K; p.R = R; p.S = S;
+    p.stride = stride; p.pad = pad; p.dil = dil; p.act = act; p.ustride = ustride;
+    p.M = N * OH * OW;
+    p.OHs = OH; p.OWs = OW; p.o_mul = 1; p.oy_add = 0; p.ox_add = 0;
+    p.tap_allow = ~0ull;
+    hipStream_t st = (hipStream_t)stream;
+    if (ustride > 1) {
+        // dgrad of a strided conv, phase-decomposed exactly like conv_igemm.hip: one launch per output parity phase
+        if (stride != 1 || scale || shift || residual || act != DASS_ACT_NONE || stat_partial || y3 || !y) return DASS_ERR_UNSUPPORTED;
+        if (ldy != K) return DASS_ERR_UNSUPPORTED;
+        bool any_empty = false;
+        unsigned long long masks[8][8];
+        for (int py = 0; py < ustride; ++py)
+            for (int px = 0; px < ustride; ++px) {
+                unsigned long long mk = 0ull;
+                for (int r = 0; r < R; ++r)
+                    for (int s2 = 0; s2 < S; ++s2) {
+                        const int ty = py - pad + r * dil, tx = px - pad + s2 * dil;
+                        if (((ty % ustride) + ustride) % ustride == 0 && ((tx % ustride) + ustride) % ustride == 0) mk |= 1ull << (r * S + s2);
+                    }
+                masks[py][px] = mk;
+                if (!mk && py < OH && px < OW) any_empty = true;
+            }
+        if (any_empty && hipMemsetAsync(y, 0, sizeof(float) * (size_t)N * OH * OW * K, st) != hipSuccess) return DASS_ERR_LAUNCH;
+        for (int py = 0; py < ustride; ++py)
+            for (int px = 0; px < ustride; ++px) {
+                if (!masks[py][px] || py >= OH || px >= OW) continue;
+                X3P q = p;
+                q.OHs = (OH - py + ustride - 1) / ustride;
+                q.OWs = (OW - px + ustride - 1) / ustride;
+                q.o_mul = ustride; q.oy_add = py; q.ox_add = px;
+                q.tap_allow = masks[py][px];
+                q.M = N * q.OHs * q.OWs;
+                const int rc = dispatch_x3(q, st);
+                if (rc != DASS_OK) return rc;
+            }
+        return DASS_OK;
+    }
+    const int rc = dispatch_x3(p, st);
+    if (stat_rows) *stat_rows = p.mtiles;
+    return rc;
+}

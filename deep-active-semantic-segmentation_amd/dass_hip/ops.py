@@ -124,6 +124,30 @@ def conv_launch(x, ldx, w_op, y, ldy, dims, scale=None, shift=None, residual=Non
                                 _cdt(y), _stream()), "dass_conv2d_igemm")
 
 
+# ----------------------------------------------------------------------------- pre-split ("x3") operands
+def x3_alloc(nrows, c, device):
+    """uninitialised x3 buffer for a [rows][c] activation: rows x ceil(c/32) slabs of 192 B + one zero row"""
+    return torch.empty((lib.dass_x3_bytes(nrows, c),), dtype=torch.uint8, device=device)
+
+
+def split3_rows(x, ld, m, c, nc_scale=None, rows_per_image=1):
+    """f32 pixel rows -> x3 rows (the operand of dass_conv2d_x3); nc_scale: [N,C] Dropout2d multipliers of the producer"""
+    out = x3_alloc(m, c, x.device)
+    check(lib.dass_split3_rows(_p(x), ld, _p(out), m, c, _p(nc_scale), rows_per_image, _stream()), "dass_split3_rows")
+    return out
+
+
+def conv_x3_launch(x3, w3, y, ldy, dims, y3=None, scale=None, shift=None, residual=None, ldr=0, act=ACT_NONE, ustride=1,
+                   stats=None):
+    """dims as conv_launch; stats: None or a [rows, 2, K] f32 buffer -> returns the number of partial rows written"""
+    n, h, w, c, oh, ow, k, r, s, stride, pad, dil = dims
+    nrows = ctypes.c_int(0)
+    check(lib.dass_conv2d_x3(_p(x3), _p(w3), _p(y), ldy, _p(y3), _p(scale), _p(shift), _p(residual), ldr, n, h, w, c, oh, ow, k,
+                             r, s, stride, pad, dil, ustride, act, _p(stats), ctypes.byref(nrows) if stats is not None else None,
+                             _stream()), "dass_conv2d_x3")
+    return nrows.value
+
+
 def channel_stats(x, ld, m, k):
     nrows = lib.dass_stat_rows(m)
     partial = torch.empty((nrows, 2, k), dtype=torch.float32, device=x.device)

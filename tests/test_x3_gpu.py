@@ -1,0 +1,174 @@
+"""The pipelined pre-split conv engine (csrc/conv_x3.hip: LDS-DMA ring, counted vmcnt, one barrier per slab) against an
+f64 convolution computed outside the kernel, for every tile variant: forward with the fused epilogue options, BN partial
+sums, x3 output, dgrad (stride 1 and phase-decomposed stride 2), ragged M / K / C edges and dilations whose taps fall
+entirely into the padding."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# (N, C, H, W, K, ksize, stride, pad, dil)
+CASES = [(2, 304, 33, 33, 256, 3, 1, 1, 1),      # C = 9.5 slabs (zero-padded tail), decoder shape at 33^2
+         (2, 256, 33, 33, 256, 3, 1, 6, 6),      # dilation 6 on a 33-map: border tiles skip taps
+         (1, 512, 33, 33, 256, 3, 1, 18, 18),    # dilation 18: most taps fall in the padding
+         (3, 1024, 17, 17, 256, 1, 1, 0, 1),     # 1x1, M = 867 (ragged last tile)
+         (2, 64, 31, 29, 72, 1, 1, 0, 1),        # K = 72: ragged N tile, K % 32 != 0
+         (2, 128, 35, 35, 128, 3, 2, 1, 1),      # stride 2
+         (2, 48, 19, 23, 40, 3, 1, 1, 1),        # C = 48 (1.5 slabs), K = 40
+         (1, 96, 9, 9, 320, 1, 1, 2, 1)]         # 1x1 over a zero-padded border (MobileNet fixed_padding form)
+TILES = [1, 2, 3, 4, 5, 6, 7]
+
+
+@pytest.fixture(autouse=True)
+def _engine():
+    from dass_hip import ops
+    from dass_hip._lib import lib
+
+    mode, dt = ops.f32_mma(), ops.compute_dtype()
+    ops.set_compute_dtype(torch.float32)
+    ops.set_f32_mma("bf16x6")
+    yield
+    lib.dass_x3_force_tile(0)
+    ops.set_f32_mma(mode)
+    ops.set_compute_dtype(dt)
+
+
+def _inputs(case):
+    n, c, h, wd, k, ks, stride, pad, dil = case
+    g = torch.Generator().manual_seed(c * 7 + k)
+    x = torch.randn(n, c, h, wd, generator=g)
+    w = torch.randn(k, c, ks, ks, generator=g) * (2.0 / (c * ks * ks)) ** 0.5
+    return x, w
+
+
+def _x3_of(ops, t_nchw):
+    n, c, h, w = t_nchw.shape
+    rows = t_nchw.permute(0, 2, 3, 1).contiguous().cuda()
+    return ops.split3_rows(rows, c, n * h * w, c)
+
+
+def _decode_x3(buf, rows, c):
+    """x3 bytes -> f32 [rows, c] (x0 + x1 + x2), and the raw zero row"""
+    cc = (c + 31) // 32
+    v = buf.view(torch.bfloat16).view(rows + 1, cc, 3, 32).float()
+    full = (v[:, :, 0] + v[:, :, 1]) + v[:, :, 2]
+    return full[:rows].reshape(rows, cc * 32)[:, :c], v[rows]
+
+
+def _rel(a, ref):
+    return (a.double().cpu() - ref).norm().item() / max(ref.norm().item(), 1e-30)
+
+
+def test_split3_rows_is_exact():
+    from dass_hip import ops
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(37, 72, generator=g) * torch.logspace(-6, 4, 72)[None]
+    x[0, :4] = torch.tensor([0.0, -0.0, 1e-30, 65504.0])
+    xr = x.cuda()
+    buf = ops.split3_rows(xr, 72, 37, 72)
+    back, zero = _decode_x3(buf, 37, 72)
+    assert torch.equal(back.cpu(), x), (back.cpu() - x).abs().max()     # three bf16 parts carry all 24 significand bits
+    assert float(zero.abs().max()) == 0.0
+    cc = 3
+    v = buf.view(torch.bfloat16).view(38, cc, 3, 32)
+    assert float(v[:37, 2, :, 8:].float().abs().max()) == 0.0           # channels 72..95 of the last slab are zero
+    mask = (torch.rand(1, 72, generator=g) > 0.5).float() * 2.0
+    buf2 = ops.split3_rows(xr, 72, 37, 72, nc_scale=mask.cuda(), rows_per_image=37)
+    assert torch.equal(_decode_x3(buf2, 37, 72)[0].cpu(), x * mask)
+
+
+@pytest.mark.parametrize("tile", TILES)
+@pytest.mark.parametrize("case", CASES)
+def test_x3_forward_vs_f64(case, tile):
+    from dass_hip import ops
+    from dass_hip._lib import lib
+
+    lib.dass_x3_force_tile(tile)
+    n, c, h, wd, k, ks, stride, pad, dil = case
+    x, w = _inputs(case)
+    oh, ow = ops.conv_out_size(h, ks, stride, pad, dil), ops.conv_out_size(wd, ks, stride, pad, dil)
+    x3 = _x3_of(ops, x)
+    w3 = ops.prepare_conv_weight(w.permute(0, 2, 3, 1).contiguous().cuda())
+    dims = (n, h, wd, c, oh, ow, k, ks, ks, stride, pad, dil)
+    ref = F.conv2d(x.double(), w.double(), None, stride, pad, dil).permute(0, 2, 3, 1)
+    y = torch.full((n, oh, ow, k), float("nan"), device="cuda")
+    ops.conv_x3_launch(x3, w3, y, k, dims)
+    assert _rel(y, ref) <= 2e-6, (case, tile, _rel(y, ref))
+    assert (y.double().cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    # the classic engine accumulates the same products in the same order: results agree to the last bit or two
+    y_old = torch.empty_like(y)
+    xr = x.permute(0, 2, 3, 1).contiguous().cuda()
+    if c % 4 == 0:
+        ops.conv_launch(xr, c, w3, y_old, k, dims)
+        assert (y - y_old).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("tile", [1, 2, 4])
+def test_x3_epilogue_stats_and_x3_output(tile):
+    from dass_hip import ops
+    from dass_hip._lib import lib
+
+    lib.dass_x3_force_tile(tile)
+    case = (2, 96, 21, 19, 136, 3, 1, 2, 2)
+    n, c, h, wd, k, ks, stride, pad, dil = case
+    x, w = _inputs(case)
+    g = torch.Generator().manual_seed(11)
+    scale, shift = torch.rand(k, generator=g) + 0.5, torch.randn(k, generator=g)
+    oh, ow = ops.conv_out_size(h, ks, stride, pad, dil), ops.conv_out_size(wd, ks, stride, pad, dil)
+    res = torch.randn(n, oh, ow, k, generator=g)
+    x3, w3 = _x3_of(ops, x), ops.prepare_conv_weight(w.permute(0, 2, 3, 1).contiguous().cuda())
+    dims = (n, h, wd, c, oh, ow, k, ks, ks, stride, pad, dil)
+    raw = F.conv2d(x.double(), w.double(), None, stride, pad, dil).permute(0, 2, 3, 1)
+    ref = torch.relu(raw * scale.double() + shift.double() + res.double())
+    m = n * oh * ow
+    y = torch.empty((n, oh, ow, k), device="cuda")
+    y3 = ops.x3_alloc(m, k, "cuda")
+    y3.fill_(0x7f)
+    ops.conv_x3_launch(x3, w3, y, k, dims, y3=y3, scale=scale.cuda(), shift=shift.cuda(), residual=res.cuda(), ldr=k, act=ops.ACT_RELU)
+    assert _rel(y, ref) <= 2e-6
+    back, zero = _decode_x3(y3, m, k)
+    assert torch.equal(back.reshape(n, oh, ow, k), y), "the x3 rows are the exact split of the f32 result"
+    assert float(zero.abs().max()) == 0.0
+    # the x3 result feeds the next conv directly: y3-only output, 1x1 consumer
+    w2 = torch.randn(64, k, 1, 1, generator=g) * 0.1
+    y2 = torch.empty((n, oh, ow, 64), device="cuda")
+    ops.conv_x3_launch(y3, ops.prepare_conv_weight(w2.permute(0, 2, 3, 1).contiguous().cuda()), y2, 64, (n, oh, ow, k, oh, ow, 64, 1, 1, 1, 0, 1))
+    ref2 = F.conv2d(y.permute(0, 3, 1, 2).double().cpu(), w2.double()).permute(0, 2, 3, 1)
+    assert _rel(y2, ref2) <= 2e-6
+    # BatchNorm partial sums of the raw output
+    rows = lib.dass_conv2d_igemm_stats_rows(m)
+    part = torch.zeros((rows, 2, k), device="cuda")
+    yr = torch.empty((n, oh, ow, k), device="cuda")
+    nrows = ops.conv_x3_launch(x3, w3, yr, k, dims, stats=part)
+    assert 1 <= nrows <= rows
+    sums = part[:nrows].double().sum(0).cpu()
+    flat = raw.reshape(m, k)
+    assert (sums[0] - flat.sum(0)).abs().max().item() <= 1e-4 * flat.abs().sum(0).max().item()
+    assert (sums[1] - (flat * flat).sum(0)).abs().max().item() <= 1e-4 * (flat * flat).sum(0).max().item()
+
+
+@pytest.mark.parametrize("tile", TILES)
+@pytest.mark.parametrize("case", [(2, 64, 33, 33, 96, 3, 1, 1, 1), (2, 128, 35, 35, 128, 3, 2, 1, 1), (2, 256, 17, 17, 512, 1, 2, 0, 1),
+                                  (1, 64, 33, 33, 64, 3, 1, 4, 4)])
+def test_x3_dgrad_vs_f64(case, tile):
+    """input gradient = the same kernel over dy (x3) and the transposed weight operand; stride 2 is phase-decomposed"""
+    from dass_hip import ops
+    from dass_hip._lib import lib
+
+    lib.dass_x3_force_tile(tile)
+    n, c, h, wd, k, ks, stride, pad, dil = case
+    x, w = _inputs(case)
+    oh, ow = ops.conv_out_size(h, ks, stride, pad, dil), ops.conv_out_size(wd, ks, stride, pad, dil)
+    g = torch.Generator().manual_seed(5)
+    dy = torch.randn(n, k, oh, ow, generator=g)
+    xd = x.double().requires_grad_(True)
+    F.conv2d(xd, w.double(), None, stride, pad, dil).backward(dy.double())
+    ref = xd.grad.permute(0, 2, 3, 1)
+    dy3 = _x3_of(ops, dy)
+    wt3 = ops.prepare_conv_weight(w.permute(0, 2, 3, 1).contiguous().cuda(), mode=1)
+    dx = torch.full((n, h, wd, c), float("nan"), device="cuda")
+    pad_t = dil * (ks - 1) - pad
+    ops.conv_x3_launch(dy3, wt3, dx, c, (n, oh, ow, k, h, wd, c, ks, ks, 1, pad_t, dil), ustride=stride)
+    assert _rel(dx, ref) <= 2e-6, (case, tile, _rel(dx, ref))
