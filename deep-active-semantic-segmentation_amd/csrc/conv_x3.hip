@@ -189,36 +189,37 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // ---- slab iterator of the LOADER (channel slab outer, active taps inner: the 9 taps of a 3x3 re-read the same
-    // neighbourhood back to back, so the re-reads are L2 hits)
+    // neighbourhood back to back, so the re-reads are L2 hits).  The uniform offsets of the NEXT slab to issue are
+    // computed one slab ahead (the tap table lives in LDS: its read must not sit in front of a DMA issue).
     unsigned long long it_mask = tapmask;
-    int it_cc = 0;
-    auto issue_next = [&](int stage) {
+    int it_cc = 0, nx_t = 0;
+    unsigned nx_a_uni = 0u, nx_b_uni = 0u;
+    auto advance = [&]() {
         if (!it_mask) {
             ++it_cc;
             it_mask = tapmask;
         }
-        const int t = __builtin_ctzll(it_mask);
+        nx_t = __builtin_ctzll(it_mask);
         it_mask &= it_mask - 1;
+        nx_a_uni = tap_delta[nx_t] + (unsigned)(it_cc * 192);
+        nx_b_uni = (unsigned)((nx_t * p.CC + it_cc) * 192);
+    };
+    auto issue_rowgroup = [&](int j, int stage) {  // the three parts of rowgroup wave + j * NW of the next slab
         const unsigned st = smem_base + (unsigned)(stage * STAGE);
-        const unsigned a_uni = tap_delta[t] + (unsigned)(it_cc * 192);
-        const unsigned b_uni = (unsigned)((t * p.CC + it_cc) * 192);
-#pragma unroll
-        for (int j = 0; j < RG; ++j) {
-            const int q = wave + j * NW;
-            if (q < AG) {
-                const bool valid = (vmask[j] >> t) & 1ull;
-                const unsigned voff = valid ? rb_off[j] + a_uni : p.zero_off + chunk_off;
-                const unsigned dst = __builtin_amdgcn_readfirstlane(st + q * 3072);
-                dma16(rsa, dst, voff);
-                dma16(rsa, dst + 1024, voff + 64);
-                dma16(rsa, dst + 2048, voff + 128);
-            } else {
-                const unsigned voff = rb_off[j] + b_uni;
-                const unsigned dst = __builtin_amdgcn_readfirstlane(st + A_BYTES + (q - AG) * 3072);
-                dma16(rsb, dst, voff);
-                dma16(rsb, dst + 1024, voff + 64);
-                dma16(rsb, dst + 2048, voff + 128);
-            }
+        const int q = wave + j * NW;
+        if (q < AG) {
+            const bool valid = (vmask[j] >> nx_t) & 1ull;
+            const unsigned voff = valid ? rb_off[j] + nx_a_uni : p.zero_off + chunk_off;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(st + q * 3072);
+            dma16(rsa, dst, voff);
+            dma16(rsa, dst + 1024, voff + 64);
+            dma16(rsa, dst + 2048, voff + 128);
+        } else {
+            const unsigned voff = rb_off[j] + nx_b_uni;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(st + A_BYTES + (q - AG) * 3072);
+            dma16(rsb, dst, voff);
+            dma16(rsb, dst + 1024, voff + 64);
+            dma16(rsb, dst + 2048, voff + 128);
         }
     };
 
@@ -233,13 +234,46 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
 
     // ---- prologue: NSTAGE - 1 slabs in flight
     int issued = 0;
+    if (total > 0) advance();
 #pragma unroll
     for (int sg = 0; sg < NSTAGE - 1; ++sg)
         if (issued < total) {
-            issue_next(sg);
-            ++issued;
+#pragma unroll
+            for (int j = 0; j < RG; ++j) issue_rowgroup(j, sg);
+            if (++issued < total) advance();
         }
 
+    // ---- main loop, skewed by half a slab: the fragments of slab s / k-step 0 are read while the MFMAs of slab s-1 /
+    // k-step 1 (operands already in registers) run, and those of k-step 1 while k-step 0 multiplies, so the LDS read
+    // latency is covered; the DMA issue of the slab NSTAGE-1 ahead is cut into its rowgroups and placed BETWEEN the
+    // MFMA groups of the first half (an in-order wave issues them in the shadow of the running MFMAs).
+    uint4 a0[3][MT], b0[3][NT], a1[3][MT], b1[3][NT];
+    auto load_frags = [&](const char *ap, const char *bp, uint4(&a)[3][MT], uint4(&b)[3][NT]) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[pl][nt] = *reinterpret_cast<const uint4 *>(bp + nt * 6144 + pl * 1024);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[pl][mt] = *reinterpret_cast<const uint4 *>(ap + mt * 6144 + pl * 1024);
+        }
+    };
+    // six products, smallest first: (a0,b2) (a2,b0) (a1,b1) (a0,b1) (a1,b0) (a0,b0); `between(term)` runs after each group
+    auto multiply = [&](const uint4(&a)[3][MT], const uint4(&b)[3][NT], auto between) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int term = 0; term < 6; ++term) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    constexpr int PA_OF[6] = {0, 2, 1, 0, 1, 0}, PB_OF[6] = {2, 0, 1, 1, 0, 0};
+                    acc[mt][nt] = mfma16(a[PA_OF[term]][mt], b[PB_OF[term]][nt], acc[mt][nt]);
+                }
+            between(term);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto nothing = [](int) {};
     int cur = 0, nxt = NSTAGE - 1;  // stage being computed / stage the next issue goes to
     for (int s = 0; s < total; ++s) {
         // slab s has landed once at most (slabs issued after it) * G of this wave's DMAs are still outstanding
@@ -247,40 +281,30 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
         if (NSTAGE >= 4 && later >= 2) wait_vmcnt<(NSTAGE >= 4 ? 2 * G : 0)>();
         else if (NSTAGE >= 3 && later >= 1) wait_vmcnt<(NSTAGE >= 3 ? G : 0)>();
         else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of slab s-1 have returned (WAR on its stage)
         __builtin_amdgcn_s_barrier();  // everyone's slab-s pieces landed; everyone is done reading slab s-1
-        if (issued < total) {
-            issue_next(nxt);  // into the stage slab s-1 occupied
-            ++issued;
-        }
         const char *st = smem + cur * STAGE;
-        __builtin_amdgcn_s_setprio(1);
+        load_frags(st + a_lane0, st + b_lane0, a0, b0);
+        const bool more = issued < total;  // block-uniform
+        if (s > 0) {
+            multiply(a1, b1, [&](int term) {  // slab s-1, k-step 1
+                if (more && term < RG) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_rowgroup(term, nxt);  // into the stage slab s-1 occupied
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        } else if (more) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            uint4 a[3][MT], b[3][NT];
-            const char *ap = st + (ks ? a_lane1 : a_lane0);
-            const char *bp = st + (ks ? b_lane1 : b_lane0);
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) b[pl][nt] = *reinterpret_cast<const uint4 *>(bp + nt * 6144 + pl * 1024);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) a[pl][mt] = *reinterpret_cast<const uint4 *>(ap + mt * 6144 + pl * 1024);
-            }
-            // six products, smallest first: (a0,b2) (a2,b0) (a1,b1) (a0,b1) (a1,b0) (a0,b0)
-#pragma unroll
-            for (int term = 0; term < 6; ++term)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        constexpr int PA_OF[6] = {0, 2, 1, 0, 1, 0}, PB_OF[6] = {2, 0, 1, 1, 0, 0};
-                        acc[mt][nt] = mfma16(a[PA_OF[term]][mt], b[PB_OF[term]][nt], acc[mt][nt]);
-                    }
+            for (int j = 0; j < RG; ++j) issue_rowgroup(j, nxt);
         }
-        __builtin_amdgcn_s_setprio(0);
+        if (more && ++issued < total) advance();
+        load_frags(st + a_lane1, st + b_lane1, a1, b1);
+        multiply(a0, b0, nothing);
         cur = cur + 1 == NSTAGE ? 0 : cur + 1;
         nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
     }
+    if (total > 0) multiply(a1, b1, nothing);
     wait_vmcnt<0>();
     __syncthreads();  // all waves out of the main loop: the ring is free for the epilogue
 

@@ -19,7 +19,8 @@ from ._lib import check, lib
 F32, BF16, F32X3, F32X6 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 
-_state = {"dtype": torch.float32, "f32_mma": os.environ.get("DASS_F32_MMA", "bf16x6")}
+_state = {"dtype": torch.float32, "f32_mma": os.environ.get("DASS_F32_MMA", "bf16x6"),
+          "x3": os.environ.get("DASS_X3", "1") == "1"}
 assert _state["f32_mma"] in ("f32", "bf16x3", "bf16x6"), "DASS_F32_MMA must be f32, bf16x3 or bf16x6"
 
 
@@ -48,6 +49,18 @@ def set_f32_mma(mode):
 
 def f32_mma():
     return _state["f32_mma"]
+
+
+def set_x3_pipeline(on):
+    """bf16x6 engine only: True (default, DASS_X3=1) = dense convs run the pipelined pre-split kernel (csrc/conv_x3.hip:
+    activations converted ONCE to three bf16 parts by the producing pass, LDS-DMA ring, no conversion in the MFMA loop);
+    False = the classic kernel that converts inside its loop (csrc/conv_igemm.hip).  Same six products in the same
+    order either way: results agree to the last bit or two."""
+    _state["x3"] = bool(on)
+
+
+def x3_pipeline():
+    return _state["x3"] and _state["f32_mma"] == "bf16x6"
 
 
 def _cdt(t):
@@ -146,6 +159,20 @@ def conv_x3_launch(x3, w3, y, ldy, dims, y3=None, scale=None, shift=None, residu
                              r, s, stride, pad, dil, ustride, act, _p(stats), ctypes.byref(nrows) if stats is not None else None,
                              _stream()), "dass_conv2d_x3")
     return nrows.value
+
+
+def x3_operand(t, xs, ld, m, c, nc_scale=None, rows_per_image=1):
+    """x3 rows of activation `t` (xs = its NHWC row view): taken from the side buffer the producing pass attached to the
+    tensor (`t._dass_x3`, valid while the tensor is unmodified) or converted now by dass_split3_rows"""
+    if nc_scale is None:
+        hit = t.__dict__.get("_dass_x3") if hasattr(t, "__dict__") else None
+        if hit is not None and hit[0] == (t.data_ptr(), t._version, m, c):
+            return hit[1]
+    return split3_rows(xs, ld, m, c, nc_scale, rows_per_image)
+
+
+def attach_x3(t, buf, m, c):
+    t.__dict__["_dass_x3"] = ((t.data_ptr(), t._version, m, c), buf)
 
 
 def channel_stats(x, ld, m, k):
@@ -492,7 +519,29 @@ class _ConvBnAct(torch.autograd.Function):
         y_raw = None
         batch_stats = bn is not None and bn_use_batch_stats(bn)
         fuse = (not spec.depthwise) and (not rowtap) and (bn is None or (not batch_stats and not need_grad))
-        if fuse:
+        # pipelined pre-split engine: dense convs of the bf16x6 engine with enough output channels for its tiles
+        use_x3 = (x3_pipeline() and dt == torch.float32 and not spec.depthwise and not rowtap and not image_input and k > 32)
+        dims = (n, h, w, c, oh, ow, k, r, weight.shape[3], spec.stride, spec.pad, spec.dil)
+        if fuse and use_x3:
+            scale = shift = None
+            if bn is not None:
+                state = bn_eval_state(bn, k, dev)
+                scale, shift = state.scale, state.shift
+            elif bias is not None:
+                shift = bias.detach().float()
+            in_scale = getattr(spec, "in_scale", None)
+            if in_scale is not None:
+                assert not need_grad and tuple(in_scale.shape) == (n, c) and in_scale.dtype == torch.float32
+            x3 = x3_operand(x, xs, ldx, n * h * w, c, in_scale, h * w)
+            w_op = weight_operand(weight, 0, dt, cpad=c)
+            want_y3 = getattr(spec, "emit_x3", False) and nc_scale is None and kpad == k
+            y3 = x3_alloc(m, k, dev) if want_y3 else None
+            conv_x3_launch(x3, w_op, out, ldo, dims, y3=y3, scale=scale, shift=shift, residual=res_t, ldr=ldr or 0, act=spec.act)
+            if y3 is not None:
+                attach_x3(out, y3, m, k)
+            if nc_scale is not None:
+                scale_shift_act(out, ldo, out, ldo, m, k, None, None, nc_scale=nc_scale, rows_per_image=oh * ow)
+        elif fuse:
             scale = shift = None
             if bn is not None:
                 state = bn_eval_state(bn, k, dev)
@@ -513,7 +562,16 @@ class _ConvBnAct(torch.autograd.Function):
             assert k % 4 == 0, "BN epilogue needs K % 4 == 0"
             y_raw = new_act(n, k, oh, ow, dt, dev)
             fused_stats = None
-            if batch_stats and not spec.depthwise and not rowtap:
+            if use_x3:
+                x3 = x3_operand(x, xs, ldx, n * h * w, c)
+                w_op = weight_operand(weight, 0, dt, cpad=c)
+                partial = None
+                if batch_stats:
+                    partial = torch.empty((lib.dass_conv2d_igemm_stats_rows(m), 2, k), dtype=torch.float32, device=dev)
+                nrows = conv_x3_launch(x3, w_op, y_raw, k, dims, stats=partial)
+                if batch_stats:
+                    fused_stats = (partial, nrows)
+            elif batch_stats and not spec.depthwise and not rowtap:
                 # train-mode BN: the conv epilogue also emits the per-tile channel sums (no second read of y_raw)
                 rmax = lib.dass_conv2d_igemm_stats_rows(m)
                 partial = torch.empty((rmax, 2, k), dtype=torch.float32, device=dev)
@@ -673,9 +731,13 @@ class _ConvBnAct(torch.autograd.Function):
                 dx = new_act(n, c, h, w, dt, dev)
                 pad_t = spec.dil * (r - 1) - spec.pad
                 # dgrad = stride-1 conv over dy with flipped/transposed taps; ustride re-inserts the stride
-                check(lib.dass_conv2d_igemm(_p(dy), lddy, _p(w_t), _p(dx), c, None, None, None, 0, None, n, oh, ow,
-                                            kk, h, w, c, r, s, 1, pad_t, spec.dil, spec.stride, ACT_NONE, _cdt(dx),
-                                            _stream()), "dass_conv2d_igemm(dgrad)")
+                if x3_pipeline() and dt == torch.float32 and c > 32 and kk == k and lddy % 4 == 0:
+                    dy3 = x3_operand(dy, dy, lddy, m, kk)
+                    conv_x3_launch(dy3, w_t, dx, c, (n, oh, ow, kk, h, w, c, r, s, 1, pad_t, spec.dil), ustride=spec.stride)
+                else:
+                    check(lib.dass_conv2d_igemm(_p(dy), lddy, _p(w_t), _p(dx), c, None, None, None, 0, None, n, oh, ow,
+                                                kk, h, w, c, r, s, 1, pad_t, spec.dil, spec.stride, ACT_NONE, _cdt(dx),
+                                                _stream()), "dass_conv2d_igemm(dgrad)")
             if ctx.needs_input_grad[1] and getattr(spec, "rowtap", False):
                 dwk = torch.empty((k, r, s, c_in), dtype=torch.float32, device=dev)
                 check(lib.dass_conv2d_rowtap_wgrad(_p(xs), _p(dy), lddy, _p(dwk), n, h, w, c_in, oh, ow, k, r, s, spec.stride,

@@ -61,7 +61,7 @@ class Decoder(nn.Module):
     def _split_first_conv(self):
         conv = self.last_conv[0]
         wt = conv.weight
-        key = (wt.data_ptr(), wt._version, ops.f32_mma())
+        key = (wt.data_ptr(), wt._version, ops.f32_mma(), ops.x3_pipeline())
         hit = self.__dict__.get("_dass_split_w")
         if hit is None or hit[0] != key:
             krsc = wt.detach().float().permute(0, 2, 3, 1)
@@ -80,7 +80,10 @@ class Decoder(nn.Module):
         st = ops.bn_eval_state(self.last_conv[1], 256, feats.device)
         xb, ldb = ops.rows(feats[:, 256:])
         yb = ops.new_act(n, 256, h, w, torch.float32, feats.device)
-        ops.conv_launch(xb, ldb, wb, yb, 256, (n, h, w, 48, h, w, 256, 3, 3, 1, 1, 1), scale=st.scale)
+        if ops.x3_pipeline():
+            ops.conv_x3_launch(ops.split3_rows(xb, ldb, n * h * w, 48), wb, yb, 256, (n, h, w, 48, h, w, 256, 3, 3, 1, 1, 1), scale=st.scale)
+        else:
+            ops.conv_launch(xb, ldb, wb, yb, 256, (n, h, w, 48, h, w, 256, 3, 3, 1, 1, 1), scale=st.scale)
         return wa, st, yb
 
     def head_mc_pass(self, feats, prep, m1, m2):
@@ -91,8 +94,21 @@ class Decoder(nn.Module):
         n, c, h, w = feats.shape
         lc = self.last_conv
         xa, lda = ops.rows(feats[:, :256])
+        dims = (n, h, w, 256, h, w, 256, 3, 3, 1, 1, 1)
+        if ops.x3_pipeline():
+            # pre-split engine: the ASPP mask rides in the conversion pass of the 256 masked channels (exact: the
+            # multipliers are 0 and 2), the first conv hands its result to the second as x3 rows (no f32 round trip)
+            m = n * h * w
+            xa3 = ops.split3_rows(xa, lda, m, 256, nc_scale=m1.contiguous(), rows_per_image=h * w)
+            h1_3 = ops.x3_alloc(m, 256, feats.device)
+            ops.conv_x3_launch(xa3, wa, None, 0, dims, y3=h1_3, scale=st.scale, shift=st.shift, residual=yb, ldr=256, act=ops.ACT_RELU)
+            st2 = ops.bn_eval_state(lc[4], 256, feats.device)
+            h2 = ops.new_act(n, 256, h, w, torch.float32, feats.device)
+            ops.conv_x3_launch(h1_3, ops.weight_operand(lc[3].weight, 0, torch.float32, cpad=256), h2, 256, dims,
+                               scale=st2.scale, shift=st2.shift, act=ops.ACT_RELU)
+            return ops.conv_bn_act(h2, lc[7], in_scale=m2)
         h1 = ops.new_act(n, 256, h, w, torch.float32, feats.device)
-        ops.conv_launch(xa, lda, wa, h1, 256, (n, h, w, 256, h, w, 256, 3, 3, 1, 1, 1), scale=st.scale, shift=st.shift,
+        ops.conv_launch(xa, lda, wa, h1, 256, dims, scale=st.scale, shift=st.shift,
                         residual=yb, ldr=256, in_scale=m1.contiguous(), act=ops.ACT_RELU)
         h2 = ops.conv_bn_act(h1, lc[3], lc[4], ops.ACT_RELU)
         return ops.conv_bn_act(h2, lc[7], in_scale=m2)
