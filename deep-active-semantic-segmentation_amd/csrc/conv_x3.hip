@@ -34,11 +34,12 @@ struct X3P {
     const float *shift;
     const char *res;
     float *stat_partial;
+    float *ws;  // stream-K workspace: 2 slabs of BM x BN f32 per workgroup of the main launch
     long ldy, ldr;
     unsigned x3_bytes, w3_bytes, zero_off, row_pitch;  // row_pitch = CC * 192
     int cc_out;
     int N, H, W, CC, OH, OW, K, R, S, stride, pad, dil, act;
-    int M, mtiles, ntiles;
+    int M, mtiles, ntiles, sk_wgs;
     int OHs, OWs, o_mul, oy_add, ox_add, ustride;
     unsigned long long tap_allow;
 };
@@ -94,8 +95,52 @@ __device__ __forceinline__ void split3_4(f32x4 v, uint2 &p0, uint2 &p1, uint2 &p
     p2 = make_uint2(pk_bf16(sa), pk_bf16(sb));
 }
 
+// fused epilogue of ONE 4-channel group of output pixel m (tile-independent: used by the main kernel and the fix-up pass)
+__device__ __forceinline__ void x3_store_out(const X3P &p, f32x4 v, int m, int k, int ohw, bool vec_ok) {
+    float *y = reinterpret_cast<float *>(p.y);
+    const float *res = reinterpret_cast<const float *>(p.res);
+    long mo = m;  // output pixel index; differs from m only for a phase sub-grid
+    if (p.o_mul != 1) {
+        const int n = m / ohw, rem = m - n * ohw;
+        const int ohs = rem / p.OWs;
+        mo = ((long)n * p.OH + ohs * p.o_mul + p.oy_add) * p.OW + (rem - ohs * p.OWs) * p.o_mul + p.ox_add;
+    }
+    if (vec_ok) {
+        if (p.scale) v *= *reinterpret_cast<const f32x4 *>(p.scale + k);
+        if (p.shift) v += *reinterpret_cast<const f32x4 *>(p.shift + k);
+        if (res) v += *reinterpret_cast<const f32x4 *>(res + mo * p.ldr + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+        if (y) *reinterpret_cast<f32x4 *>(y + mo * p.ldy + k) = v;
+        if (p.y3) {
+            uint2 q0, q1, q2;
+            split3_4(v, q0, q1, q2);
+            char *d = p.y3 + (mo * p.cc_out + (k >> 5)) * 192 + (k & 31) * 2;
+            *reinterpret_cast<uint2 *>(d) = q0;
+            *reinterpret_cast<uint2 *>(d + 64) = q1;
+            *reinterpret_cast<uint2 *>(d + 128) = q2;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (k + e >= p.K) break;
+            float u = v[e] * (p.scale ? p.scale[k + e] : 1.f) + (p.shift ? p.shift[k + e] : 0.f);
+            if (res) u += res[mo * p.ldr + k + e];
+            y[mo * p.ldy + k + e] = apply_act(u, p.act);
+        }
+    }
+}
+
 // LDS image of one operand stage: rowgroup g (16 rows), part pl -> a 1 KiB piece at (g * 3 + pl) * 1024; inside a piece
 // row r16 / 16-B chunk c sits at r16 * 64 + ((c ^ ((r16 >> 2) & 3)) * 16).
+//
+// Work decomposition ("stream-K"): the unit of work is one 32-k slab of one output tile; the U = tiles * S units (S = CC *
+// taps, tile-major) are cut into p.sk_wgs EQUAL contiguous ranges, one per workgroup.  A workgroup walks its range tile by
+// tile ("segments").  A segment that covers its whole tile runs the fused epilogue; one that covers only part of it writes
+// its raw accumulators to a workspace slab, and conv_x3_fixup_kernel adds the slabs of such a tile in workgroup order
+// (deterministic) and runs the same epilogue.  With sk_wgs = CUs every CU gets the same number of slabs whatever the tile
+// count (M = 8712 layers: 138 tiles on 256 CUs; 133128-row layers: 1042 tiles = 4.07 rounds); with sk_wgs = tiles it
+// degenerates to one tile per workgroup and no workspace traffic.
 template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(const X3P p) {
     constexpr int NW = WARPS_M * WARPS_N;
@@ -111,9 +156,6 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     __shared__ __attribute__((aligned(16))) char smem[RING + 64 * 4];
     unsigned *tap_delta = reinterpret_cast<unsigned *>(smem + RING);
 
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int mt_i = wg / p.ntiles, nt_i = wg - mt_i * p.ntiles;
-    const int m0 = mt_i * BM, n0 = nt_i * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WARPS_N, wn = wave - wm * WARPS_N;
@@ -130,6 +172,35 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     const bool phase = p.o_mul != 1;
     auto tap_ey = [&](int r) -> int { return phase ? (p.oy_add - p.pad + r * p.dil) / p.ustride : r * p.dil; };
     auto tap_ex = [&](int s) -> int { return phase ? (p.ox_add - p.pad + s * p.dil) / p.ustride : s * p.dil; };
+    if (tid < ntaps) {
+        const int r = tid / p.S, s2 = tid - r * p.S;
+        tap_delta[tid] = (unsigned)(tap_ey(r) * p.W + tap_ex(s2)) * p.row_pitch;
+    }
+
+    // ---- fragment addresses: lane (r = lane & 31, h = lane >> 5) reads row r, chunk 2 ks + h of each part
+    const int fr = lane & 31, fh = lane >> 5;
+    const int fsw = ((fr & 15) >> 2) & 3;
+    const int f_row = (fr >> 4) * 3072 + (fr & 15) * 64;
+    const int a_lane0 = (wm * (TMW / 16)) * 3072 + f_row + (((0 + fh) ^ fsw) * 16);
+    const int a_lane1 = (wm * (TMW / 16)) * 3072 + f_row + (((2 + fh) ^ fsw) * 16);
+    const int b_lane0 = A_BYTES + (wn * (TNW / 16)) * 3072 + f_row + (((0 + fh) ^ fsw) * 16);
+    const int b_lane1 = A_BYTES + (wn * (TNW / 16)) * 3072 + f_row + (((2 + fh) ^ fsw) * 16);
+
+    // ---- this workgroup's range of (tile, slab) units
+    const int wgid = xcd_remap(blockIdx.x, gridDim.x);
+    const long S_tile = (long)p.CC * ntaps;
+    const long U = (long)p.mtiles * p.ntiles * S_tile;
+    const long u_begin = U * wgid / p.sk_wgs, u_end = U * (wgid + 1) / p.sk_wgs;
+    int seg_idx = 0;
+    for (long u = u_begin; u < u_end; ++seg_idx) {
+    const int tile = (int)(u / S_tile);
+    const int s_lo = (int)(u - (long)tile * S_tile);
+    const int s_hi = (int)((u_end - u) < (S_tile - s_lo) ? s_lo + (u_end - u) : S_tile);
+    u += s_hi - s_lo;
+    const bool complete = s_lo == 0 && s_hi == (int)S_tile;
+    const int mt_i = tile / p.ntiles, nt_i = tile - mt_i * p.ntiles;
+    const int m0 = mt_i * BM, n0 = nt_i * BN;
+    __syncthreads();  // the previous segment's epilogue is done with the ring; tap_delta is visible
 
     unsigned rb_off[RG];
     unsigned long long vmask[RG];
@@ -141,6 +212,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
         vmask[j] = 0ull;
         a_by[j] = a_bx[j] = 0;
         a_ok[j] = false;
+        rb_off[j] = 0u;
         if (q < AG) {
             const int m = m0 + q * 16 + r16;
             a_ok[j] = m < p.M;
@@ -165,7 +237,6 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
         if (!((p.tap_allow >> t) & 1ull)) continue;
         const int r = t / p.S, s = t - r * p.S;
         const int ey = tap_ey(r), ex = tap_ex(s);
-        if (tid == 0) tap_delta[t] = (unsigned)(ey * p.W + ex) * p.row_pitch;
         bool any = false;
 #pragma unroll
         for (int j = 0; j < RG; ++j) {
@@ -176,9 +247,14 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
         }
         if (__syncthreads_or((int)any)) tapmask |= (1ull << t);
     }
-    __syncthreads();  // tap_delta visible
 
-    const int total = __builtin_popcountll(tapmask) * p.CC;
+    // active slabs of [s_lo, s_hi): slab s = cc * ntaps + t (channel slab outer, taps inner)
+    const int pc = __builtin_popcountll(tapmask);
+    auto active_below = [&](int sidx) -> int {
+        const int cc = sidx / ntaps, t = sidx - cc * ntaps;
+        return cc * pc + __builtin_popcountll(tapmask & ((1ull << t) - 1ull));
+    };
+    const int total = active_below(s_hi) - active_below(s_lo);
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -188,11 +264,11 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // ---- slab iterator of the LOADER (channel slab outer, active taps inner: the 9 taps of a 3x3 re-read the same
-    // neighbourhood back to back, so the re-reads are L2 hits).  The uniform offsets of the NEXT slab to issue are
-    // computed one slab ahead (the tap table lives in LDS: its read must not sit in front of a DMA issue).
-    unsigned long long it_mask = tapmask;
-    int it_cc = 0, nx_t = 0;
+    // ---- slab iterator of the LOADER (the 9 taps of a 3x3 re-read the same neighbourhood back to back, so the re-reads
+    // are L2 hits).  The uniform offsets of the NEXT slab to issue are computed one slab ahead (the tap table lives in
+    // LDS: its read must not sit in front of a DMA issue).
+    int it_cc = s_lo / ntaps, nx_t = 0;
+    unsigned long long it_mask = tapmask & ~((1ull << (s_lo - it_cc * ntaps)) - 1ull);
     unsigned nx_a_uni = 0u, nx_b_uni = 0u;
     auto advance = [&]() {
         if (!it_mask) {
@@ -222,15 +298,6 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
             dma16(rsb, dst + 2048, voff + 128);
         }
     };
-
-    // ---- fragment addresses: lane (r = lane & 31, h = lane >> 5) reads row r, chunk 2 ks + h of each part
-    const int fr = lane & 31, fh = lane >> 5;
-    const int fsw = ((fr & 15) >> 2) & 3;
-    const int f_row = (fr >> 4) * 3072 + (fr & 15) * 64;
-    const int a_lane0 = (wm * (TMW / 16)) * 3072 + f_row + (((0 + fh) ^ fsw) * 16);
-    const int a_lane1 = (wm * (TMW / 16)) * 3072 + f_row + (((2 + fh) ^ fsw) * 16);
-    const int b_lane0 = A_BYTES + (wn * (TNW / 16)) * 3072 + f_row + (((0 + fh) ^ fsw) * 16);
-    const int b_lane1 = A_BYTES + (wn * (TNW / 16)) * 3072 + f_row + (((2 + fh) ^ fsw) * 16);
 
     // ---- prologue: NSTAGE - 1 slabs in flight
     int issued = 0;
@@ -308,7 +375,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     wait_vmcnt<0>();
     __syncthreads();  // all waves out of the main loop: the ring is free for the epilogue
 
-    if (p.stat_partial) {
+    if (p.stat_partial && complete) {
         // BatchNorm batch statistics of the RAW output, one partial row per M-tile (rows >= M are zero: their taps all
         // read the zero row)
         float *red = reinterpret_cast<float *>(smem);  // [WARPS_M][2][BN]
@@ -350,7 +417,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     static_assert(NT % PBLK == 0, "column blocks per pass");
     float *patch = reinterpret_cast<float *>(smem) + wave * 32 * PITCH;
     const bool vec_ok = (!y || (p.ldy & 3) == 0) && ((p.K & 3) == 0) && (!res || (p.ldr & 3) == 0);
-    if (p.y3 && wg == 0)  // the zero row consumers point padded taps at
+    float *slab = complete ? nullptr : p.ws + ((long)wgid * 2 + (seg_idx > 0 ? 1 : 0)) * (BM * BN);
+    if (p.y3 && tile == 0 && s_lo == 0)  // the zero row consumers point padded taps at
         for (int i = tid; i < p.cc_out * 12; i += 64 * NW)
             *reinterpret_cast<uint4 *>(p.y3 + (long)p.M * p.cc_out * 192 + i * 16) = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
@@ -371,43 +439,73 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
             for (int it = 0; it < (32 * C4) / 64; ++it) {
                 const int idx = it * 64 + lane;
                 const int row = idx / C4, c4 = idx - row * C4;
-                const int m = m0 + wm * TMW + mt * 32 + row;
-                const int k = n0 + wn * TNW + ntp * 32 + c4 * 4;
+                const int lr = wm * TMW + mt * 32 + row, lc = wn * TNW + ntp * 32 + c4 * 4;  // tile-local
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(patch + row * PITCH + c4 * 4);
+                if (slab) {  // partial segment: raw sums to the workspace (the fix-up pass owns the epilogue of this tile)
+                    *reinterpret_cast<f32x4 *>(slab + lr * BN + lc) = v;
+                    continue;
+                }
+                const int m = m0 + lr, k = n0 + lc;
                 if (m >= p.M || k >= p.K) continue;
-                long mo = m;
-                if (p.o_mul != 1) {
-                    const int n = m / ohw, rem = m - n * ohw;
-                    const int ohs = rem / p.OWs;
-                    mo = ((long)n * p.OH + ohs * p.o_mul + p.oy_add) * p.OW + (rem - ohs * p.OWs) * p.o_mul + p.ox_add;
-                }
-                f32x4 v = *reinterpret_cast<const f32x4 *>(patch + row * PITCH + c4 * 4);
-                if (vec_ok) {
-                    if (p.scale) v *= *reinterpret_cast<const f32x4 *>(p.scale + k);
-                    if (p.shift) v += *reinterpret_cast<const f32x4 *>(p.shift + k);
-                    if (res) v += *reinterpret_cast<const f32x4 *>(res + mo * p.ldr + k);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
-                    if (y) *reinterpret_cast<f32x4 *>(y + mo * p.ldy + k) = v;
-                    if (p.y3) {
-                        uint2 q0, q1, q2;
-                        split3_4(v, q0, q1, q2);
-                        char *d = p.y3 + (mo * p.cc_out + (k >> 5)) * 192 + (k & 31) * 2;
-                        *reinterpret_cast<uint2 *>(d) = q0;
-                        *reinterpret_cast<uint2 *>(d + 64) = q1;
-                        *reinterpret_cast<uint2 *>(d + 128) = q2;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (k + e >= p.K) break;
-                        float u = v[e] * (p.scale ? p.scale[k + e] : 1.f) + (p.shift ? p.shift[k + e] : 0.f);
-                        if (res) u += res[mo * p.ldr + k + e];
-                        y[mo * p.ldy + k + e] = apply_act(u, p.act);
-                    }
-                }
+                x3_store_out(p, v, m, k, ohw, vec_ok);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+        }
+    }
+    }  // segments
+}
+
+// Fix-up pass of the stream-K decomposition: block i looks at the boundary between workgroups i and i + 1 of the main
+// launch.  If it falls inside a tile and is the FIRST boundary inside that tile, the block adds that tile's workspace
+// slabs in workgroup order (a fixed order: results do not depend on timing), runs the epilogue and, for train-mode BN,
+// the tile's partial statistics.
+template <int BM, int BN> __global__ __launch_bounds__(256) void conv_x3_fixup_kernel(const X3P p) {
+    const int ntaps = p.R * p.S;
+    const long S_tile = (long)p.CC * ntaps;
+    const long U = (long)p.mtiles * p.ntiles * S_tile;
+    const int i = blockIdx.x;
+    auto bound = [&](int w) -> long { return U * w / p.sk_wgs; };
+    const long b1 = bound(i + 1);
+    const int tile = (int)(b1 / S_tile);
+    const long t_lo = (long)tile * S_tile, t_hi = t_lo + S_tile;
+    if (b1 == t_lo || b1 >= U) return;   // boundary on a tile edge: nothing is split here
+    if (bound(i) > t_lo) return;         // an earlier boundary already lies inside this tile: its block does the work
+    const int mt_i = tile / p.ntiles, nt_i = tile - mt_i * p.ntiles;
+    const int m0 = mt_i * BM, n0 = nt_i * BN;
+    const int ohw = p.OHs * p.OWs;
+    const float *res = reinterpret_cast<const float *>(p.res);
+    const float *y = reinterpret_cast<const float *>(p.y);
+    const bool vec_ok = (!y || (p.ldy & 3) == 0) && ((p.K & 3) == 0) && (!res || (p.ldr & 3) == 0);
+    constexpr int C4 = BN / 4, RPP = 256 / C4;  // 4-column groups per row, rows per pass
+    __shared__ float red[2][RPP][BN];
+    const int tid = threadIdx.x;
+    const int c4 = tid % C4, r0 = tid / C4;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    for (int lr = r0; lr < BM; lr += RPP) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int w = i; w < p.sk_wgs && bound(w) < t_hi; ++w) {
+            if (bound(w + 1) == bound(w)) continue;  // a workgroup with an empty range wrote nothing
+            const float *slab = p.ws + ((long)w * 2 + (bound(w) >= t_lo ? 0 : 1)) * (BM * BN);
+            v += *reinterpret_cast<const f32x4 *>(slab + lr * BN + c4 * 4);
+        }
+        s1 += v;
+        s2 += v * v;
+        const int m = m0 + lr, k = n0 + c4 * 4;
+        if (m < p.M && k < p.K) x3_store_out(p, v, m, k, ohw, vec_ok);
+    }
+    if (p.stat_partial) {  // rows >= M of the slabs are exact zeros
+        constexpr int NR = RPP;
+        for (int e = 0; e < 4; ++e) {
+            red[0][r0][c4 * 4 + e] = s1[e];
+            red[1][r0][c4 * 4 + e] = s2[e];
+        }
+        __syncthreads();
+        for (int j = tid; j < 2 * BN; j += 256) {
+            const int which = j / BN, col = j - which * BN;
+            float a = 0.f;
+            for (int q = 0; q < NR; ++q) a += red[which][q][col];
+            if (n0 + col < p.K) p.stat_partial[((long)mt_i * 2 + which) * p.K + n0 + col] = a;
         }
     }
 }
@@ -452,46 +550,62 @@ __global__ __launch_bounds__(256) void split3_rows_kernel(const float *__restric
     }
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE> int launch_x3(X3P &p, hipStream_t st) {
+static int g_cus = 0;  // compute units of the current device (stream-K launches one workgroup per resident slot)
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE> int launch_x3(X3P &p, hipStream_t st, int mode, long ws_bytes) {
+    constexpr int LDS = NSTAGE * (BM + BN) * 192 + 256;
+    constexpr int RES = (160 * 1024) / LDS >= 4 ? 4 : (160 * 1024) / LDS;  // resident workgroups per CU (LDS-limited)
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = (p.K + BN - 1) / BN;
-    hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE>), dim3(p.mtiles * p.ntiles), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
+    const long tiles = (long)p.mtiles * p.ntiles, slots = (long)g_cus * RES;
+    const long units = tiles * p.CC * p.R * p.S;
+    // one tile per workgroup when that quantises well (or the problem is tiny); equal slab ranges per resident slot otherwise
+    bool stream = mode == 2;
+    if (mode == 0) {
+        const long rounds = (tiles + slots - 1) / slots;
+        const double eff = (double)tiles / (double)(rounds * slots);  // busy share of the last-round-limited schedule
+        stream = eff < 0.92 && units >= 6 * slots && (long)p.CC * p.R * p.S >= 4;
+    }
+    if (stream && (!p.ws || ws_bytes < 2 * slots * (long)BM * BN * 4)) stream = false;
+    p.sk_wgs = stream ? (int)slots : (int)tiles;
+    hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE>), dim3(p.sk_wgs), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
     DASS_LAUNCH_CHECK();
+    if (stream) {
+        hipLaunchKernelGGL((conv_x3_fixup_kernel<BM, BN>), dim3(p.sk_wgs), dim3(256), 0, st, p);
+        DASS_LAUNCH_CHECK();
+    }
     return DASS_OK;
 }
 
-// tile choice: the same wave-quantisation cost model as conv_igemm.hip (workgroups are dealt over 256 CUs, the busiest CU
-// decides); efficiencies from tools/conv_sweep.py --x3
 static int g_x3_force = -1;  // tuning / test knob: dass_x3_force_tile(); -1 = take DASS_X3_TILE from the environment once
 
-static int dispatch_x3(X3P &p, hipStream_t st) {
+// force = tile + 10 * mode: tile 0 = model's choice, 1..7 = variant; mode 0 = auto, 1 = one tile per workgroup, 2 = stream-K
+static int dispatch_x3(X3P &p, hipStream_t st, long ws_bytes) {
     if (g_x3_force < 0) g_x3_force = getenv("DASS_X3_TILE") ? atoi(getenv("DASS_X3_TILE")) : 0;
-    const int force = g_x3_force;
-    auto cost = [&](int bm, int bn, double eff, int per_cu) {
-        const long wgs = (long)((p.M + bm - 1) / bm) * ((p.K + bn - 1) / bn);
-        const long rounds = (wgs + 256 * per_cu - 1) / (256 * per_cu);
-        return (double)rounds * per_cu * bm * bn / eff;
-    };
-    int pick = force;
+    if (!g_cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return DASS_ERR_LAUNCH;
+        g_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int mode = g_x3_force / 10;
+    int pick = g_x3_force % 10;
     if (!pick) {
-        const double c1 = p.K > 64 ? cost(256, 128, 1.0, 1) : 1e30;
-        const double c2 = p.K > 64 ? cost(128, 128, 0.95, 1) : 1e30;
-        const double c3 = cost(128, 64, 0.85, 2);
-        const double c4 = cost(64, 64, 0.75, 2);
-        pick = 1;
-        double best = c1;
-        if (c2 < best) { best = c2; pick = 2; }
-        if (c3 < best) { best = c3; pick = 3; }
-        if (c4 < best) { best = c4; pick = 4; }
+        // measured (tools/x3_time.py): the 8-wave 128x128 / 256x128 tiles have the best MFMA : LDS ratio; with the slab
+        // ranges balanced by stream-K they no longer need many tiles to fill the chip
+        const long t256 = (long)((p.M + 255) / 256) * ((p.K + 127) / 128);
+        if (p.K <= 64) pick = 4;
+        else if (t256 >= 4 * g_cus) pick = 1;
+        else pick = 2;
     }
     switch (pick) {
-    case 1: return launch_x3<256, 128, 4, 2, 2>(p, st);
-    case 2: return launch_x3<128, 128, 4, 2, 3>(p, st);
-    case 3: return launch_x3<128, 64, 4, 1, 2>(p, st);
-    case 5: return launch_x3<128, 128, 2, 2, 3>(p, st);
-    case 6: return launch_x3<64, 64, 2, 2, 3>(p, st);
-    case 7: return launch_x3<128, 128, 4, 2, 2>(p, st);
-    default: return launch_x3<64, 64, 2, 2, 2>(p, st);
+    case 1: return launch_x3<256, 128, 4, 2, 2>(p, st, mode, ws_bytes);
+    case 2: return launch_x3<128, 128, 4, 2, 3>(p, st, mode, ws_bytes);
+    case 3: return launch_x3<128, 64, 4, 1, 2>(p, st, mode, ws_bytes);
+    case 5: return launch_x3<128, 128, 2, 2, 3>(p, st, mode, ws_bytes);
+    case 6: return launch_x3<64, 64, 2, 2, 3>(p, st, mode, ws_bytes);
+    case 7: return launch_x3<128, 128, 4, 2, 2>(p, st, mode, ws_bytes);
+    default: return launch_x3<64, 64, 2, 2, 2>(p, st, mode, ws_bytes);
     }
 }
 
@@ -501,6 +615,9 @@ extern "C" int dass_x3_force_tile(int tile) {
     g_x3_force = tile < 0 ? 0 : tile;
     return DASS_OK;
 }
+
+// two BM x BN f32 slabs per workgroup of the largest stream-K launch (256 CUs x 256 x 128 tiles; every other variant needs less)
+extern "C" int64_t dass_conv2d_x3_workspace_bytes(void) { return (int64_t)2 * 256 * (256 * 128) * 4; }
 
 extern "C" int64_t dass_x3_bytes(int64_t rows, int C) { return (rows + 1) * ((C + 31) / 32) * 192; }
 
@@ -518,8 +635,10 @@ extern "C" int dass_split3_rows(const float *x, int64_t ld, void *out, int64_t M
 
 extern "C" int dass_conv2d_x3(const void *x3, const void *w3, void *y, int64_t ldy, void *y3, const float *scale, const float *shift,
                               const void *residual, int64_t ldr, int N, int H, int W, int C, int OH, int OW, int K, int R, int S,
-                              int stride, int pad, int dil, int ustride, int act, float *stat_partial, int *stat_rows, void *stream) {
+                              int stride, int pad, int dil, int ustride, int act, float *stat_partial, int *stat_rows, void *workspace,
+                              int64_t workspace_bytes, void *stream) {
     if (!x3 || !w3 || (!y && !y3)) return DASS_ERR_ARG;
+    if (workspace && ((uintptr_t)workspace & 15)) return DASS_ERR_ARG;
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || K <= 0 || R <= 0 || S <= 0) return DASS_ERR_ARG;
     if (R * S > 64 || stride < 1 || dil < 1 || ustride < 1 || ustride > 8) return DASS_ERR_ARG;
     if (((uintptr_t)x3 & 15) || ((uintptr_t)w3 & 15) || ((uintptr_t)y3 & 15)) return DASS_ERR_ARG;
@@ -538,6 +657,7 @@ extern "C" int dass_conv2d_x3(const void *x3, const void *w3, void *y, int64_t l
     p.shift = shift;
     p.res = (const char *)residual;
     p.stat_partial = stat_partial;
+    p.ws = (float *)workspace;
     p.ldy = ldy;
     p.ldr = ldr;
     p.x3_bytes = (unsigned)xbytes;
@@ -578,12 +698,12 @@ extern "C" int dass_conv2d_x3(const void *x3, const void *w3, void *y, int64_t l
                 q.o_mul = ustride; q.oy_add = py; q.ox_add = px;
                 q.tap_allow = masks[py][px];
                 q.M = N * q.OHs * q.OWs;
-                const int rc = dispatch_x3(q, st);
+                const int rc = dispatch_x3(q, st, workspace_bytes);
                 if (rc != DASS_OK) return rc;
             }
         return DASS_OK;
     }
-    const int rc = dispatch_x3(p, st);
+    const int rc = dispatch_x3(p, st, workspace_bytes);
     if (stat_rows) *stat_rows = p.mtiles;
     return rc;
 }

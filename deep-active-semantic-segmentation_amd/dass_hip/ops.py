@@ -155,10 +155,23 @@ def conv_x3_launch(x3, w3, y, ldy, dims, y3=None, scale=None, shift=None, residu
     """dims as conv_launch; stats: None or a [rows, 2, K] f32 buffer -> returns the number of partial rows written"""
     n, h, w, c, oh, ow, k, r, s, stride, pad, dil = dims
     nrows = ctypes.c_int(0)
+    ws = _x3_workspace(x3.device)
     check(lib.dass_conv2d_x3(_p(x3), _p(w3), _p(y), ldy, _p(y3), _p(scale), _p(shift), _p(residual), ldr, n, h, w, c, oh, ow, k,
                              r, s, stride, pad, dil, ustride, act, _p(stats), ctypes.byref(nrows) if stats is not None else None,
-                             _stream()), "dass_conv2d_x3")
+                             _p(ws), ws.numel(), _stream()), "dass_conv2d_x3")
     return nrows.value
+
+
+_x3_ws = {}
+
+
+def _x3_workspace(device):
+    """scratch for the stream-K schedule of dass_conv2d_x3 (one per device and stream: launches on one stream are ordered)"""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    ws = _x3_ws.get(key)
+    if ws is None:
+        ws = _x3_ws[key] = torch.empty((lib.dass_conv2d_x3_workspace_bytes(),), dtype=torch.uint8, device=device)
+    return ws
 
 
 def x3_operand(t, xs, ld, m, c, nc_scale=None, rows_per_image=1):

@@ -303,8 +303,11 @@ int dass_sgd_step_multi(void *const *p, const void *const *g, void *const *buf, 
  * dass_x3_bytes: allocation size.  dass_split3_rows: f32 rows -> x3 rows; nc_scale (nullable) multiplies row m by
  * nc_scale[m / rows_per_image][c] first (Dropout2d mask of the producer, aspp.py:89 / decoder.py:35). */
 int64_t dass_x3_bytes(int64_t rows, int C);
-/* tuning / test knob: 0 = cost model (default), 1..7 = force one tile variant of dass_conv2d_x3 (csrc/conv_x3.hip) */
+/* tuning / test knob: tile + 10 * mode.  tile 0 = the dispatcher's choice, 1..7 = force one tile variant of
+ * dass_conv2d_x3 (csrc/conv_x3.hip); mode 0 = auto, 1 = one output tile per workgroup, 2 = stream-K slab ranges */
 int dass_x3_force_tile(int tile);
+/* bytes of scratch dass_conv2d_x3 wants for its stream-K schedule (partial tiles of split output tiles) */
+int64_t dass_conv2d_x3_workspace_bytes(void);
 int dass_split3_rows(const float *x, int64_t ld, void *out, int64_t M, int C, const float *nc_scale,
                      int64_t rows_per_image, void *stream);
 /* nn.Conv2d forward (F.conv2d call sites of resnet.py:38-41, aspp.py:26, decoder.py:41-47) and, over dy with the
@@ -312,11 +315,14 @@ int dass_split3_rows(const float *x, int64_t ld, void *out, int64_t M, int C, co
  * x3 from dass_split3_rows (or a producer's y3), w3 from dass_weight_transform(DASS_F32X6) / dass_weight_split_batch.
  * Output: y (f32 rows, ldy; nullable) and/or y3 (x3 rows of the result, K % 4 == 0).  stat_partial/stat_rows
  * (nullable): per-M-tile BatchNorm partial sums as dass_conv2d_igemm_stats.  ustride > 1: phase-decomposed dgrad of a
- * strided conv (plain f32 output only).  Buffers beyond 4 GiB are DASS_ERR_UNSUPPORTED (32-bit buffer offsets). */
+ * strided conv (plain f32 output only).  Buffers beyond 4 GiB are DASS_ERR_UNSUPPORTED (32-bit buffer offsets).
+ * workspace (nullable, 16-B aligned, dass_conv2d_x3_workspace_bytes()): with it the launch may balance the reduction slabs
+ * over the CUs ("stream-K": output tiles split between workgroups are summed by a second, deterministic launch);
+ * without it every output tile is one workgroup. */
 int dass_conv2d_x3(const void *x3, const void *w3, void *y, int64_t ldy, void *y3, const float *scale,
                    const float *shift, const void *residual, int64_t ldr, int N, int H, int W, int C, int OH, int OW,
                    int K, int R, int S, int stride, int pad, int dil, int ustride, int act, float *stat_partial,
-                   int *stat_rows, void *stream);
+                   int *stat_rows, void *workspace, int64_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,8 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 # (N, C, H, W, K, ksize, stride, pad, dil)
-CASES = [(2, 304, 33, 33, 256, 3, 1, 1, 1),      # C = 9.5 slabs (zero-padded tail), decoder shape at 33^2
+CASES = [(8, 256, 33, 33, 256, 3, 1, 1, 1),      # layer3 3x3 at full size: M = 8712, 138 tiles of 128 x 128 on 256 CUs
+         (2, 304, 33, 33, 256, 3, 1, 1, 1),      # C = 9.5 slabs (zero-padded tail), decoder shape at 33^2
          (2, 256, 33, 33, 256, 3, 1, 6, 6),      # dilation 6 on a 33-map: border tiles skip taps
          (1, 512, 33, 33, 256, 3, 1, 18, 18),    # dilation 18: most taps fall in the padding
          (3, 1024, 17, 17, 256, 1, 1, 0, 1),     # 1x1, M = 867 (ragged last tile)
@@ -17,7 +18,8 @@ CASES = [(2, 304, 33, 33, 256, 3, 1, 1, 1),      # C = 9.5 slabs (zero-padded ta
          (2, 128, 35, 35, 128, 3, 2, 1, 1),      # stride 2
          (2, 48, 19, 23, 40, 3, 1, 1, 1),        # C = 48 (1.5 slabs), K = 40
          (1, 96, 9, 9, 320, 1, 1, 2, 1)]         # 1x1 over a zero-padded border (MobileNet fixed_padding form)
-TILES = [1, 2, 3, 4, 5, 6, 7]
+# dass_x3_force_tile codes: tile + 10 * mode (mode 1 = one tile per workgroup, 2 = stream-K slab ranges, 0 = auto)
+TILES = [11, 12, 13, 14, 15, 16, 17, 21, 22, 23, 24, 0]
 
 
 @pytest.fixture(autouse=True)
@@ -105,13 +107,13 @@ def test_x3_forward_vs_f64(case, tile):
         assert (y - y_old).abs().max().item() <= 1e-5 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("tile", [1, 2, 4])
+@pytest.mark.parametrize("tile", [11, 12, 14, 21, 22, 23, 24])
 def test_x3_epilogue_stats_and_x3_output(tile):
     from dass_hip import ops
     from dass_hip._lib import lib
 
     lib.dass_x3_force_tile(tile)
-    case = (2, 96, 21, 19, 136, 3, 1, 2, 2)
+    case = (4, 96, 41, 39, 136, 3, 1, 2, 2)   # 6396 output rows: enough slabs for real stream-K ranges
     n, c, h, wd, k, ks, stride, pad, dil = case
     x, w = _inputs(case)
     g = torch.Generator().manual_seed(11)
@@ -172,3 +174,25 @@ def test_x3_dgrad_vs_f64(case, tile):
     pad_t = dil * (ks - 1) - pad
     ops.conv_x3_launch(dy3, wt3, dx, c, (n, oh, ow, k, h, wd, c, ks, ks, 1, pad_t, dil), ustride=stride)
     assert _rel(dx, ref) <= 2e-6, (case, tile, _rel(dx, ref))
+
+
+def test_x3_stream_k_is_deterministic_and_matches_one_tile_per_workgroup():
+    """the fix-up pass adds the partial slabs of a split tile in workgroup order: two runs agree bit for bit, and the
+    result equals the one-tile-per-workgroup schedule to the last bit or two (same products, slab sums re-associated)"""
+    from dass_hip import ops
+    from dass_hip._lib import lib
+
+    case = (8, 256, 33, 33, 256, 3, 1, 1, 1)
+    n, c, h, wd, k, ks, stride, pad, dil = case
+    x, w = _inputs(case)
+    x3, w3 = _x3_of(ops, x), ops.prepare_conv_weight(w.permute(0, 2, 3, 1).contiguous().cuda())
+    dims = (n, h, wd, c, h, wd, k, ks, ks, stride, pad, dil)
+    outs = []
+    for code in (22, 22, 12, 21, 24):
+        lib.dass_x3_force_tile(code)
+        y = torch.full((n, h, wd, k), float("nan"), device="cuda")
+        ops.conv_x3_launch(x3, w3, y, k, dims)
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+    for other in outs[2:]:
+        assert (outs[0] - other).abs().max().item() <= 2e-6 * outs[0].abs().max().item()

@@ -15,11 +15,11 @@ from conv_sweep import r101_shapes, timeit  # noqa: E402
 
 
 def main():
-    tiles = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3, 4, 7]
+    tiles = [int(a) for a in sys.argv[1:]] or [0, 11, 12, 14, 21, 22, 23, 24]
     ops.set_f32_mma("bf16x6")
     dev = "cuda"
     tot_old, tot_new, tot_best, tot_flop, tot_split = 0.0, {t: 0.0 for t in tiles}, 0.0, 0.0, 0.0
-    print("%-14s %3s %7s %5s %5s | %8s | %s | %7s" % ("shape", "cnt", "M", "C", "K", "old us", " ".join("t%d us  " % t for t in tiles), "split us"))
+    print("%-14s %3s %7s %5s %5s | %8s | %s | %7s" % ("shape", "cnt", "M", "C", "K", "old us", " ".join("t%-2d us " % t for t in tiles), "split us"))
     for name, cnt, n, h, w, c, k, ks, st, pad, dil in r101_shapes():
         if c < 16 or k < 32:
             continue
