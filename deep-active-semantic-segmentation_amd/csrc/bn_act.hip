@@ -157,7 +157,9 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const T *__restric
                                                               const float *__restrict__ shift,
                                                               const T *__restrict__ res, long ldr,
                                                               const float *__restrict__ nc_scale, long M, int K,
-                                                              long rows_per_image, int act) {
+                                                              long rows_per_image, int act, char *__restrict__ out3) {
+    if (out3 && blockIdx.x == 0) x3_zero_row(out3, M, (K + 31) >> 5);
+    const int cc3 = (K + 31) >> 5;
     // (row, 4-channel group) walked incrementally: the grid stride is decomposed once, so the loop has no 64-bit division
     const int kv = K >> 2;
     const long stride = (long)gridDim.x * blockDim.x;
@@ -183,7 +185,8 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const T *__restric
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
         if (nc_scale) v *= *reinterpret_cast<const f32x4 *>(nc_scale + (m / rows_per_image) * K + k);
-        st4<T>(out + m * ldo + k, v);
+        if (out) st4<T>(out + m * ldo + k, v);
+        if (out3) x3_store4(out3, m, cc3, k, v);  // the same values as three bf16 parts: operand of the next dense conv
     }
 }
 
@@ -200,7 +203,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
                                                            long lddx, T *__restrict__ dres, long lddr, long M, int K,
                                                            long rows_per_image, float inv_count, int train, int act,
                                                            const float *__restrict__ gate_scale = nullptr,
-                                                           const float *__restrict__ gate_shift = nullptr) {
+                                                           const float *__restrict__ gate_shift = nullptr,
+                                                           char *__restrict__ dx3 = nullptr) {
+    if (dx3 && blockIdx.x == 0) x3_zero_row(dx3, M, (K + 31) >> 5);
+    const int cc3 = (K + 31) >> 5;
     const int kv = K >> 2;
     const long stride = (long)gridDim.x * blockDim.x;
     const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -235,7 +241,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
                 const f32x4 dg = *reinterpret_cast<const f32x4 *>(dgamma + k);
                 r = g - (db + xh * dg) * inv_count;
             }
-            st4<T>(dx + m * lddx + k, r * (ga * is));
+            const f32x4 dxv = r * (ga * is);
+            st4<T>(dx + m * lddx + k, dxv);
+            if (dx3) x3_store4(dx3, m, cc3, k, dxv);  // operand of the producing conv's input-gradient launch
         }
     }
 }
@@ -287,18 +295,19 @@ extern "C" int dass_bn_eval_scale_shift(const float *gamma, const float *beta, c
 
 extern "C" int dass_scale_shift_act(const void *x, int64_t ldx, void *out, int64_t ldo, const float *scale,
                                     const float *shift, const void *residual, int64_t ldr, const float *nc_scale,
-                                    int64_t M, int K, int64_t rows_per_image, int act, int dtype, void *stream) {
-    if (!x || !out || M <= 0 || !ok4(K, ldx, ldo, residual ? ldr : 4) || rows_per_image <= 0) return DASS_ERR_ARG;
+                                    int64_t M, int K, int64_t rows_per_image, int act, int dtype, void *out3, void *stream) {
+    if (!x || (!out && !out3) || M <= 0 || !ok4(K, ldx, out ? ldo : 4, residual ? ldr : 4) || rows_per_image <= 0) return DASS_ERR_ARG;
+    if (out3 && (dtype != DASS_F32 || ((uintptr_t)out3 & 15))) return DASS_ERR_ARG;
     const int grid = dass_grid_1d(M * (K / 4), 256);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DASS_F32)
         hipLaunchKernelGGL(scale_shift_act_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, ldx,
                            (float *)out, ldo, scale, shift, (const float *)residual, ldr, nc_scale, M, K,
-                           rows_per_image, act);
+                           rows_per_image, act, (char *)out3);
     else if (dtype == DASS_BF16)
         hipLaunchKernelGGL(scale_shift_act_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)x, ldx,
                            (bf16_t *)out, ldo, scale, shift, (const bf16_t *)residual, ldr, nc_scale, M, K,
-                           rows_per_image, act);
+                           rows_per_image, act, (char *)nullptr);
     else
         return DASS_ERR_UNSUPPORTED;
     DASS_LAUNCH_CHECK();
@@ -345,7 +354,8 @@ extern "C" int dass_bn_bwd_reduce_gate(const void *dout, int64_t lddo, const voi
 extern "C" int dass_bn_bwd_apply_gate(const void *dout, int64_t lddo, const void *x, int64_t ldx, const float *mean, const float *invstd,
                                       const float *gamma, const float *dbeta, const float *dgamma, const float *gate_scale,
                                       const float *gate_shift, const float *nc_scale, void *dx, int64_t lddx, int64_t M, int K,
-                                      int64_t rows_per_image, double count, int train, int act, int dtype, void *stream) {
+                                      int64_t rows_per_image, double count, int train, int act, int dtype, void *dx3, void *stream) {
+    if (dx3 && ((uintptr_t)dx3 & 15)) return DASS_ERR_ARG;
     if (!dout || !x || !dx || !invstd || !gate_scale || !gate_shift || M <= 0 || !ok4(K, lddo, ldx, lddx) || rows_per_image <= 0)
         return DASS_ERR_ARG;
     if (train && (!mean || !dbeta || !dgamma || count <= 0)) return DASS_ERR_ARG;
@@ -354,7 +364,7 @@ extern "C" int dass_bn_bwd_apply_gate(const void *dout, int64_t lddo, const void
     const float inv_count = train ? (float)(1.0 / count) : 0.f;
     hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float *)dout, lddo, (const float *)nullptr, 0,
                        (const float *)x, ldx, mean, invstd, gamma, dbeta, dgamma, nc_scale, (float *)dx, lddx, (float *)nullptr, 0, M, K,
-                       rows_per_image, inv_count, train, act, gate_scale, gate_shift);
+                       rows_per_image, inv_count, train, act, gate_scale, gate_shift, (char *)dx3);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
@@ -372,8 +382,9 @@ extern "C" int dass_bn_bwd_apply(const void *dout, int64_t lddo, const void *out
                                  int64_t ldx, const float *mean, const float *invstd, const float *gamma,
                                  const float *dbeta, const float *dgamma, const float *nc_scale, void *dx,
                                  int64_t lddx, void *dres, int64_t lddr, int64_t M, int K, int64_t rows_per_image,
-                                 double count, int train, int act, int dtype, void *stream) {
+                                 double count, int train, int act, int dtype, void *dx3, void *stream) {
     if (!dout || !out || M <= 0 || !ok4(K, lddo, ldo) || rows_per_image <= 0) return DASS_ERR_ARG;
+    if (dx3 && (!dx || dtype != DASS_F32 || ((uintptr_t)dx3 & 15))) return DASS_ERR_ARG;
     if (dx && (!invstd || lddx % 4)) return DASS_ERR_ARG;
     if (dx && train && (!x || !mean || !dbeta || !dgamma || ldx % 4 || count <= 0)) return DASS_ERR_ARG;
     if (dres && lddr % 4) return DASS_ERR_ARG;
@@ -384,7 +395,7 @@ extern "C" int dass_bn_bwd_apply(const void *dout, int64_t lddo, const void *out
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)dout, lddo,
                            (const float *)out, ldo, (const float *)x, ldx, mean, invstd, gamma, dbeta, dgamma,
                            nc_scale, (float *)dx, lddx, (float *)dres, lddr, M, K, rows_per_image, inv_count, train,
-                           act);
+                           act, (const float *)nullptr, (const float *)nullptr, (char *)dx3);
     else if (dtype == DASS_BF16)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)dout, lddo,
                            (const bf16_t *)out, ldo, (const bf16_t *)x, ldx, mean, invstd, gamma, dbeta, dgamma,

@@ -75,26 +75,6 @@ __device__ __forceinline__ f32x16 mfma16(const uint4 &a, const uint4 &b, f32x16 
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&a), *reinterpret_cast<const bf16x8 *>(&b), c, 0, 0, 0);
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pk_bf16(f32x2 v) {
-    bf16x2v b = __builtin_convertvector(v, bf16x2v);
-    return *reinterpret_cast<unsigned *>(&b);
-}
-// four f32 -> the three bf16 parts (x0, x1, x2), 8 B each
-__device__ __forceinline__ void split3_4(f32x4 v, uint2 &p0, uint2 &p1, uint2 &p2) {
-    const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
-    const unsigned h0 = pk_bf16(a), h1 = pk_bf16(b);
-    const f32x2 ra = a - f32x2{__uint_as_float(h0 << 16), __uint_as_float(h0 & 0xffff0000u)};
-    const f32x2 rb = b - f32x2{__uint_as_float(h1 << 16), __uint_as_float(h1 & 0xffff0000u)};
-    const unsigned m0 = pk_bf16(ra), m1 = pk_bf16(rb);
-    const f32x2 sa = ra - f32x2{__uint_as_float(m0 << 16), __uint_as_float(m0 & 0xffff0000u)};
-    const f32x2 sb = rb - f32x2{__uint_as_float(m1 << 16), __uint_as_float(m1 & 0xffff0000u)};
-    p0 = make_uint2(h0, h1);
-    p1 = make_uint2(m0, m1);
-    p2 = make_uint2(pk_bf16(sa), pk_bf16(sb));
-}
-
 // fused epilogue of ONE 4-channel group of output pixel m (tile-independent: used by the main kernel and the fix-up pass)
 __device__ __forceinline__ void x3_store_out(const X3P &p, f32x4 v, int m, int k, int ohw, bool vec_ok) {
     float *y = reinterpret_cast<float *>(p.y);
@@ -112,14 +92,7 @@ __device__ __forceinline__ void x3_store_out(const X3P &p, f32x4 v, int m, int k
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
         if (y) *reinterpret_cast<f32x4 *>(y + mo * p.ldy + k) = v;
-        if (p.y3) {
-            uint2 q0, q1, q2;
-            split3_4(v, q0, q1, q2);
-            char *d = p.y3 + (mo * p.cc_out + (k >> 5)) * 192 + (k & 31) * 2;
-            *reinterpret_cast<uint2 *>(d) = q0;
-            *reinterpret_cast<uint2 *>(d + 64) = q1;
-            *reinterpret_cast<uint2 *>(d + 128) = q2;
-        }
+        if (p.y3) x3_store4(p.y3, mo, p.cc_out, k, v);
     } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -479,16 +452,26 @@ template <int BM, int BN> __global__ __launch_bounds__(256) void conv_x3_fixup_k
     const bool vec_ok = (!y || (p.ldy & 3) == 0) && ((p.K & 3) == 0) && (!res || (p.ldr & 3) == 0);
     constexpr int C4 = BN / 4, RPP = 256 / C4;  // 4-column groups per row, rows per pass
     __shared__ float red[2][RPP][BN];
+    __shared__ const float *contrib[256];  // the tile's slabs, in workgroup order (64-bit divisions done once, not per row)
+    __shared__ int ncontrib;
     const int tid = threadIdx.x;
+    if (tid == 0) {
+        int nc = 0;
+        for (int w = i; w < p.sk_wgs && nc < 256; ++w) {
+            const long bw = bound(w);
+            if (bw >= t_hi) break;
+            if (bound(w + 1) == bw) continue;  // a workgroup with an empty range wrote nothing
+            contrib[nc++] = p.ws + ((long)w * 2 + (bw >= t_lo ? 0 : 1)) * (BM * BN);
+        }
+        ncontrib = nc;
+    }
+    __syncthreads();
+    const int nc = ncontrib;
     const int c4 = tid % C4, r0 = tid / C4;
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     for (int lr = r0; lr < BM; lr += RPP) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        for (int w = i; w < p.sk_wgs && bound(w) < t_hi; ++w) {
-            if (bound(w + 1) == bound(w)) continue;  // a workgroup with an empty range wrote nothing
-            const float *slab = p.ws + ((long)w * 2 + (bound(w) >= t_lo ? 0 : 1)) * (BM * BN);
-            v += *reinterpret_cast<const f32x4 *>(slab + lr * BN + c4 * 4);
-        }
+        for (int c = 0; c < nc; ++c) v += *reinterpret_cast<const f32x4 *>(contrib[c] + lr * BN + c4 * 4);
         s1 += v;
         s2 += v * v;
         const int m = m0 + lr, k = n0 + c4 * 4;
@@ -567,6 +550,7 @@ template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE> int launch_x3(X3
         stream = eff < 0.92 && units >= 6 * slots && (long)p.CC * p.R * p.S >= 4;
     }
     if (stream && (!p.ws || ws_bytes < 2 * slots * (long)BM * BN * 4)) stream = false;
+    if (stream && (long)p.CC * p.R * p.S / (units / slots > 0 ? units / slots : 1) + 2 > 256) stream = false;  // fix-up contributor table
     p.sk_wgs = stream ? (int)slots : (int)tiles;
     hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE>), dim3(p.sk_wgs), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
     DASS_LAUNCH_CHECK();
@@ -588,15 +572,20 @@ static int dispatch_x3(X3P &p, hipStream_t st, long ws_bytes) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return DASS_ERR_LAUNCH;
         g_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    const int mode = g_x3_force / 10;
+    int mode = g_x3_force / 10;
     int pick = g_x3_force % 10;
     if (!pick) {
-        // measured (tools/x3_time.py): the 8-wave 128x128 / 256x128 tiles have the best MFMA : LDS ratio; with the slab
-        // ranges balanced by stream-K they no longer need many tiles to fill the chip
+        // measured on every DeepLab-R101 shape (tools/x3_time.py).  The chip is power-limited under MFMA load (all 256 CUs
+        // busy lower the clock), so what decides is bytes moved per MFMA and a balanced schedule:
+        //  * many tiles (133128-row layers): 256 x 128, slab ranges balanced by stream-K when the tile count quantises badly;
+        //  * long reductions on few tiles (ASPP / layer-4 dilated 3x3 at 8712 rows): 256 x 128 with stream-K always;
+        //  * short reductions: 64 x 64 tiles, three workgroups per CU.
         const long t256 = (long)((p.M + 255) / 256) * ((p.K + 127) / 128);
+        const long s_tile = (long)p.CC * p.R * p.S;
         if (p.K <= 64) pick = 4;
         else if (t256 >= 4 * g_cus) pick = 1;
-        else pick = 2;
+        else if (s_tile >= 100) { pick = 1; if (!mode) mode = 2; }
+        else pick = 4;
     }
     switch (pick) {
     case 1: return launch_x3<256, 128, 4, 2, 2>(p, st, mode, ws_bytes);

@@ -52,6 +52,41 @@ template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t *p, f32x4 v) {
     *reinterpret_cast<uint2 *>(p) = u;
 }
 
+// ---- exact three-way bf16 split of f32 values (the operand format of the bf16x6 engine: x = x0 + x1 + x2)
+typedef float dass_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 dass_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_bf16(dass_f32x2 v) {
+    dass_bf16x2 b = __builtin_convertvector(v, dass_bf16x2);  // v_cvt_pk_bf16_f32, RNE
+    return *reinterpret_cast<unsigned *>(&b);
+}
+// four f32 -> the three bf16 parts (x0, x1, x2), 8 B each
+__device__ __forceinline__ void split3_4(f32x4 v, uint2 &p0, uint2 &p1, uint2 &p2) {
+    const dass_f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    const unsigned h0 = pk_bf16(a), h1 = pk_bf16(b);
+    const dass_f32x2 ra = a - dass_f32x2{__uint_as_float(h0 << 16), __uint_as_float(h0 & 0xffff0000u)};
+    const dass_f32x2 rb = b - dass_f32x2{__uint_as_float(h1 << 16), __uint_as_float(h1 & 0xffff0000u)};
+    const unsigned m0 = pk_bf16(ra), m1 = pk_bf16(rb);
+    const dass_f32x2 sa = ra - dass_f32x2{__uint_as_float(m0 << 16), __uint_as_float(m0 & 0xffff0000u)};
+    const dass_f32x2 sb = rb - dass_f32x2{__uint_as_float(m1 << 16), __uint_as_float(m1 & 0xffff0000u)};
+    p0 = make_uint2(h0, h1);
+    p1 = make_uint2(m0, m1);
+    p2 = make_uint2(pk_bf16(sa), pk_bf16(sb));
+}
+// x3 rows (csrc/conv_x3.hip): element (row m, channel k..k+3) of a [rows][cc][3][32] bf16 tensor
+__device__ __forceinline__ void x3_store4(char *base, long m, int cc, int k, f32x4 v) {
+    uint2 q0, q1, q2;
+    split3_4(v, q0, q1, q2);
+    char *d = base + (m * cc + (k >> 5)) * 192 + (k & 31) * 2;
+    *reinterpret_cast<uint2 *>(d) = q0;
+    *reinterpret_cast<uint2 *>(d + 64) = q1;
+    *reinterpret_cast<uint2 *>(d + 128) = q2;
+}
+// the all-zero row (index rows) and nothing else; call from ONE block of a producer kernel
+__device__ __forceinline__ void x3_zero_row(char *base, long rows, int cc) {
+    for (int i = threadIdx.x; i < cc * 12; i += blockDim.x)
+        *reinterpret_cast<uint4 *>(base + rows * cc * 192 + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == DASS_ACT_RELU) return v > 0.f ? v : 0.f;
     if (act == DASS_ACT_RELU6) return v < 0.f ? 0.f : (v > 6.f ? 6.f : v);

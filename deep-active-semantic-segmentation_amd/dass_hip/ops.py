@@ -323,9 +323,17 @@ def bn_eval_state(bn, k, device):
 
 
 def scale_shift_act(x, ldx, out, ldo, m, k, scale, shift, residual=None, ldr=0, nc_scale=None, rows_per_image=1,
-                    act=ACT_NONE):
+                    act=ACT_NONE, out3=None):
+    """out3: optional x3 buffer that receives the same values as three bf16 parts (operand of the next dense conv)"""
     check(lib.dass_scale_shift_act(_p(x), ldx, _p(out), ldo, _p(scale), _p(shift), _p(residual), ldr, _p(nc_scale),
-                                   m, k, rows_per_image, act, _dt(out), _stream()), "dass_scale_shift_act")
+                                   m, k, rows_per_image, act, _dt(x), _p(out3), _stream()), "dass_scale_shift_act")
+
+
+def x3_alloc_for(m, k, device):
+    """x3 buffer a producer kernel fills 4 channels at a time: zero-filled when the last 32-channel slab is ragged"""
+    if k % 32 == 0:
+        return x3_alloc(m, k, device)
+    return torch.zeros((lib.dass_x3_bytes(m, k),), dtype=torch.uint8, device=device)
 
 
 def bn_use_batch_stats(bn):
@@ -602,8 +610,13 @@ class _ConvBnAct(torch.autograd.Function):
                 scale, shift = state.scale, state.shift
             else:
                 scale, shift = None, (bias.detach().float() if bias is not None else None)
+            out3 = None
+            if x3_pipeline() and dt == torch.float32 and getattr(spec, "emit_x3", True) and k >= 32 and kpad == k:
+                out3 = x3_alloc_for(m, k, dev)  # the consumer is (almost always) the next dense conv: hand it split rows
             scale_shift_act(y_raw, k, out, ldo, m, k, scale, shift, residual=res_t, ldr=ldr or 0,
-                            nc_scale=nc_scale, rows_per_image=oh * ow, act=spec.act)
+                            nc_scale=nc_scale, rows_per_image=oh * ow, act=spec.act, out3=out3)
+            if out3 is not None:
+                attach_x3(out, out3, m, k)
         if need_grad:
             ctx.spec = spec
             ctx.image_input = image_input
@@ -689,16 +702,22 @@ class _ConvBnAct(torch.autograd.Function):
                     # averager scales BN affine gradients exactly like conv weight gradients
                     dbeta, dgamma = db.clone(), dg.clone()
                     _allreduce_bn_grads(sums, ctx.sync_world)
+            dy3 = None
+            if (x3_pipeline() and dt == torch.float32 and not spec.depthwise and not ctx.image_input and ctx.needs_input_grad[0]
+                    and c > 32 and k >= 32):
+                dy3 = x3_alloc_for(m, k, dev)  # dy also as split rows: the operand of the input-gradient launch below
             if gate:
                 check(lib.dass_bn_bwd_apply_gate(_p(dout_r), lddo, _p(y_raw), k, _p(mean_v), _p(invstd_v), _p(gamma_v.detach()), _p(db), _p(dg),
                                                  _p(bn_scale), _p(bn_shift), _p(nc_scale), _p(dy), lddy, m, k, oh * ow,
-                                                 float(m) * ctx.sync_world, 1 if ctx.train_stats else 0, spec.act, _dt(out), _stream()),
-                      "dass_bn_bwd_apply_gate")
+                                                 float(m) * ctx.sync_world, 1 if ctx.train_stats else 0, spec.act, _dt(out), _p(dy3),
+                                                 _stream()), "dass_bn_bwd_apply_gate")
             else:
                 check(lib.dass_bn_bwd_apply(_p(dout_r), lddo, _p(out), ldo, _p(src), k, _p(mean_v), _p(invstd_v),
                                             _p(gamma_v.detach() if gamma_v is not None else None), _p(db), _p(dg),
                                             _p(nc_scale), _p(dy), lddy, _p(dres), k, m, k, oh * ow, float(m) * ctx.sync_world,
-                                            1 if ctx.train_stats else 0, spec.act, _dt(out), _stream()), "dass_bn_bwd_apply")
+                                            1 if ctx.train_stats else 0, spec.act, _dt(out), _p(dy3), _stream()), "dass_bn_bwd_apply")
+            if dy3 is not None:
+                attach_x3(dy, dy3, m, k)
         dx = dw = None
         kk = kp if simple else k
         if spec.depthwise:
@@ -822,11 +841,12 @@ def _dgrad_operand_uncached(wsrc, dtype):
 
 
 def conv_bn_act(x, conv, bn=None, act=ACT_NONE, residual=None, nc_scale=None, extra_pad=0, image_input=False,
-                in_scale=None):
+                in_scale=None, emit_x3=True):
     """in_scale: [N,C] f32 multipliers applied to the INPUT while it is staged (inference only): a
     Dropout2d mask of the producer folded into this conv's loader (MC-dropout tail, SURVEY 8a note iii)."""
     spec = ConvSpec(conv, bn, act, extra_pad)
     spec.grad_enabled = torch.is_grad_enabled()
+    spec.emit_x3 = emit_x3  # False where the consumer is not a dense conv (concat / pool / upsample / classifier)
     if in_scale is not None:
         assert bn is None or not bn_use_batch_stats(bn), "in_scale needs eval-mode BN"
         spec.in_scale = in_scale.contiguous()
@@ -997,7 +1017,7 @@ class _BroadcastBN(torch.autograd.Function):
         dx = torch.empty((n, c), dtype=gs.dtype, device=gs.device)
         check(lib.dass_bn_bwd_apply(_p(gs), c, _p(yv), c, _p(xv), c, _p(mean), _p(invstd), _p(gamma.detach()),
                                     _p(sums[0]), _p(sums[1]), None, _p(dx), c, None, 0, n, c, 1, float(n) * ctx.sync_world,
-                                    1 if ctx.train_stats else 0, ACT_NONE, _dt(dx), _stream()), "dass_bn_bwd_apply")
+                                    1 if ctx.train_stats else 0, ACT_NONE, _dt(dx), None, _stream()), "dass_bn_bwd_apply")
         return dx.view(n, 1, 1, c).permute(0, 3, 1, 2), dgamma, dbeta, None, None, None
 
 

@@ -20,7 +20,7 @@ class ASPPModule(nn.Module):
         self._init_weight()
 
     def forward(self, x):
-        return ops.conv_bn_act(x, self.atrous_conv, self.bn, ops.ACT_RELU)
+        return ops.conv_bn_act(x, self.atrous_conv, self.bn, ops.ACT_RELU, emit_x3=False)  # consumer: the channel concat
 
     def _init_weight(self):
         init_weights(self)
@@ -69,13 +69,13 @@ class ASPP(nn.Module):
         x3 = self.aspp3(x)
         x4 = self.aspp4(x)
         x5 = ops.global_avgpool(x)
-        x5 = ops.conv_bn_act(x5, self.global_average_pool[1], None, ops.ACT_RELU)
+        x5 = ops.conv_bn_act(x5, self.global_average_pool[1], None, ops.ACT_RELU, emit_x3=False)
         x5 = ops.broadcast_bn(x5, self.bn_global_average_pool, h, w)
         cat = ops.concat(x1, x2, x3, x4, x5)
         mask = None
         if apply_dropout:
             mask = dropout_mask if dropout_mask is not None else dropout_mask_for(self.dropout, x.shape[0], 256, x.device)
-        return ops.conv_bn_act(cat, self.conv1, self.bn1, ops.ACT_RELU, nc_scale=mask)
+        return ops.conv_bn_act(cat, self.conv1, self.bn1, ops.ACT_RELU, nc_scale=mask, emit_x3=False)  # consumer: the decoder upsample
 
     def _init_weight(self):
         init_weights(self)

@@ -40,7 +40,7 @@ class InvertedResidual(nn.Module):
         c = self.conv
         res = x if self.use_res_connect else None
         if self.expand:
-            h = ops.conv_bn_act(x, c[0], c[1], ops.ACT_RELU6, extra_pad=d)   # 1x1 over the zero-padded input
+            h = ops.conv_bn_act(x, c[0], c[1], ops.ACT_RELU6, extra_pad=d, emit_x3=False)   # 1x1 over the zero-padded input (feeds the depthwise conv)
             h = ops.conv_bn_act(h, c[3], c[4], ops.ACT_RELU6)                 # depthwise, pad 0
             return ops.conv_bn_act(h, c[6], c[7], ops.ACT_NONE, residual=res)
         h = ops.conv_bn_act(x, c[0], c[1], ops.ACT_RELU6, extra_pad=d)       # depthwise over the padded input
@@ -95,7 +95,7 @@ class MobileNetV2(nn.Module):
     def _run(seq, x, first_is_image):
         for i, m in enumerate(seq):
             if isinstance(m, nn.Sequential):  # the stem conv_bn
-                x = ops.conv_bn_act(x, m[0], m[1], ops.ACT_RELU6, image_input=first_is_image and i == 0)
+                x = ops.conv_bn_act(x, m[0], m[1], ops.ACT_RELU6, image_input=first_is_image and i == 0, emit_x3=not (first_is_image and i == 0))
             elif isinstance(m, nn.Dropout2d):
                 mask = dropout_mask_for(m, x.shape[0], x.shape[1], x.device)
                 if mask is not None:

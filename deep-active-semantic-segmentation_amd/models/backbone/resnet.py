@@ -68,7 +68,7 @@ class ResNet(nn.Module):
 
     @ops.bn_counter_scope
     def forward(self, input):
-        x = ops.conv_bn_act(input, self.conv1, self.bn1, ops.ACT_RELU, image_input=True)
+        x = ops.conv_bn_act(input, self.conv1, self.bn1, ops.ACT_RELU, image_input=True, emit_x3=False)  # consumer: the max-pool
         x = ops.maxpool3x3s2(x)
         x = self.layer1(x)
         low_level_feat = x

@@ -41,17 +41,17 @@ class Decoder(nn.Module):
 
     def features(self, x, low_level_feat):
         """[upsampled ASPP output | 48-ch low-level] -- the core-set feature tensor (decoder.py:41-46)"""
-        low = ops.conv_bn_act(low_level_feat, self.conv1, self.bn1, ops.ACT_RELU)
+        low = ops.conv_bn_act(low_level_feat, self.conv1, self.bn1, ops.ACT_RELU, emit_x3=False)
         return ops.upsample_cat(x, low)
 
     def head(self, feats, dropout_mask=None, in_scale=None, mask_as_in_scale=None):
         lc = self.last_conv
         h = ops.conv_bn_act(feats, lc[0], lc[1], ops.ACT_RELU, in_scale=in_scale)
         if mask_as_in_scale is not None:  # inference: fold the Dropout2d mask into the classifier's loader
-            h = ops.conv_bn_act(h, lc[3], lc[4], ops.ACT_RELU)
+            h = ops.conv_bn_act(h, lc[3], lc[4], ops.ACT_RELU, emit_x3=False)
             return ops.conv_bn_act(h, lc[7], in_scale=mask_as_in_scale)
         mask = dropout_mask if dropout_mask is not None else dropout_mask_for(lc[6], feats.shape[0], 256, feats.device)
-        h = ops.conv_bn_act(h, lc[3], lc[4], ops.ACT_RELU, nc_scale=mask)
+        h = ops.conv_bn_act(h, lc[3], lc[4], ops.ACT_RELU, nc_scale=mask, emit_x3=False)  # consumer: the 19-class 1x1
         return ops.conv_bn_act(h, lc[7])
 
     # ---- MC-dropout scoring: last_conv[0] split along its input channels.  Only the 256 upsampled-ASPP channels carry a
@@ -110,7 +110,7 @@ class Decoder(nn.Module):
         h1 = ops.new_act(n, 256, h, w, torch.float32, feats.device)
         ops.conv_launch(xa, lda, wa, h1, 256, dims, scale=st.scale, shift=st.shift,
                         residual=yb, ldr=256, in_scale=m1.contiguous(), act=ops.ACT_RELU)
-        h2 = ops.conv_bn_act(h1, lc[3], lc[4], ops.ACT_RELU)
+        h2 = ops.conv_bn_act(h1, lc[3], lc[4], ops.ACT_RELU, emit_x3=False)
         return ops.conv_bn_act(h2, lc[7], in_scale=m2)
 
     @ops.bn_counter_scope

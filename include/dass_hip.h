@@ -151,10 +151,12 @@ int dass_bn_eval_scale_shift(const float *gamma, const float *beta, const float 
                              const float *running_var, float eps, int K,
                              float *mean, float *invstd, float *scale, float *shift, void *stream);
 /* out = act(x*scale[k] + shift[k] + residual) * nc_scale[n][k] ; n = m / rows_per_image */
+/* out3 (nullable, f32 only): the same values additionally as x3 rows [M + 1][ceil(K/32)][192] (see dass_split3_rows;
+ * K % 32 != 0: the caller zero-fills the buffer first); out may then be NULL when only the split form is consumed. */
 int dass_scale_shift_act(const void *x, int64_t ldx, void *out, int64_t ldo,
                          const float *scale, const float *shift, const void *residual, int64_t ldr,
                          const float *nc_scale, int64_t M, int K, int64_t rows_per_image,
-                         int act, int dtype, void *stream);
+                         int act, int dtype, void *out3, void *stream);
 /* backward of the above.  pass 1: partial[row][0][k]=sum dact, [1][k]=sum dact*xhat with
  * dact = dout*nc_scale*act'(out) and xhat=(x-mean)*invstd. */
 int dass_bn_bwd_reduce(const void *dout, int64_t lddo, const void *out, int64_t ldo,
@@ -169,8 +171,10 @@ int dass_bn_bwd_apply(const void *dout, int64_t lddo, const void *out, int64_t l
                       const float *gamma, const float *dbeta, const float *dgamma,
                       const float *nc_scale, void *dx, int64_t lddx, void *dres, int64_t lddr,
                       int64_t M, int K, int64_t rows_per_image, double count, int train,
-                      int act, int dtype, void *stream);
-/* the two passes for a layer WITHOUT residual, f32: the activation gate is re-derived from the conv output as
+                      int act, int dtype, void *dx3, void *stream);
+/* (dx3, nullable, f32 only: dx additionally as x3 rows, the operand of the input-gradient conv; K % 32 == 0 or a
+ * zero-filled buffer)
+ * the two passes for a layer WITHOUT residual, f32: the activation gate is re-derived from the conv output as
  * act'(fma(x, gate_scale, gate_shift)) -- the forward's own affine (dass_scale_shift_act applies exactly this fma), so the
  * gate is bit-identical to the one of the stored output and `out` is not read (one HBM pass less in each). */
 int dass_bn_bwd_reduce_gate(const void *dout, int64_t lddo, const void *x, int64_t ldx,
@@ -181,7 +185,7 @@ int dass_bn_bwd_apply_gate(const void *dout, int64_t lddo, const void *x, int64_
                            const float *mean, const float *invstd, const float *gamma, const float *dbeta, const float *dgamma,
                            const float *gate_scale, const float *gate_shift, const float *nc_scale,
                            void *dx, int64_t lddx, int64_t M, int K, int64_t rows_per_image, double count, int train,
-                           int act, int dtype, void *stream);
+                           int act, int dtype, void *dx3, void *stream);
 /* column sums only: out[k] = sum_m x[m,k] (bias gradient of decoder.last_conv.7) */
 int dass_colsum(const void *x, int64_t ldx, int64_t M, int K, float *partial, float *out, int dtype, void *stream);
 

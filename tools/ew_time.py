@@ -28,7 +28,7 @@ for m, k in ((8712, 1024), (8712, 256), (33800, 512), (133128, 256), (133128, 64
     t2 = timeit(lambda: check(lib.dass_bn_bwd_reduce(ops._p(dy), k, ops._p(out), k, ops._p(x), k, ops._p(mean), ops._p(inv), None, m, k, 1, ops.ACT_RELU,
                                                      ops._p(partial), 0, ops._stream()), "r"))
     t3 = timeit(lambda: check(lib.dass_bn_bwd_apply(ops._p(dy), k, ops._p(out), k, ops._p(x), k, ops._p(mean), ops._p(inv), ops._p(sc), ops._p(db), ops._p(dg), None,
-                                                    ops._p(dx), k, None, 0, m, k, 1, float(m), 1, ops.ACT_RELU, 0, ops._stream()), "a"))
+                                                    ops._p(dx), k, None, 0, m, k, 1, float(m), 1, ops.ACT_RELU, 0, None, ops._stream()), "a"))
     b = m * k * 4 / 1e9
     print("M=%6d K=%4d (%.1f MB): scale_shift_act %.1f us %.0f GB/s | bwd_reduce %.1f us %.0f GB/s | bwd_apply %.1f us %.0f GB/s"
           % (m, k, b * 1e3, t1 * 1e3, 2 * b / t1 * 1e3, t2 * 1e3, 3 * b / t2 * 1e3, t3 * 1e3, 4 * b / t3 * 1e3), flush=True)
