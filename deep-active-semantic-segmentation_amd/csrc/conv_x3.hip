@@ -585,7 +585,7 @@ static int dispatch_x3(X3P &p, hipStream_t st, long ws_bytes) {
         if (p.K <= 64) pick = 4;
         else if (t256 >= 4 * g_cus) pick = 1;
         else if (s_tile >= 100) { pick = 1; if (!mode) mode = 2; }
-        else pick = 4;
+        else { pick = 4; if (!mode) mode = 1; }  // short reductions: segments would be too short to amortise the fix-up
     }
     switch (pick) {
     case 1: return launch_x3<256, 128, 4, 2, 2>(p, st, mode, ws_bytes);

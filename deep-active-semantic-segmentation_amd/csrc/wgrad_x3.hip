@@ -1,0 +1,329 @@
+// Conv weight gradient on PRE-SPLIT operands for gfx950: dW[k][tap][c] = sum over output pixels of dY[pix][k] * X[pix @ tap][c].
+//
+// conv_igemm.hip's wgrad kernels split both f32 operands into three bf16 parts while staging them -- every dy / x slab is
+// converted again by each of the up to 18 workgroups (taps x tiles) that read it.  Here both operands arrive as x3 rows
+// (csrc/conv_x3.hip): dy3 from the BN-backward pass, x3 from the forward's producer, so the loop is copy + MFMA only:
+//   * the reduction index is the PIXEL: a 32-pixel slab of 32 channels of one part is two 1 KiB pieces
+//     [16 pixels][32 ch] bf16, fetched by ONE LDS-DMA instruction each (lane = pixel l >> 2, 16-B chunk l & 3);
+//     out-of-image taps and pixels beyond the split read the operand's zero row;
+//   * MFMA fragments want 8 consecutive pixels of one channel per lane while the image is [pixel][channel]: gfx950's
+//     transposed LDS read (ds_read_b64_tr_b16) delivers exactly that, conflict-free on unpadded 64-B rows;
+//   * same ring / one barrier per slab / counted vmcnt / half-slab skew as conv_x3_kernel;
+//   * one workgroup = (K-tile, C-tile, tap, pixel split); partial tiles are added into dW with f32 atomics in
+//     two-128-B-segment wave instructions (the shape that runs at the full atomic rate).
+// Reference site replaced: the weight gradient autograd derives for every dense nn.Conv2d of the DeepLab path.
+#include "dass_common.h"
+#include <cstdlib>
+
+namespace {
+
+struct WX3P {
+    const char *dy3;   // [M + 1][KC][192], row M zero
+    const char *x3;    // [rows_in + 1][CC][192], row rows_in zero
+    float *dw;         // [K][R*S][C] f32, accumulated atomically
+    unsigned dy3_bytes, x3_bytes, dy_zero, x_zero, dy_pitch, x_pitch;
+    int N, H, W, C, OH, OW, K, R, S, stride, pad, dil;
+    int M, KC, CC, ktiles, ctiles, psplit, pix_per_split;
+};
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void wdma16(v4i rsrc, unsigned lds, unsigned voff) {  // see conv_x3.hip:dma16
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds), "s"(rsrc)
+                 : "memory");
+}
+__device__ __forceinline__ v4i wmake_srd(const void *base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    v4i r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+template <int N> __device__ __forceinline__ void wwait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// transposed LDS read issued through asm: the wait is the caller's (lgkmcnt counted by hand below)
+__device__ __forceinline__ v2u tr16(unsigned addr) {
+    v2u v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+
+// Tile BMK (out channels) x BNC (in channels); NW waves as WARPS_M x WARPS_N.  LDS stage = 32 pixels:
+// operand A (dy): BMK/32 chunks x 3 parts x 2 pixel halves, piece (chunk ch, part pl, half hf) at ((ch*3 + pl)*2 + hf) * 1024;
+// operand B (x) behind it with BNC/32 chunks.
+template <int BMK, int BNC, int WARPS_M, int WARPS_N, int NSTAGE>
+__global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void wgrad_x3_kernel(const WX3P p) {
+    constexpr int NW = WARPS_M * WARPS_N;
+    constexpr int TMW = BMK / WARPS_M, TNW = BNC / WARPS_N, MT = TMW / 32, NT = TNW / 32;
+    constexpr int ACH = BMK / 32, BCH = BNC / 32;           // 32-channel chunks per operand
+    constexpr int A_BYTES = ACH * 6144, B_BYTES = BCH * 6144, STAGE = A_BYTES + B_BYTES;
+    constexpr int CHW = (ACH + BCH) / NW;                   // chunks a wave loads (all three parts, both pixel halves)
+    static_assert((ACH + BCH) % NW == 0 && CHW >= 1, "chunks must divide over the waves");
+    static_assert(ACH % CHW == 0, "a wave loads chunks of ONE operand");
+    constexpr int G = CHW * 6;                              // DMA instructions per wave and slab
+    static_assert(MT >= 1 && NT >= 1 && NSTAGE >= 2 && NSTAGE <= 3 && G * (NSTAGE - 2) <= 63, "tile");
+    __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE];
+
+    int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tap = wg % (p.R * p.S);
+    wg /= (p.R * p.S);
+    const int ct = wg % p.ctiles;
+    wg /= p.ctiles;
+    const int kt = wg % p.ktiles;
+    const int ps = wg / p.ktiles;
+    const int k0 = kt * BMK, c0 = ct * BNC;
+    const int r = tap / p.S, s2 = tap - r * p.S;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WARPS_N, wn = wave - wm * WARPS_N;
+    const int ohw = p.OH * p.OW;
+    const long pbeg = (long)ps * p.pix_per_split;
+    long pend = pbeg + p.pix_per_split;
+    if (pend > p.M) pend = p.M;
+    const int total = (int)((pend - pbeg + 31) / 32);       // 32-pixel slabs
+
+    const v4i rsa = wmake_srd(p.dy3, p.dy3_bytes), rsb = wmake_srd(p.x3, p.x3_bytes);
+    const unsigned smem_base = (unsigned)(size_t)smem;
+
+    // ---- loader role of this wave: chunks first_ch .. first_ch + CHW - 1 of operand A (waves below ACH / CHW) or B
+    const bool loads_a = wave * CHW < ACH;                  // wave-uniform
+    const int first_ch = loads_a ? wave * CHW : wave * CHW - ACH;
+    const int lp = lane >> 2;                               // pixel row of the piece this lane fetches
+    const unsigned chunk16 = (unsigned)((lane & 3) * 16);
+    // pixel cursors: pixel (pbeg + 16 * half + lp) of the CURRENT slab to issue, advanced by 32 per slab
+    long cur_pix[2];
+    int c_oh[2], c_ow[2];
+    unsigned c_off[2];                                      // operand B: byte offset of the tap's input pixel row (x3)
+    const int tap_dy = -p.pad + r * p.dil, tap_dx = -p.pad + s2 * p.dil;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        cur_pix[hf] = pbeg + 16 * hf + lp;
+        const long pix = cur_pix[hf] < p.M ? cur_pix[hf] : 0;
+        const int n = (int)(pix / ohw);
+        const int rem = (int)(pix - (long)n * ohw);
+        c_oh[hf] = rem / p.OW;
+        c_ow[hf] = rem - c_oh[hf] * p.OW;
+        c_off[hf] = (unsigned)(((long)n * p.H + (c_oh[hf] * p.stride + tap_dy)) * p.W + (c_ow[hf] * p.stride + tap_dx)) * p.x_pitch;
+    }
+    const unsigned adv_px = (unsigned)(32 * p.stride) * p.x_pitch;
+    const unsigned adv_row = (unsigned)(p.stride * p.W - p.OW * p.stride) * p.x_pitch;
+    const unsigned adv_img = (unsigned)(p.H * p.W - p.OH * p.stride * p.W) * p.x_pitch;
+
+    auto issue_slab = [&](int stage) {
+        const unsigned st = smem_base + (unsigned)(stage * STAGE);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const bool live = cur_pix[hf] < pend;
+            unsigned src;
+            if (loads_a) {
+                src = live ? (unsigned)cur_pix[hf] * p.dy_pitch : p.dy_zero;
+            } else {
+                const int iy = c_oh[hf] * p.stride + tap_dy, ix = c_ow[hf] * p.stride + tap_dx;
+                src = (live && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? c_off[hf] : p.x_zero;
+            }
+            const bool zero = loads_a ? !live : src == p.x_zero;
+#pragma unroll
+            for (int j = 0; j < CHW; ++j) {
+                const int ch = first_ch + j;
+                const int gch = (loads_a ? k0 : c0) / 32 + ch;                 // chunk index in the tensor
+                const bool ch_ok = gch < (loads_a ? p.KC : p.CC);            // beyond the tensor: zeros
+                const unsigned base = (zero || !ch_ok) ? (loads_a ? p.dy_zero : p.x_zero) : src + (unsigned)(gch * 192);
+                const unsigned dst = __builtin_amdgcn_readfirstlane(st + (loads_a ? 0 : A_BYTES) + ((ch * 3) * 2 + hf) * 1024);
+                wdma16(loads_a ? rsa : rsb, dst, base + chunk16);
+                wdma16(loads_a ? rsa : rsb, dst + 2048, base + 64 + chunk16);
+                wdma16(loads_a ? rsa : rsb, dst + 4096, base + 128 + chunk16);
+            }
+            // advance this cursor by 32 pixels
+            cur_pix[hf] += 32;
+            if (!loads_a) {
+                c_ow[hf] += 32;
+                c_off[hf] += adv_px;
+                while (c_ow[hf] >= p.OW) {
+                    c_ow[hf] -= p.OW;
+                    c_off[hf] += adv_row;
+                    if (++c_oh[hf] >= p.OH) {
+                        c_oh[hf] = 0;
+                        c_off[hf] += adv_img;
+                    }
+                }
+            }
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // ---- transposed-read lane roles: group g = lane >> 4 -> channel half (g & 1), pixel half of the 16-deep k-step
+    // (g >> 1); inside the group lane 4 q + pp supplies the address of pixel row q, 4-channel column chunk pp
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const unsigned lane_off = (unsigned)((8 * (g >> 1) + q) * 64 + (16 * (g & 1) + 4 * pp) * 2);
+    const unsigned a_rd = smem_base + (unsigned)((wm * (TMW / 32)) * 6144) + lane_off;
+    const unsigned b_rd = smem_base + (unsigned)(A_BYTES + (wn * (TNW / 32)) * 6144) + lane_off;
+
+    int issued = 0;
+#pragma unroll
+    for (int sg = 0; sg < NSTAGE - 1; ++sg)
+        if (issued < total) {
+            issue_slab(sg);
+            ++issued;
+        }
+
+    // fragments of one 16-pixel k-step: [part][block][pixels 0-3 / 4-7 of this lane's half].  They stay in the registers
+    // the asm reads wrote until the explicit lgkmcnt wait (the compiler does not know these loads: cdna_hip_programming.md
+    // 5.7 form (iii)); the 16-B operands are assembled inside multiply(), after the wait.
+    v2u a0[3][MT][2], b0[3][NT][2], a1[3][MT][2], b1[3][NT][2];
+    auto load_frags = [&](unsigned abase, unsigned bbase, v2u(&a)[3][MT][2], v2u(&b)[3][NT][2]) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                b[pl][nt][0] = tr16(bbase + nt * 6144 + pl * 2048);
+                b[pl][nt][1] = tr16(bbase + nt * 6144 + pl * 2048 + 256);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                a[pl][mt][0] = tr16(abase + mt * 6144 + pl * 2048);
+                a[pl][mt][1] = tr16(abase + mt * 6144 + pl * 2048 + 256);
+            }
+        }
+    };
+    auto multiply = [&](const v2u(&a)[3][MT][2], const v2u(&b)[3][NT][2]) {
+        auto frag = [](const v2u(&f)[2]) { return make_uint4(f[0][0], f[0][1], f[1][0], f[1][1]); };
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    constexpr int PA_OF[6] = {0, 2, 1, 0, 1, 0}, PB_OF[6] = {2, 0, 1, 1, 0, 0};
+                    const uint4 av = frag(a[PA_OF[term]][mt]), bv = frag(b[PB_OF[term]][nt]);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&av),
+                                                                          *reinterpret_cast<const bf16x8 *>(&bv), acc[mt][nt], 0, 0, 0);
+                }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    int cur = 0, nxt = NSTAGE - 1;
+    for (int s = 0; s < total; ++s) {
+        const int later = issued - s - 1;
+        if (NSTAGE >= 3 && later >= 1) wwait_vmcnt<(NSTAGE >= 3 ? G : 0)>();
+        else wwait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned so = (unsigned)(cur * STAGE);
+        // k-step 0 = pixels 0..15 of the slab (pieces hf = 0), k-step 1 = pixels 16..31 (hf = 1, + 1024)
+        if (s > 0) {
+            // slab s-1 / k-step 1 sits in a1 / b1: its reads were issued before the previous multiply and waited for below
+            load_frags(a_rd + so, b_rd + so, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (issued < total) {
+                issue_slab(nxt);
+                ++issued;
+            }
+            multiply(a1, b1);
+        } else {
+            load_frags(a_rd + so, b_rd + so, a0, b0);
+            if (issued < total) {
+                issue_slab(nxt);
+                ++issued;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a0 / b0 have landed (the asm reads are not counted by the compiler)
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(a_rd + so + 1024, b_rd + so + 1024, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(a0, b0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a1 / b1 have landed
+        __builtin_amdgcn_sched_barrier(0);
+        cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+        nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
+    }
+    if (total > 0) multiply(a1, b1);
+    wwait_vmcnt<0>();
+
+    const long rs = (long)p.R * p.S;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int c = c0 + wn * TNW + nt * 32 + (lane & 31);
+        if (c >= p.C) continue;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                const int k = k0 + wm * TMW + mt * 32 + row;
+                if (k < p.K) atomicAdd(p.dw + ((long)k * rs + tap) * p.C + c, acc[mt][nt][reg]);
+            }
+        }
+    }
+}
+
+static long wx3_split(long base, long M, long target_wgs, long min_slabs) {
+    long want = (target_wgs + base - 1) / base;
+    long maxsplit = M / (32 * min_slabs);
+    if (maxsplit < 1) maxsplit = 1;
+    if (want > maxsplit) want = maxsplit;
+    return want < 1 ? 1 : want;
+}
+
+template <int BMK, int BNC, int WARPS_M, int WARPS_N, int NSTAGE> int launch_wx3(WX3P &p, hipStream_t st, long target, long min_slabs) {
+    p.ktiles = (p.K + BMK - 1) / BMK;
+    p.ctiles = (p.C + BNC - 1) / BNC;
+    const long base = (long)p.ktiles * p.ctiles * p.R * p.S;
+    const long split = wx3_split(base, p.M, target, min_slabs);
+    long pps = (p.M + split - 1) / split;
+    pps = (pps + 31) / 32 * 32;
+    p.pix_per_split = (int)pps;
+    p.psplit = (int)((p.M + pps - 1) / pps);
+    hipLaunchKernelGGL((wgrad_x3_kernel<BMK, BNC, WARPS_M, WARPS_N, NSTAGE>), dim3((unsigned)(base * p.psplit)), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+}  // namespace
+
+extern "C" int dass_conv2d_wgrad_x3(const void *x3, const void *dy3, float *dw, int N, int H, int W, int C, int OH, int OW, int K, int R,
+                                    int S, int stride, int pad, int dil, int zero_first, void *stream) {
+    if (!x3 || !dy3 || !dw) return DASS_ERR_ARG;
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || K <= 0 || R <= 0 || S <= 0 || stride < 1 || dil < 1) return DASS_ERR_ARG;
+    if (((uintptr_t)x3 & 15) || ((uintptr_t)dy3 & 15)) return DASS_ERR_ARG;
+    if ((long)N * OH * OW >= (1l << 31)) return DASS_ERR_ARG;
+    const int CC = (C + 31) / 32, KC = (K + 31) / 32;
+    const long xbytes = ((long)N * H * W + 1) * CC * 192, dbytes = ((long)N * OH * OW + 1) * KC * 192;
+    if (xbytes >= (1l << 32) || dbytes >= (1l << 32)) return DASS_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (zero_first && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * R * S * C, st) != hipSuccess) return DASS_ERR_LAUNCH;
+    WX3P p;
+    p.dy3 = (const char *)dy3;
+    p.x3 = (const char *)x3;
+    p.dw = dw;
+    p.dy3_bytes = (unsigned)dbytes;
+    p.x3_bytes = (unsigned)xbytes;
+    p.dy_pitch = (unsigned)(KC * 192);
+    p.x_pitch = (unsigned)(CC * 192);
+    p.dy_zero = (unsigned)((long)N * OH * OW * KC * 192);
+    p.x_zero = (unsigned)((long)N * H * W * CC * 192);
+    p.N = N; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K; p.R = R; p.S = S;
+    p.stride = stride; p.pad = pad; p.dil = dil;
+    p.M = N * OH * OW;
+    p.KC = KC; p.CC = CC;
+    static const long target = getenv("DASS_WX3_TARGET") ? atol(getenv("DASS_WX3_TARGET")) : 768;
+    static const long min_slabs = getenv("DASS_WX3_MINSLABS") ? atol(getenv("DASS_WX3_MINSLABS")) : 16;
+    static const int force = getenv("DASS_WX3_TILE") ? atoi(getenv("DASS_WX3_TILE")) : 0;
+    const bool big = (K > 64 && C > 64 && force != 2) || force == 1;
+    if (big) return launch_wx3<128, 128, 4, 2, 3>(p, st, target, min_slabs);
+    return launch_wx3<64, 64, 2, 2, 3>(p, st, target, min_slabs);
+}

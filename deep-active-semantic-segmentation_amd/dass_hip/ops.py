@@ -538,6 +538,7 @@ class _ConvBnAct(torch.autograd.Function):
         ldo = kpad
         state = None
         y_raw = None
+        x3_saved = None  # split rows of the input, kept for the weight gradient (dass_conv2d_wgrad_x3)
         batch_stats = bn is not None and bn_use_batch_stats(bn)
         fuse = (not spec.depthwise) and (not rowtap) and (bn is None or (not batch_stats and not need_grad))
         # pipelined pre-split engine: dense convs of the bf16x6 engine with enough output channels for its tiles
@@ -585,6 +586,7 @@ class _ConvBnAct(torch.autograd.Function):
             fused_stats = None
             if use_x3:
                 x3 = x3_operand(x, xs, ldx, n * h * w, c)
+                x3_saved = x3
                 w_op = weight_operand(weight, 0, dt, cpad=c)
                 partial = None
                 if batch_stats:
@@ -631,12 +633,12 @@ class _ConvBnAct(torch.autograd.Function):
                                   state.mean if state is not None else None,
                                   state.invstd if state is not None else None,
                                   state.scale if state is not None else None,
-                                  state.shift if state is not None else None)
+                                  state.shift if state is not None else None, x3_saved)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        xs, weight, gamma, y_raw, out, nc_scale, mean, invstd, bn_scale, bn_shift = ctx.saved_tensors
+        xs, weight, gamma, y_raw, out, nc_scale, mean, invstd, bn_scale, bn_shift, x3_in = ctx.saved_tensors
         spec = ctx.spec
         n, h, w, c, oh, ow, k, ldx, ldo, c_in = ctx.dims
         dt = out.dtype
@@ -703,9 +705,9 @@ class _ConvBnAct(torch.autograd.Function):
                     dbeta, dgamma = db.clone(), dg.clone()
                     _allreduce_bn_grads(sums, ctx.sync_world)
             dy3 = None
-            if (x3_pipeline() and dt == torch.float32 and not spec.depthwise and not ctx.image_input and ctx.needs_input_grad[0]
-                    and c > 32 and k >= 32):
-                dy3 = x3_alloc_for(m, k, dev)  # dy also as split rows: the operand of the input-gradient launch below
+            if (x3_pipeline() and dt == torch.float32 and not spec.depthwise and not ctx.image_input and k >= 32
+                    and ((ctx.needs_input_grad[0] and c > 32) or (ctx.needs_input_grad[1] and x3_in is not None))):
+                dy3 = x3_alloc_for(m, k, dev)  # dy also as split rows: operand of the input- and weight-gradient launches
             if gate:
                 check(lib.dass_bn_bwd_apply_gate(_p(dout_r), lddo, _p(y_raw), k, _p(mean_v), _p(invstd_v), _p(gamma_v.detach()), _p(db), _p(dg),
                                                  _p(bn_scale), _p(bn_shift), _p(nc_scale), _p(dy), lddy, m, k, oh * ow,
@@ -753,8 +755,14 @@ class _ConvBnAct(torch.autograd.Function):
                     wstream = ctypes.c_void_p(side.cuda_stream)
                 else:
                     wstream = _stream()
-                check(lib.dass_conv2d_wgrad_acc(_p(xs), ldx, _p(dy), lddy, _p(dwk), n, h, w, c, oh, ow, kk, r, s,
-                                                spec.stride, spec.pad, spec.dil, _cdt(dy), wstream), "dass_conv2d_wgrad_acc")
+                dy3_w = dy.__dict__.get("_dass_x3") if x3_in is not None and kk == k and x3_pipeline() else None
+                if dy3_w is not None and dy3_w[0] == (dy.data_ptr(), dy._version, m, k):
+                    # both operands already exist as split rows (forward producer / BN-backward pass): copy + MFMA only
+                    check(lib.dass_conv2d_wgrad_x3(_p(x3_in), _p(dy3_w[1]), _p(dwk), n, h, w, c, oh, ow, kk, r, s, spec.stride, spec.pad,
+                                                   spec.dil, 0, wstream), "dass_conv2d_wgrad_x3")
+                else:
+                    check(lib.dass_conv2d_wgrad_acc(_p(xs), ldx, _p(dy), lddy, _p(dwk), n, h, w, c, oh, ow, kk, r, s,
+                                                    spec.stride, spec.pad, spec.dil, _cdt(dy), wstream), "dass_conv2d_wgrad_acc")
                 if side is not None:
                     _EV_JOIN.record(side)
                     join = _EV_JOIN

@@ -327,6 +327,11 @@ int dass_conv2d_x3(const void *x3, const void *w3, void *y, int64_t ldy, void *y
                    const float *shift, const void *residual, int64_t ldr, int N, int H, int W, int C, int OH, int OW,
                    int K, int R, int S, int stride, int pad, int dil, int ustride, int act, float *stat_partial,
                    int *stat_rows, void *workspace, int64_t workspace_bytes, void *stream);
+/* weight gradient of the same conv from pre-split operands: dw[K][R][S][C] (f32) (+)= sum over output pixels of
+ * dy[pix][k] * x[pix @ tap][c]; x3 = the forward input, dy3 = the gradient of the conv output (both x3 rows with their zero
+ * row; csrc/wgrad_x3.hip).  zero_first = 1 clears dw, 0 accumulates (pixel splits add with f32 atomics either way). */
+int dass_conv2d_wgrad_x3(const void *x3, const void *dy3, float *dw, int N, int H, int W, int C, int OH, int OW, int K,
+                         int R, int S, int stride, int pad, int dil, int zero_first, void *stream);
 
 #ifdef __cplusplus
 }

@@ -196,3 +196,32 @@ def test_x3_stream_k_is_deterministic_and_matches_one_tile_per_workgroup():
     assert torch.equal(outs[0], outs[1])
     for other in outs[2:]:
         assert (outs[0] - other).abs().max().item() <= 2e-6 * outs[0].abs().max().item()
+
+
+@pytest.mark.parametrize("case", [(2, 64, 33, 33, 96, 3, 1, 1, 1), (2, 128, 35, 35, 128, 3, 2, 1, 1), (3, 256, 17, 17, 512, 1, 1, 0, 1),
+                                  (1, 72, 33, 33, 40, 3, 1, 4, 4), (8, 256, 33, 33, 256, 3, 1, 1, 1), (2, 304, 29, 31, 256, 3, 1, 1, 1),
+                                  (2, 96, 9, 9, 320, 1, 1, 2, 1)])
+def test_x3_wgrad_vs_f64(case):
+    """weight gradient from pre-split operands (csrc/wgrad_x3.hip: transposed LDS reads of DMA-filled [pixel][channel]
+    pieces) against an f64 autograd gradient; pixel splits accumulate with f32 atomics, hence the 4e-6 bound"""
+    from dass_hip import ops
+    from dass_hip._lib import check, lib
+
+    n, c, h, wd, k, ks, stride, pad, dil = case
+    x, w = _inputs(case)
+    oh, ow = ops.conv_out_size(h, ks, stride, pad, dil), ops.conv_out_size(wd, ks, stride, pad, dil)
+    g = torch.Generator().manual_seed(9)
+    dy = torch.randn(n, k, oh, ow, generator=g)
+    wd64 = w.double().requires_grad_(True)
+    F.conv2d(x.double(), wd64, None, stride, pad, dil).backward(dy.double())
+    ref = wd64.grad.permute(0, 2, 3, 1)  # [K][R][S][C]
+    x3, dy3 = _x3_of(ops, x), _x3_of(ops, dy)
+    dw = torch.full((k, ks, ks, c), float("nan"), device="cuda")
+    # K, C > 64 -> the 128 x 128 tile (8 waves), otherwise 64 x 64 (4 waves): the cases cover both
+    check(lib.dass_conv2d_wgrad_x3(ops._p(x3), ops._p(dy3), ops._p(dw), n, h, wd, c, oh, ow, k, ks, ks, stride, pad, dil, 1, ops._stream()),
+          "dass_conv2d_wgrad_x3")
+    assert _rel(dw, ref) <= 4e-6, (case, _rel(dw, ref))
+    # accumulate form: a second call adds the same gradient again
+    check(lib.dass_conv2d_wgrad_x3(ops._p(x3), ops._p(dy3), ops._p(dw), n, h, wd, c, oh, ow, k, ks, ks, stride, pad, dil, 0, ops._stream()),
+          "dass_conv2d_wgrad_x3")
+    assert _rel(dw, 2 * ref) <= 4e-6
