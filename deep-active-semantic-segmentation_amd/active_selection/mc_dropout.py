@@ -99,21 +99,25 @@ class ActiveSelectionMCDropout(ActiveSelectionBase):
         base_size = 512 if self.crop_size == -1 else self.crop_size
         dev = next(self.unwrap(model).parameters()).device
         out_hw = base_size - region_size + 1
-        score_maps = torch.empty((len(images), out_hw, out_hw), dtype=torch.float32, device=dev)
+        # this rank's shard of the pool (the T-pass forwards are the cost); existing_regions is indexed like `images`
+        local, start = self.local_slice(images)
+        score_maps = torch.empty((len(local), out_hw, out_hw), dtype=torch.float32, device=dev)
         map_ctr = 0
-        for sample in self.make_loader(images, True):
+        for sample in self.make_loader(local, True):
             image_batch = sample['image'].to(dev)
             label_batch = sample['label'].to(dev)
             maps = self._get_vote_entropy_for_batch(model, image_batch, label_batch, steps)
             emaps = torch.stack(maps)
             for i in range(emaps.shape[0]):
-                regs = existing_regions[map_ctr + i]
+                regs = existing_regions[start + map_ctr + i]
                 if regs:
                     for lr in regs:
                         ops.zero_rect(emaps, i, lr[0], lr[0] + lr[2], lr[1], lr[1] + lr[3])
             score_maps[map_ctr:map_ctr + emaps.shape[0]] = ops.box_sum(emaps, region_size)
             map_ctr += emaps.shape[0]
-        ops.minmax_normalize_(score_maps)
+        # one min and one max over the WHOLE pool (mc_dropout.py:152-155), then every rank holds every normalised map
+        ops.minmax_normalize_(score_maps, self.global_minmax(ops.minmax(score_maps)))
+        score_maps = self.gather(score_maps, len(images))
         num_requested_indices = (selection_size * base_size * base_size) / (region_size * region_size)
         regions, num_selected_indices = ops.square_nms(score_maps, region_size, num_requested_indices)
         new_regions = {}

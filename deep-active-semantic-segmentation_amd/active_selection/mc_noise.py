@@ -98,17 +98,19 @@ class ActiveSelectionMCNoise(ActiveSelectionBase):
         base_size = 512 if self.crop_size == -1 else self.crop_size
         dev = next(self.unwrap(model).parameters()).device
         out_hw = base_size - region_size + 1
-        score_maps = torch.empty((len(images), out_hw, out_hw), dtype=torch.float32, device=dev)
+        local, start = self.local_slice(images)  # sharded like ActiveSelectionMCDropout.create_region_maps
+        score_maps = torch.empty((len(local), out_hw, out_hw), dtype=torch.float32, device=dev)
         map_ctr = 0
-        for sample in self.make_loader(images, True):
+        for sample in self.make_loader(local, True):
             image_batch, label_batch = sample['image'].to(dev), sample['label'].to(dev)
             emaps = torch.stack(self._combined(model, image_batch, label_batch))
             for i in range(emaps.shape[0]):
-                for lr in existing_regions[map_ctr + i] or []:
+                for lr in existing_regions[start + map_ctr + i] or []:
                     ops.zero_rect(emaps, i, lr[0], lr[0] + lr[2], lr[1], lr[1] + lr[3])
             score_maps[map_ctr:map_ctr + emaps.shape[0]] = ops.box_sum(emaps, region_size)
             map_ctr += emaps.shape[0]
-        ops.minmax_normalize_(score_maps)
+        ops.minmax_normalize_(score_maps, self.global_minmax(ops.minmax(score_maps)))
+        score_maps = self.gather(score_maps, len(images))
         num_requested_indices = (selection_size * base_size * base_size) / (region_size * region_size)
         regions, num_selected_indices = ActiveSelectionMCDropout.square_nms(score_maps, region_size, num_requested_indices)
         new_regions = {images[i]: regions[i] for i in range(len(regions)) if regions[i] != []}

@@ -1321,13 +1321,24 @@ def zero_rect(maps, i, r0, r1, c0, c1):
     check(lib.dass_zero_rect(_p(maps), i, h, w, r0, r1, c0, c1, _stream()), "dass_zero_rect")
 
 
-def minmax_normalize_(maps):
-    """x.add_(-min).mul_(1/(max-min)) over ALL maps (mc_dropout.py:152-155)"""
+def minmax(maps):
+    """-> device tensor [min, max] over every element (an empty tensor gives [+inf, -inf], the identities of min / max)"""
     nel = maps.numel()
+    if nel == 0:
+        return torch.tensor([float("inf"), float("-inf")], dtype=torch.float32, device=maps.device)
     partial = torch.empty((lib.dass_minmax_blocks(nel), 2), dtype=torch.float32, device=maps.device)
     mm = torch.empty((2,), dtype=torch.float32, device=maps.device)
     check(lib.dass_minmax(_p(maps), nel, _p(partial), _p(mm), _stream()), "dass_minmax")
-    check(lib.dass_affine_inplace(_p(maps), nel, _p(mm), _stream()), "dass_affine_inplace")
+    return mm
+
+
+def minmax_normalize_(maps, mm=None):
+    """x.add_(-min).mul_(1/(max-min)) over ALL maps (mc_dropout.py:152-155); mm: [min, max] computed elsewhere (the
+    GLOBAL extrema when the maps are one rank's shard of the pool)"""
+    if mm is None:
+        mm = minmax(maps)
+    if maps.numel():
+        check(lib.dass_affine_inplace(_p(maps), maps.numel(), _p(mm), _stream()), "dass_affine_inplace")
     return mm
 
 

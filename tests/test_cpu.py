@@ -306,6 +306,19 @@ assert feats.shape == (11, 3)
 picked = S.select_top(scores.tolist(), keys, 4, reverse=True)
 ref = S.select_top([score_of(k) for k in keys], keys, 4, reverse=True)
 assert picked == ref, (picked, ref)
+# region scoring (SURVEY 8e row 2): shard-local score maps, GLOBAL min / max (two one-float all-reduces), gather, then the
+# greedy NMS replicated on every rank == one process normalising and suppressing the whole pool
+g = torch.Generator().manual_seed(5)
+all_maps = torch.rand(len(keys), 12, 12, generator=g) * 3 + 0.5
+all_maps[7] *= 4.0                                   # the global max lives on ONE rank's shard, the min on the other's
+all_maps[2] *= 0.01
+mine = all_maps[start:start + len(local)].clone()
+mm = sel.global_minmax(torch.stack((mine.min(), mine.max())))
+assert float(mm[0]) == float(all_maps.min()) and float(mm[1]) == float(all_maps.max())
+mine.add_(-mm[0]).mul_(1.0 / (mm[1] - mm[0]))
+got_regions, got_count = S.square_nms(sel.gather(mine, len(keys)), 3, 9)
+want_regions, want_count = S.square_nms(S.minmax_normalize(all_maps.clone()), 3, 9)
+assert got_regions == want_regions and got_count == want_count
 print("rank %d ok %s" % (rank, picked))
 dist.destroy_process_group()
 """
