@@ -20,7 +20,8 @@ F32, BF16, F32X3, F32X6 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 
 _state = {"dtype": torch.float32, "f32_mma": os.environ.get("DASS_F32_MMA", "bf16x6"),
-          "x3": os.environ.get("DASS_X3", "1") == "1"}
+          "x3": os.environ.get("DASS_X3", "infer")}
+assert _state["x3"] in ("off", "infer", "all"), "DASS_X3 must be off, infer or all"
 assert _state["f32_mma"] in ("f32", "bf16x3", "bf16x6"), "DASS_F32_MMA must be f32, bf16x3 or bf16x6"
 
 
@@ -51,16 +52,25 @@ def f32_mma():
     return _state["f32_mma"]
 
 
-def set_x3_pipeline(on):
-    """bf16x6 engine only: True (default, DASS_X3=1) = dense convs run the pipelined pre-split kernel (csrc/conv_x3.hip:
-    activations converted ONCE to three bf16 parts by the producing pass, LDS-DMA ring, no conversion in the MFMA loop);
-    False = the classic kernel that converts inside its loop (csrc/conv_igemm.hip).  Same six products in the same
-    order either way: results agree to the last bit or two."""
-    _state["x3"] = bool(on)
+def set_x3_pipeline(mode):
+    """bf16x6 engine only -- where the dense convs run the pipelined pre-split kernels (csrc/conv_x3.hip, wgrad_x3.hip:
+    activations converted ONCE to three bf16 parts by the producing pass, LDS-DMA ring, no conversion in the MFMA loop)
+    instead of the classic kernel that converts inside its loop (csrc/conv_igemm.hip):
+      "infer" (default, DASS_X3) forward passes without autograd (pool scoring, validation): measured +8..25 % there;
+      "all"   training too (forward, input and weight gradients; the BN passes then also write split rows): measured
+              no faster than the classic engine on the R101 train step (DESIGN.md 5), offered for experiments;
+      "off"   never.
+    Same six products in the same order either way: results agree to the last bit or two."""
+    mode = {True: "all", False: "off"}.get(mode, mode)
+    assert mode in ("off", "infer", "all")
+    _state["x3"] = mode
 
 
-def x3_pipeline():
-    return _state["x3"] and _state["f32_mma"] == "bf16x6"
+def x3_pipeline(training=False):
+    """is the pre-split engine on for an inference call site (training=False) / for a call that records autograd"""
+    if _state["f32_mma"] != "bf16x6":
+        return False
+    return _state["x3"] == "all" or (_state["x3"] == "infer" and not training)
 
 
 def _cdt(t):
@@ -542,7 +552,8 @@ class _ConvBnAct(torch.autograd.Function):
         batch_stats = bn is not None and bn_use_batch_stats(bn)
         fuse = (not spec.depthwise) and (not rowtap) and (bn is None or (not batch_stats and not need_grad))
         # pipelined pre-split engine: dense convs of the bf16x6 engine with enough output channels for its tiles
-        use_x3 = (x3_pipeline() and dt == torch.float32 and not spec.depthwise and not rowtap and not image_input and k > 32)
+        x3_on = x3_pipeline(training=need_grad)
+        use_x3 = (x3_on and dt == torch.float32 and not spec.depthwise and not rowtap and not image_input and k > 32)
         dims = (n, h, w, c, oh, ow, k, r, weight.shape[3], spec.stride, spec.pad, spec.dil)
         if fuse and use_x3:
             scale = shift = None
@@ -613,7 +624,7 @@ class _ConvBnAct(torch.autograd.Function):
             else:
                 scale, shift = None, (bias.detach().float() if bias is not None else None)
             out3 = None
-            if x3_pipeline() and dt == torch.float32 and getattr(spec, "emit_x3", True) and k >= 32 and kpad == k:
+            if x3_on and dt == torch.float32 and getattr(spec, "emit_x3", True) and k >= 32 and kpad == k:
                 out3 = x3_alloc_for(m, k, dev)  # the consumer is (almost always) the next dense conv: hand it split rows
             scale_shift_act(y_raw, k, out, ldo, m, k, scale, shift, residual=res_t, ldr=ldr or 0,
                             nc_scale=nc_scale, rows_per_image=oh * ow, act=spec.act, out3=out3)
@@ -621,6 +632,7 @@ class _ConvBnAct(torch.autograd.Function):
                 attach_x3(out, out3, m, k)
         if need_grad:
             ctx.spec = spec
+            ctx.x3_on = x3_on
             ctx.image_input = image_input
             ctx.dims = (n, h, w, c, oh, ow, k, ldx, ldo, c_in)
             ctx.train_stats = batch_stats
@@ -705,7 +717,7 @@ class _ConvBnAct(torch.autograd.Function):
                     dbeta, dgamma = db.clone(), dg.clone()
                     _allreduce_bn_grads(sums, ctx.sync_world)
             dy3 = None
-            if (x3_pipeline() and dt == torch.float32 and not spec.depthwise and not ctx.image_input and k >= 32
+            if (ctx.x3_on and dt == torch.float32 and not spec.depthwise and not ctx.image_input and k >= 32
                     and ((ctx.needs_input_grad[0] and c > 32) or (ctx.needs_input_grad[1] and x3_in is not None))):
                 dy3 = x3_alloc_for(m, k, dev)  # dy also as split rows: operand of the input- and weight-gradient launches
             if gate:
@@ -755,7 +767,7 @@ class _ConvBnAct(torch.autograd.Function):
                     wstream = ctypes.c_void_p(side.cuda_stream)
                 else:
                     wstream = _stream()
-                dy3_w = dy.__dict__.get("_dass_x3") if x3_in is not None and kk == k and x3_pipeline() else None
+                dy3_w = dy.__dict__.get("_dass_x3") if x3_in is not None and kk == k and ctx.x3_on else None
                 if dy3_w is not None and dy3_w[0] == (dy.data_ptr(), dy._version, m, k):
                     # both operands already exist as split rows (forward producer / BN-backward pass): copy + MFMA only
                     check(lib.dass_conv2d_wgrad_x3(_p(x3_in), _p(dy3_w[1]), _p(dwk), n, h, w, c, oh, ow, kk, r, s, spec.stride, spec.pad,
@@ -771,7 +783,7 @@ class _ConvBnAct(torch.autograd.Function):
                 dx = new_act(n, c, h, w, dt, dev)
                 pad_t = spec.dil * (r - 1) - spec.pad
                 # dgrad = stride-1 conv over dy with flipped/transposed taps; ustride re-inserts the stride
-                if x3_pipeline() and dt == torch.float32 and c > 32 and kk == k and lddy % 4 == 0:
+                if ctx.x3_on and dt == torch.float32 and c > 32 and kk == k and lddy % 4 == 0:
                     dy3 = x3_operand(dy, dy, lddy, m, kk)
                     conv_x3_launch(dy3, w_t, dx, c, (n, oh, ow, kk, h, w, c, r, s, 1, pad_t, spec.dil), ustride=spec.stride)
                 else:

