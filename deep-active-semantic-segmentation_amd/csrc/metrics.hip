@@ -90,3 +90,44 @@ extern "C" int dass_bn_finalize_sums(const float *sums, int K, double count, con
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// DIAGNOSTIC (tools/clock_probe.py; never on the product path): the shader clock the chip holds while `blocks`
+// workgroups run a bf16 MFMA loop fed from LDS (the conv kernels' regime).  Each workgroup stamps s_memtime (shader
+// cycles) and s_memrealtime (100 MHz) around the loop: clock = d(memtime) / d(memrealtime) * 100 MHz
+// (MI355X_MICROARCH.md, "DVFS give-back" item 6).  out[block] = {cycles, realtime ticks}.
+__global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long *out, int iters, int use_lds) {
+    __shared__ __attribute__((aligned(16))) unsigned lds[4096];
+    for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = 0x3f803f80u ^ (i * 2654435761u >> 9);  // random-ish finite bf16 pairs
+    __syncthreads();
+    f32x16 acc[4];
+    for (int j = 0; j < 4; ++j)
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    uint4 a = *reinterpret_cast<const uint4 *>(&lds[(threadIdx.x * 4) & 4095]);
+    uint4 b = *reinterpret_cast<const uint4 *>(&lds[(threadIdx.x * 4 + 1024) & 4095]);
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+        if (use_lds) {  // two 16-B fragment reads per four MFMAs, like a 64 x 64 wave tile
+            a = *reinterpret_cast<const uint4 *>(&lds[(threadIdx.x * 4 + it * 64) & 4095]);
+            b = *reinterpret_cast<const uint4 *>(&lds[(threadIdx.x * 4 + it * 64 + 2048) & 4095]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&a), *reinterpret_cast<const bf16x8 *>(&b), acc[j], 0, 0, 0);
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float keep = 0.f;
+    for (int j = 0; j < 4; ++j) keep += acc[j][threadIdx.x & 15];
+    if (threadIdx.x == 0) {
+        out[blockIdx.x * 2] = c1 - c0;
+        out[blockIdx.x * 2 + 1] = r1 - r0;
+    }
+    if (keep == 123.456f) out[0] = 0;  // keeps the accumulators alive
+}
+
+extern "C" int dass_clock_probe(void *out, int blocks, int iters, int use_lds, void *stream) {
+    if (!out || blocks <= 0 || iters <= 0) return DASS_ERR_ARG;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned long long *)out, iters, use_lds);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}

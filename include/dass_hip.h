@@ -332,6 +332,10 @@ int dass_conv2d_x3(const void *x3, const void *w3, void *y, int64_t ldy, void *y
  * row; csrc/wgrad_x3.hip).  zero_first = 1 clears dw, 0 accumulates (pixel splits add with f32 atomics either way). */
 int dass_conv2d_wgrad_x3(const void *x3, const void *dy3, float *dw, int N, int H, int W, int C, int OH, int OW, int K,
                          int R, int S, int stride, int pad, int dil, int zero_first, void *stream);
+/* DIAGNOSTIC, not on the product path (tools/clock_probe.py): `blocks` workgroups run a bf16 MFMA loop (use_lds: with
+ * LDS fragment reads) and report {shader cycles, 100 MHz ticks} per block into out[2 * blocks] (uint64): the clock the chip
+ * sustains under that load = cycles / ticks * 100 MHz. */
+int dass_clock_probe(void *out, int blocks, int iters, int use_lds, void *stream);
 
 #ifdef __cplusplus
 }
