@@ -147,3 +147,168 @@ def test_mc_dropout_properties_full_size():
     assert diff <= votes.numel() * 1e-5  # tile decomposition differs with the batch: only exact near-ties may move
     _, means_s = ops.vote_entropy(sharded, lab.cuda(), ncls)
     assert (means_s - means).abs().max().item() <= 1e-4
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Independent value checks at full size: >= 4096 randomly chosen output pixels -- every image, all four
+# borders, the corners, the last M-tile and (through all K columns) the last N-tile -- of forward, input gradient and a
+# weight-gradient slice, against f64 dot products computed OUTSIDE the kernels (torch f64 over gathered 3x3 patches).
+def _sample_pixels(n, h, w, count, seed):
+    g = torch.Generator().manual_seed(seed)
+    idx = torch.stack((torch.randint(0, n, (count,), generator=g), torch.randint(0, h, (count,), generator=g),
+                       torch.randint(0, w, (count,), generator=g)), 1)
+    edge = []
+    for img in range(n):  # corners and a point on every border of every image; the very last pixel = last row of the last M-tile
+        for (yy, xx) in ((0, 0), (0, w - 1), (h - 1, 0), (h - 1, w - 1), (0, w // 2), (h - 1, w // 3), (h // 2, 0), (h // 3, w - 1)):
+            edge.append((img, yy, xx))
+    return torch.cat((idx, torch.tensor(edge)), 0)
+
+
+def _patches_f64(x_nhwc, pix, ks, pad, dil):
+    """x [N,H,W,C] (device) -> f64 [P, ks*ks*C]: the zero-padded receptive fields of the sampled pixels (stride 1)"""
+    n, h, w, c = x_nhwc.shape
+    xp = torch.zeros((n, h + 2 * pad, w + 2 * pad, c), dtype=torch.float64, device=x_nhwc.device)
+    xp[:, pad:pad + h, pad:pad + w] = x_nhwc.double()
+    cols = []
+    for r in range(ks):
+        for s in range(ks):
+            cols.append(xp[pix[:, 0], pix[:, 1] + r * dil, pix[:, 2] + s * dil])
+    return torch.cat(cols, 1)
+
+
+@pytest.mark.parametrize("shape", [(8, 129, 304, 256), (8, 193, 304, 256), (8, 33, 256, 256)])
+@pytest.mark.parametrize("engine", ["bf16x6", "bf16x6+x3", "f32"])
+def test_fullsize_conv_values_vs_f64_dot_products(shape, engine):
+    from dass_hip import ops
+    from dass_hip._lib import check, lib
+
+    n, hw, c, k = shape
+    x3_engine = engine.endswith("x3")
+    ops.set_f32_mma(engine.split("+")[0])
+    g = torch.Generator(device="cuda").manual_seed(n * hw + c)
+    x = torch.randn((n, hw, hw, c), device="cuda", generator=g)
+    wt = torch.randn((k, 3, 3, c), device="cuda", generator=g) * (2.0 / (9 * c)) ** 0.5
+    dy = torch.randn((n, hw, hw, k), device="cuda", generator=g)
+    dims = (n, hw, hw, c, hw, hw, k, 3, 3, 1, 1, 1)
+    pix = _sample_pixels(n, hw, hw, 4096, seed=hw).cuda()
+    w64 = wt.double()
+
+    # ---- forward
+    y = torch.full((n, hw, hw, k), float("nan"), device="cuda")
+    if x3_engine:
+        ops.conv_x3_launch(ops.split3_rows(x, c, n * hw * hw, c), ops.prepare_conv_weight(wt), y, k, dims)
+    else:
+        ops.conv_launch(x, c, ops.prepare_conv_weight(wt), y, k, dims)
+    ref = _patches_f64(x, pix, 3, 1, 1) @ w64.reshape(k, -1).t()
+    got = y[pix[:, 0], pix[:, 1], pix[:, 2]].double()
+    scale = ref.abs().max().item()
+    assert torch.isfinite(y).all()
+    assert (got - ref).abs().max().item() <= 2e-5 * scale, ("fwd", (got - ref).abs().max().item(), scale)
+
+    # ---- input gradient: dx[n,y,x,:] = sum over taps of dy[n, y+1-r, x+1-s, :] @ W[:, r, s, :]
+    dx = torch.full((n, hw, hw, c), float("nan"), device="cuda")
+    w_t = ops.prepare_conv_weight(wt.permute(3, 1, 2, 0).flip(1, 2).contiguous())  # [C][3][3][K], taps flipped
+    ddims = (n, hw, hw, k, hw, hw, c, 3, 3, 1, 1, 1)
+    if x3_engine:
+        ops.conv_x3_launch(ops.split3_rows(dy, k, n * hw * hw, k), w_t, dx, c, ddims)
+    else:
+        ops.conv_launch(dy, k, w_t, dx, c, ddims)
+    wflip = w64.flip(1, 2).permute(1, 2, 0, 3).reshape(9 * k, c)   # [(r', s', k), c] with r' = 2 - r
+    refd = _patches_f64(dy, pix, 3, 1, 1) @ wflip
+    gotd = dx[pix[:, 0], pix[:, 1], pix[:, 2]].double()
+    assert torch.isfinite(dx).all()
+    assert (gotd - refd).abs().max().item() <= 2e-5 * refd.abs().max().item(), "dgrad"
+
+    # ---- weight gradient, 8 output channels spread over the K tiles (including the last one), all taps and input channels
+    ksel = torch.tensor([0, 31, 64, 127, 128, 200, k - 2, k - 1], device="cuda")
+    dw = torch.full((k, 3, 3, c), float("nan"), device="cuda")
+    if x3_engine:
+        check(lib.dass_conv2d_wgrad_x3(ops._p(ops.split3_rows(x, c, n * hw * hw, c)), ops._p(ops.split3_rows(dy, k, n * hw * hw, k)),
+                                       ops._p(dw), n, hw, hw, c, hw, hw, k, 3, 3, 1, 1, 1, 1, ops._stream()), "dass_conv2d_wgrad_x3")
+    else:
+        check(lib.dass_conv2d_wgrad(ops._p(x), c, ops._p(dy), k, ops._p(dw), n, hw, hw, c, hw, hw, k, 3, 3, 1, 1, 1,
+                                    ops._cdt(x), ops._stream()), "dass_conv2d_wgrad")
+    xp = torch.zeros((n, hw + 2, hw + 2, c), dtype=torch.float64, device="cuda")
+    xp[:, 1:hw + 1, 1:hw + 1] = x.double()
+    dys = dy[..., ksel].double().reshape(-1, ksel.numel())
+    refw = torch.stack([torch.stack([dys.t() @ xp[:, r:r + hw, s:s + hw].reshape(-1, c) for s in range(3)], 1) for r in range(3)], 1)
+    gotw = dw[ksel].double()
+    assert torch.isfinite(dw).all()
+    assert (gotw - refw).abs().max().item() <= 1e-5 * refw.abs().max().item(), "wgrad"
+
+
+def test_config_b_r101_769_forward_and_mc_dropout():
+    """BASELINE config B's size (R101 os16, 769 x 769): forward through both parity engine paths (classic kernels under
+    autograd bookkeeping off = the pre-split inference engine, and with it switched off) agree to the parity tolerance with
+    identical argmax outside near-ties; MC-dropout: hoisted T passes == T full forwards, histogram sums to T, entropy in
+    range.  193 x 193 decoder maps, 49 x 49 ASPP maps: tile edges no 513 test touches."""
+    from dass_hip import ops
+
+    pm, O = _r101(seed=7)
+    n, hw, T = 2, 769, 3
+    x, lab = O.synthetic_batch(n, hw, hw, 19, first_index=30)
+    xd = x.cuda()
+    outs = {}
+    try:
+        for mode in ("infer", "off"):
+            ops.set_x3_pipeline(mode)
+            with torch.no_grad():
+                outs[mode] = pm(xd).float()
+    finally:
+        ops.set_x3_pipeline("infer")
+    a, b = outs["infer"], outs["off"]
+    assert a.shape == (n, 19, hw, hw) and torch.isfinite(a).all()
+    scale = a.abs().max().item()
+    assert (a - b).abs().max().item() <= 1e-3 * max(1.0, scale / 50), ((a - b).abs().max().item(), scale)
+    top = a.topk(2, dim=1)[0]
+    safe = (top[:, 0] - top[:, 1]) > 1e-3 * max(1.0, scale / 50)
+    assert torch.equal(a.argmax(1)[safe], b.argmax(1)[safe])
+    m1, m2 = O.dropout_masks(n, T, seed=8)
+    votes = pm.mc_dropout_votes(xd, T, masks=(m1, m2))
+    with torch.no_grad():
+        full = torch.stack([pm(xd, dropout_masks=(m1[t].cuda(), m2[t].cuda())).argmax(1) for t in range(T)], 1)
+    assert votes.shape == (n, T, hw, hw)
+    assert (votes.long() != full).float().mean().item() <= 1e-4   # near-tie pixels only
+    emap, means = ops.vote_entropy(votes, lab.cuda(), 19)
+    assert float(emap.min()) >= 0.0 and float(emap.max()) <= math.log2(min(T, 19)) + 1e-5
+    assert float(emap[:, : hw // 10].abs().max()) == 0.0   # ignore rows (label 255) score 0
+
+
+def test_config_c_mobilenet_voc_batch16_train_steps():
+    """BASELINE config C: DeepLab-MobileNetV2, 21 classes, 513 x 513, batch 16 -- three SGD steps on one fixed batch through
+    the product surface; the first-step loss (train-mode BN) equals the CPU oracle's, every parameter receives a finite
+    gradient, and the loss goes down."""
+    from dass_hip import ops
+    from dass_hip.optim import SGD
+    from models.deeplab import DeepLab
+    from oracle import deeplab_cpu as O
+    from oracle import selection_cpu as S
+    from utils.loss import SegmentationLosses
+
+    ncls, n, hw = 21, 16, 513
+    om = O.ODeepLab("mobilenet", 16, ncls)
+    O.fill_state_dict(om, seed=41, randomize_bn_stats=False)
+    pm = DeepLab(backbone="mobilenet", output_stride=16, num_classes=ncls, sync_bn=False, pretrained=False)
+    pm.load_state_dict(om.state_dict())
+    pm = pm.cuda().train()
+    x, lab = O.synthetic_batch(n, hw, hw, ncls, first_index=60)
+    m1, m2 = O.dropout_masks(n, 3, seed=42)
+    crit = SegmentationLosses(cuda=True).build_loss("ce")
+    opt = SGD([{"params": pm.get_1x_lr_params(), "lr": 0.007}, {"params": pm.get_10x_lr_params(), "lr": 0.07}], momentum=0.9, weight_decay=5e-4)
+    om.train()
+    torch.set_num_threads(min(16, torch.get_num_threads() or 16))
+    with torch.no_grad():
+        ref_loss = float(S.ce_loss(om(x, (m1[0], m2[0])), lab))
+    losses = []
+    xd, ld = x.cuda(), lab.cuda()
+    for step in range(3):
+        opt.zero_grad(set_to_none=True)
+        loss = crit(pm(xd, dropout_masks=(m1[step].cuda(), m2[step].cuda())), ld)
+        loss.backward()
+        if step == 0:
+            missing = [k for k, p in pm.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
+            assert not missing, missing[:5]
+        opt.step()
+        losses.append(loss.item())
+    assert abs(losses[0] - ref_loss) <= 2e-4 * abs(ref_loss), (losses[0], ref_loss)
+    assert losses[2] < losses[0], losses
