@@ -196,7 +196,8 @@ def test_fullsize_conv_values_vs_f64_dot_products(shape, engine):
     # ---- forward
     y = torch.full((n, hw, hw, k), float("nan"), device="cuda")
     if x3_engine:
-        ops.conv_x3_launch(ops.split3_rows(x, c, n * hw * hw, c), ops.prepare_conv_weight(wt), y, k, dims)
+        x3 = ops.split3_rows(x, c, n * hw * hw, c)
+        ops.conv_x3_launch(x3, ops.prepare_conv_weight(wt), y, k, dims)
     else:
         ops.conv_launch(x, c, ops.prepare_conv_weight(wt), y, k, dims)
     ref = _patches_f64(x, pix, 3, 1, 1) @ w64.reshape(k, -1).t()
@@ -210,7 +211,8 @@ def test_fullsize_conv_values_vs_f64_dot_products(shape, engine):
     w_t = ops.prepare_conv_weight(wt.permute(3, 1, 2, 0).flip(1, 2).contiguous())  # [C][3][3][K], taps flipped
     ddims = (n, hw, hw, k, hw, hw, c, 3, 3, 1, 1, 1)
     if x3_engine:
-        ops.conv_x3_launch(ops.split3_rows(dy, k, n * hw * hw, k), w_t, dx, c, ddims)
+        dy3 = ops.split3_rows(dy, k, n * hw * hw, k)
+        ops.conv_x3_launch(dy3, w_t, dx, c, ddims)
     else:
         ops.conv_launch(dy, k, w_t, dx, c, ddims)
     wflip = w64.flip(1, 2).permute(1, 2, 0, 3).reshape(9 * k, c)   # [(r', s', k), c] with r' = 2 - r
@@ -223,8 +225,9 @@ def test_fullsize_conv_values_vs_f64_dot_products(shape, engine):
     ksel = torch.tensor([0, 31, 64, 127, 128, 200, k - 2, k - 1], device="cuda")
     dw = torch.full((k, 3, 3, c), float("nan"), device="cuda")
     if x3_engine:
-        check(lib.dass_conv2d_wgrad_x3(ops._p(ops.split3_rows(x, c, n * hw * hw, c)), ops._p(ops.split3_rows(dy, k, n * hw * hw, k)),
-                                       ops._p(dw), n, hw, hw, c, hw, hw, k, 3, 3, 1, 1, 1, 1, ops._stream()), "dass_conv2d_wgrad_x3")
+        x3, dy3 = ops.split3_rows(x, c, n * hw * hw, c), ops.split3_rows(dy, k, n * hw * hw, k)  # held until the launch is enqueued
+        check(lib.dass_conv2d_wgrad_x3(ops._p(x3), ops._p(dy3), ops._p(dw), n, hw, hw, c, hw, hw, k, 3, 3, 1, 1, 1, 1, ops._stream()),
+              "dass_conv2d_wgrad_x3")
     else:
         check(lib.dass_conv2d_wgrad(ops._p(x), c, ops._p(dy), k, ops._p(dw), n, hw, hw, c, hw, hw, k, 3, 3, 1, 1, 1,
                                     ops._cdt(x), ops._stream()), "dass_conv2d_wgrad")

@@ -120,6 +120,12 @@ def test_resnet_gradients_with_oracle_gates_injected(engine, train_bn):
         rec.replay()
         lo = S.ce_loss(o64(x.double(), (m1[0].double(), m2[0].double())), lab)
         lo.backward()
+        if train_bn:  # the noise floor of the SAME gated network in stock f32 PyTorch (CPU), measured in the same run
+            o32 = O.ODeepLab("resnet", 16, ncls)
+            o32.load_state_dict(om.state_dict())
+            o32.train()
+            rec.used = [False] * len(rec.gates)
+            S.ce_loss(o32(x, (m1[0], m2[0])), lab).backward()
     finally:
         rec.restore()
     assert all(rec.used), "every recorded gate was consumed by the oracle: %d sites" % len(rec.gates)
@@ -131,11 +137,23 @@ def test_resnet_gradients_with_oracle_gates_injected(engine, train_bn):
                    for k, p in pm.named_parameters()), reverse=True)
     print("%s train_bn=%s: worst %.2e (%s), median %.2e over %d parameters" %
           (engine, train_bn, errs[0][0], errs[0][1], float(np.median([e for e, _ in errs])), len(errs)))
-    # frozen BN: the rounding level.  Train-mode BN divides by per-channel batch deviations (the 5x5 maps of layer 3/4 at
-    # batch 2 hold 50 values per channel), which amplifies f32 rounding: the bound there is 5e-4, still far below any
-    # structural error (a wrong tap, stride phase or statistics term shows at 1e-2 and above)
-    assert errs[0][0] <= (5e-4 if train_bn else 5e-5), errs[:5]
-    assert float(np.median([e for e, _ in errs])) <= (5e-5 if train_bn else 1e-5)
+    if not train_bn:
+        # running statistics: the rounding level, for EVERY parameter
+        assert errs[0][0] <= 5e-5, errs[:5]
+        assert float(np.median([e for e, _ in errs])) <= 1e-5
+    else:
+        # batch statistics: the ASPP image-pool BN normalises TWO values per channel (batch 2), so its input gradient is a
+        # difference of nearly equal numbers (exactly 0 without eps) and f32 -- any f32, stock PyTorch's included -- keeps
+        # ~3 digits of it; everything upstream (the whole backbone) inherits that ~1e-3.  The bound is therefore the same
+        # gated network in stock f32 PyTorch against f64, measured here: no worse than 3x its worst / its median.
+        cpu = sorted((((p.grad.double() - g64[k]).norm().item() / max(g64[k].norm().item(), floor), k)
+                      for k, p in o32.named_parameters()), reverse=True)
+        print("      stock f32 CPU with the same gates: worst %.2e (%s), median %.2e" % (cpu[0][0], cpu[0][1], float(np.median([e for e, _ in cpu]))))
+        assert errs[0][0] <= 3 * cpu[0][0] + 1e-5, (errs[:3], cpu[:3])
+        assert float(np.median([e for e, _ in errs])) <= 3 * float(np.median([e for e, _ in cpu])) + 2e-6
+        # the layers that do not sit upstream of the two-sample BN (ASPP branches, decoder) stay at the 1e-4 level
+        down = [e for e, k in errs if k.startswith("decoder.") or k.startswith("aspp.aspp")]
+        assert max(down) <= 3e-4, max(down)
 
 
 @pytest.mark.parametrize("engine", ["bf16x6", "f32"])
