@@ -248,6 +248,69 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
     }
 }
 
+// ---- BatchNorm over a handful of ROWS (the ASPP image-pool branch: BN of an [N, C] vector that the reference broadcasts to
+// H x W first, aspp.py:62-65,79-81).  The input is post-ReLU (mean >> deviation) and N is the batch size, so the batch
+// variance is a difference of nearly equal numbers and, for N = 2, the input gradient vanishes up to eps: sum / sum-of-squares
+// partials in f32 lose three digits there (seen against the f64 oracle).  One thread per channel, two-pass, all in f64.
+__global__ void bn_rows_fwd_kernel(const float *__restrict__ x, int N, int K, double rep, const float *gamma, const float *beta,
+                                   float *running_mean, float *running_var, float momentum, float eps, float *mean,
+                                   float *invstd, float *scale, float *shift) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    double s = 0.0;
+    for (int n = 0; n < N; ++n) s += (double)x[(long)n * K + k];
+    const double mu = s / N;
+    double v = 0.0;
+    for (int n = 0; n < N; ++n) {
+        const double d = (double)x[(long)n * K + k] - mu;
+        v += d * d;
+    }
+    const double var = v / N, count = (double)N * rep;  // every row stands for `rep` identical elements
+    const double is = 1.0 / sqrt(var + (double)eps);
+    const float g = gamma ? gamma[k] : 1.f, b = beta ? beta[k] : 0.f;
+    mean[k] = (float)mu;
+    invstd[k] = (float)is;
+    scale[k] = (float)((double)g * is);
+    shift[k] = (float)((double)b - mu * (double)g * is);
+    if (momentum >= 0.f && running_mean && running_var) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[k] = (1.f - momentum) * running_mean[k] + momentum * (float)mu;
+        running_var[k] = (1.f - momentum) * running_var[k] + momentum * (float)unb;
+    }
+}
+
+// backward of the same: g [N][K] already summed over the broadcast copies; dx = gamma * invstd * (g - (dbeta + xhat * dgamma) / N)
+__global__ void bn_rows_bwd_kernel(const float *__restrict__ g, const float *__restrict__ x, const float *__restrict__ mean,
+                                   const float *__restrict__ invstd, const float *__restrict__ gamma, int N, int K, int train,
+                                   float *__restrict__ dx, float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    // batch statistics: the mean is recomputed in f64 from the rows (x - mean cancels; the stored f32 mean is rounded);
+    // invstd only multiplies, its f32 rounding is harmless
+    double mu = (double)mean[k];
+    const double is = (double)invstd[k];
+    if (train) {
+        double s = 0.0;
+        for (int n = 0; n < N; ++n) s += (double)x[(long)n * K + k];
+        mu = s / N;
+    }
+    double db = 0.0, dg = 0.0;
+    for (int n = 0; n < N; ++n) {
+        const double gv = (double)g[(long)n * K + k];
+        db += gv;
+        dg += gv * ((double)x[(long)n * K + k] - mu) * is;
+    }
+    dbeta[k] = (float)db;
+    dgamma[k] = (float)dg;
+    const double ga = gamma ? (double)gamma[k] : 1.0;
+    for (int n = 0; n < N; ++n) {
+        const double gv = (double)g[(long)n * K + k];
+        double r = gv;
+        if (train) r = gv - (db + ((double)x[(long)n * K + k] - mu) * is * dg) / N;
+        dx[(long)n * K + k] = (float)(r * ga * is);
+    }
+}
+
 bool ok4(int K, int64_t a, int64_t b = 4, int64_t c = 4, int64_t d = 4) {
     return K > 0 && K % 4 == 0 && a % 4 == 0 && b % 4 == 0 && c % 4 == 0 && d % 4 == 0;
 }
@@ -279,6 +342,25 @@ extern "C" int dass_bn_finalize(const float *partial, int rows, int K, double co
     if (!partial || rows <= 0 || K <= 0 || count <= 0 || !mean || !invstd || !scale || !shift) return DASS_ERR_ARG;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((K + FIN_CH - 1) / FIN_CH), dim3(1024), 0, (hipStream_t)stream, partial, rows, K,
                        count, rep, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_bn_rows_fwd(const float *x, int N, int K, double rep, const float *gamma, const float *beta, float *running_mean,
+                                float *running_var, float momentum, float eps, float *mean, float *invstd, float *scale, float *shift,
+                                void *stream) {
+    if (!x || N <= 0 || K <= 0 || rep <= 0 || !mean || !invstd || !scale || !shift) return DASS_ERR_ARG;
+    hipLaunchKernelGGL(bn_rows_fwd_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, N, K, rep, gamma, beta,
+                       running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_bn_rows_bwd(const float *g, const float *x, const float *mean, const float *invstd, const float *gamma, int N, int K,
+                                int train, float *dx, float *dgamma, float *dbeta, void *stream) {
+    if (!g || !x || !mean || !invstd || !dx || !dgamma || !dbeta || N <= 0 || K <= 0) return DASS_ERR_ARG;
+    hipLaunchKernelGGL(bn_rows_bwd_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, x, mean, invstd, gamma, N, K,
+                       train, dx, dgamma, dbeta);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }

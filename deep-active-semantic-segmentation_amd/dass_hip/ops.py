@@ -996,14 +996,31 @@ def global_avgpool(x):
 class _BroadcastBN(torch.autograd.Function):
     """bilinear 1x1 -> HxW (a broadcast) followed by BatchNorm2d over the broadcast map.
     Batch statistics over N*H*W copies equal statistics over N rows with count N*H*W (only the
-    unbiased running_var correction sees H*W), so BN runs on the [N,C] vector and is broadcast."""
+    unbiased running_var correction sees H*W), so BN runs on the [N,C] vector and is broadcast.
+    The rows are post-ReLU and N is the batch size: statistics and the backward run two-pass in f64
+    (dass_bn_rows_fwd / _bwd); only SyncBN, which must exchange sums, goes through the sum / sum-of-squares kernels."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, bn, h, w):
         xs, _ = rows(_cast_act(x))
         n, c = xs.shape[0], xs.shape[1]
         xv = xs.reshape(n, c).contiguous()
-        if bn_use_batch_stats(bn):
+        train = bn_use_batch_stats(bn)
+        world = sync_bn_world(bn) if train else 1
+        rows_f64 = xv.dtype == torch.float32 and world == 1
+        if train and rows_f64:
+            st = BNState(c, xv.device)
+            mom, rm, rv = -1.0, None, None
+            if bn.track_running_stats and bn.running_mean is not None:
+                mom = 0.1 if bn.momentum is None else float(bn.momentum)
+                rm, rv = bn.running_mean, bn.running_var
+                _pending_counters.append(bn.num_batches_tracked)
+                if _defer["depth"] == 0 or len(_pending_counters) >= 512:
+                    flush_bn_counters()
+            check(lib.dass_bn_rows_fwd(_p(xv), n, c, float(h * w), _p(bn.weight), _p(bn.bias), _p(rm), _p(rv), mom, float(bn.eps),
+                                       _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift), _stream()), "dass_bn_rows_fwd")
+            _running_stats_written(bn, rm, rv)
+        elif train:
             st = bn_train_state(xv, c, n, c, bn, rep=float(h * w))
         else:
             st = bn_eval_state(bn, c, xv.device)
@@ -1013,8 +1030,9 @@ class _BroadcastBN(torch.autograd.Function):
         check(lib.dass_broadcast_rows(_p(yv), _p(out), c, n, h * w, c, 1.0, _dt(out), _stream()), "dass_broadcast_rows")
         ctx.save_for_backward(xv, yv, gamma, st.mean, st.invstd)
         ctx.dims = (n, c, h, w)
-        ctx.train_stats = bn_use_batch_stats(bn)
-        ctx.sync_world = sync_bn_world(bn) if ctx.train_stats else 1
+        ctx.train_stats = train
+        ctx.sync_world = world
+        ctx.rows_f64 = rows_f64
         return out
 
     @staticmethod
@@ -1024,6 +1042,12 @@ class _BroadcastBN(torch.autograd.Function):
         gr, ldg = rows(_cast_act(g))
         gs = torch.empty((n, c), dtype=gr.dtype, device=gr.device)
         check(lib.dass_reduce_rows(_p(gr), ldg, _p(gs), n, h * w, c, _dt(gs), _stream()), "dass_reduce_rows")
+        if ctx.rows_f64:
+            dx = torch.empty((n, c), dtype=torch.float32, device=gs.device)
+            sums = torch.empty((2, c), dtype=torch.float32, device=gs.device)
+            check(lib.dass_bn_rows_bwd(_p(gs), _p(xv), _p(mean), _p(invstd), _p(gamma.detach()), n, c, 1 if ctx.train_stats else 0,
+                                       _p(dx), _p(sums[1]), _p(sums[0]), _stream()), "dass_bn_rows_bwd")
+            return dx.view(n, 1, 1, c).permute(0, 3, 1, 2), sums[1], sums[0], None, None, None
         nrows = lib.dass_stat_rows(n)
         partial = torch.empty((nrows, 2, c), dtype=torch.float32, device=gr.device)
         check(lib.dass_bn_bwd_reduce(_p(gs), c, _p(yv), c, _p(xv), c, _p(mean), _p(invstd), None, n, c, 1, ACT_NONE,

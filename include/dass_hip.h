@@ -146,6 +146,16 @@ int dass_bn_finalize(const float *partial, int rows, int K, double count, double
 int dass_bn_finalize_sums(const float *sums, int K, double count, const float *gamma, const float *beta,
                           float *running_mean, float *running_var, float momentum, float eps, int clamp_var,
                           float *mean, float *invstd, float *scale, float *shift, void *stream);
+/* BatchNorm over N ROWS of an [N][K] f32 matrix, each row standing for `rep` identical elements -- the ASPP image-pool
+ * branch, where the reference broadcasts a [N,C,1,1] tensor to H x W and THEN applies BN (aspp.py:62-65,79-81).  Post-ReLU
+ * inputs and N = batch size make sum / sum-of-squares partials cancel catastrophically, so both directions run two-pass
+ * in f64, one thread per channel.  fwd: batch mean / biased var over the rows -> mean, invstd, scale, shift (+ running
+ * statistics with the unbiased correction for count = N * rep).  bwd: g = gradient rows already summed over the copies. */
+int dass_bn_rows_fwd(const float *x, int N, int K, double rep, const float *gamma, const float *beta,
+                     float *running_mean, float *running_var, float momentum, float eps,
+                     float *mean, float *invstd, float *scale, float *shift, void *stream);
+int dass_bn_rows_bwd(const float *g, const float *x, const float *mean, const float *invstd, const float *gamma,
+                     int N, int K, int train, float *dx, float *dgamma, float *dbeta, void *stream);
 /* eval-mode BN folded to scale/shift from running stats */
 int dass_bn_eval_scale_shift(const float *gamma, const float *beta, const float *running_mean,
                              const float *running_var, float eps, int K,

@@ -304,9 +304,9 @@ def test_config_c_mobilenet_voc_batch16_train_steps():
         ref_loss = float(S.ce_loss(om(x, (m1[0], m2[0])), lab))
     losses = []
     xd, ld = x.cuda(), lab.cuda()
-    for step in range(3):
+    for step in range(4):
         opt.zero_grad(set_to_none=True)
-        loss = crit(pm(xd, dropout_masks=(m1[step].cuda(), m2[step].cuda())), ld)
+        loss = crit(pm(xd, dropout_masks=(m1[0].cuda(), m2[0].cuda())), ld)   # one fixed objective: same batch, same masks
         loss.backward()
         if step == 0:
             missing = [k for k, p in pm.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
@@ -314,4 +314,4 @@ def test_config_c_mobilenet_voc_batch16_train_steps():
         opt.step()
         losses.append(loss.item())
     assert abs(losses[0] - ref_loss) <= 2e-4 * abs(ref_loss), (losses[0], ref_loss)
-    assert losses[2] < losses[0], losses
+    assert losses[3] < losses[0], losses
