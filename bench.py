@@ -15,11 +15,18 @@ JSON line.  The headline (`value`, `dtype`) is the f32 PARITY mode -- the mode e
 product exactly from three bf16 parts per operand on the bf16 MFMA pipe (`config.f32_mma` = "bf16x6", six MFMA
 products per f32 product, f32 accumulation; dass_hip/ops.py:set_f32_mma) -- results differ from the plain f32 MFMA
 only by summation order, and the roofline peak is priced accordingly (2500 / 6 TFLOP/s).  The same line carries
-  mc_dropout  : pool-images/s of the T=10 MC-dropout vote-entropy scoring call on the same model,
-  roofline    : the dominant kernel (implicit-GEMM conv, decoder 3x3 304->256 @129^2 shape) timed live
-                with events on the launch stream against the MFMA peak of the dtype,
-  cpu_baseline: the CPU oracle (stock PyTorch fp32 restatement, oracle/) timed on this box's host cores
-                on a bounded sample (rank 0, N=1 only),
+  mc_dropout  : pool-images/s of the T=10 MC-dropout vote-entropy scoring call on the same model over 376 pool images
+                per rank (config D's per-GPU share of the 2975-image pool is 372),
+  core_set    : config E -- pooled decoder features of the same pool shard (images/s) and the k-center greedy selection
+                (k = 125, 50 pre-selected) on a [2975, 2736] feature matrix (seconds),
+  roofline    : `frac` = the TIME-WEIGHTED aggregate of every conv launch of one train step (forward, input gradient and
+                weight gradient of all 105 R101 conv layers timed with events on the launch stream: algorithmic FLOPs /
+                summed kernel time / MFMA peak of the engine); `best_launch` = the single best-case launch (decoder 3x3
+                304->256 @129^2) as reported in round 1; `sustained` = the same fractions against the bf16 MFMA rate the chip
+                actually holds under an all-CU MFMA load (profiles/r02_clock_probe.json),
+  cpu_baseline: the CPU oracle (stock PyTorch fp32 restatement, oracle/) timed on this box's host cores on bounded
+                samples (rank 0, N=1 only): (i) train steps, (ii) 10-pass MC-dropout the reference way (T full forwards)
+                and with the deterministic prefix hoisted, (iii) core-set features + sklearn fp64 k-center,
   f32_mfma_mode: the same legs with the convs on v_mfma_f32_32x32x2_f32 (the plain f32 fma chain), for comparison,
   bf16_perf_mode: the same legs with bf16 storage / f32 accumulate (NOT parity-grade: deviation from the
                 f32 reference is measured in tests/test_bf16_gpu.py), reported for information only.
@@ -55,7 +62,8 @@ def parse():
     ap.add_argument("--backbone", default="resnet101")
     ap.add_argument("--classes", type=int, default=19)
     ap.add_argument("--mc-steps", type=int, default=10, help="T of the MC-dropout scoring leg")
-    ap.add_argument("--mc-batches", type=int, default=3, help="timed scoring batches per rank")
+    ap.add_argument("--mc-batches", type=int, default=47, help="timed scoring batches per rank (47 x 8 = 376 >= config D's 372 per GPU)")
+    ap.add_argument("--no-coreset", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="headline mode (f32 = parity mode)")
     ap.add_argument("--f32-mma", default="bf16x6", choices=["bf16x6", "f32", "bf16x3"],
                     help="conv engine of the f32 headline (bf16x6 = exact three-way split, the default parity engine)")
@@ -89,6 +97,72 @@ def log(msg):
 
 class Env(object):
     pass
+
+
+def r101_conv_layers(batch, size):
+    """(count, N, H, W, C, K, ksize, stride, pad, dil) of every groups=1 conv of DeepLab-R101 os16, stem excluded
+    (3 input channels: a separate row-tap kernel, 0.7 % of the FLOPs)"""
+    s2 = (size + 1) // 2
+    s4 = (s2 + 1) // 2
+    s8 = (s4 + 1) // 2
+    s16 = (s8 + 1) // 2
+    b = batch
+    return [(1, b, s4, s4, 64, 64, 1, 1, 0, 1), (2, b, s4, s4, 256, 64, 1, 1, 0, 1), (3, b, s4, s4, 64, 64, 3, 1, 1, 1),
+            (3, b, s4, s4, 64, 256, 1, 1, 0, 1), (1, b, s4, s4, 64, 256, 1, 1, 0, 1),
+            (1, b, s4, s4, 256, 128, 1, 1, 0, 1), (1, b, s4, s4, 128, 128, 3, 2, 1, 1), (1, b, s4, s4, 256, 512, 1, 2, 0, 1),
+            (3, b, s8, s8, 512, 128, 1, 1, 0, 1), (3, b, s8, s8, 128, 128, 3, 1, 1, 1), (4, b, s8, s8, 128, 512, 1, 1, 0, 1),
+            (1, b, s8, s8, 512, 256, 1, 1, 0, 1), (1, b, s8, s8, 256, 256, 3, 2, 1, 1), (1, b, s8, s8, 512, 1024, 1, 2, 0, 1),
+            (22, b, s16, s16, 1024, 256, 1, 1, 0, 1), (22, b, s16, s16, 256, 256, 3, 1, 1, 1), (23, b, s16, s16, 256, 1024, 1, 1, 0, 1),
+            (1, b, s16, s16, 1024, 512, 1, 1, 0, 1), (2, b, s16, s16, 2048, 512, 1, 1, 0, 1), (1, b, s16, s16, 512, 512, 3, 1, 2, 2),
+            (1, b, s16, s16, 512, 512, 3, 1, 4, 4), (1, b, s16, s16, 512, 512, 3, 1, 8, 8), (3, b, s16, s16, 512, 2048, 1, 1, 0, 1),
+            (1, b, s16, s16, 1024, 2048, 1, 1, 0, 1),
+            (1, b, s16, s16, 2048, 256, 1, 1, 0, 1), (1, b, s16, s16, 2048, 256, 3, 1, 6, 6), (1, b, s16, s16, 2048, 256, 3, 1, 12, 12),
+            (1, b, s16, s16, 2048, 256, 3, 1, 18, 18), (1, b, s16, s16, 1280, 256, 1, 1, 0, 1),
+            (1, b, s4, s4, 256, 48, 1, 1, 0, 1), (1, b, s4, s4, 304, 256, 3, 1, 1, 1), (1, b, s4, s4, 256, 256, 3, 1, 1, 1)]
+
+
+def conv_aggregate(args, ops, tdt):
+    """times forward, input-gradient and weight-gradient launch of every conv layer shape of the train step through the
+    C-ABI (events on the launch stream, 5 reps) and weights them by their count: the time-weighted conv roofline"""
+    from dass_hip._lib import check, lib
+
+    dev = "cuda"
+    tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
+    gflop = 0.0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timeit(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    for cnt, n, h, w, c, k, ks, st, pad, dil in r101_conv_layers(args.batch, args.size):
+        oh, ow = ops.conv_out_size(h, ks, st, pad, dil), ops.conv_out_size(w, ks, st, pad, dil)
+        x = torch.randn((n, h, w, c), device=dev).to(tdt)
+        wt = (torch.randn((k, ks, ks, c), device=dev) * 0.05)
+        y = torch.empty((n, oh, ow, k), device=dev, dtype=tdt)
+        dy = torch.randn((n, oh, ow, k), device=dev).to(tdt)
+        dx = torch.empty((n, h, w, c), device=dev, dtype=tdt)
+        dw = torch.empty((k, ks, ks, c), device=dev)
+        wop = ops.prepare_conv_weight(wt.to(tdt) if tdt != torch.float32 else wt)
+        wop_t = ops.prepare_conv_weight((wt.permute(3, 1, 2, 0).flip(1, 2).contiguous()).to(tdt) if tdt != torch.float32
+                                        else wt.permute(3, 1, 2, 0).flip(1, 2).contiguous())
+        stream = ops._stream()
+        pad_t = dil * (ks - 1) - pad
+        tot["fwd"] += cnt * timeit(lambda: ops.conv_launch(x, c, wop, y, k, (n, h, w, c, oh, ow, k, ks, ks, st, pad, dil)))
+        tot["dgrad"] += cnt * timeit(lambda: check(lib.dass_conv2d_igemm(ops._p(dy), k, ops._p(wop_t), ops._p(dx), c, None, None, None, 0, None,
+                                                                        n, oh, ow, k, h, w, c, ks, ks, 1, pad_t, dil, st, 0, ops._cdt(dx), stream), "dgrad"))
+        tot["wgrad"] += cnt * timeit(lambda: check(lib.dass_conv2d_wgrad(ops._p(x), c, ops._p(dy), k, ops._p(dw), n, h, w, c, oh, ow, k, ks, ks,
+                                                                        st, pad, dil, ops._cdt(dy), stream), "wgrad"))
+        gflop += cnt * 2.0 * n * oh * ow * k * ks * ks * c / 1e9
+    ms = tot["fwd"] + tot["dgrad"] + tot["wgrad"]
+    return {"ms_per_step": round(ms, 3), "fwd_ms": round(tot["fwd"], 3), "dgrad_ms": round(tot["dgrad"], 3), "wgrad_ms": round(tot["wgrad"], 3),
+            "gflop": round(3 * gflop, 1), "achieved": round(3 * gflop / ms, 2)}
 
 
 def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
@@ -167,6 +241,7 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
 
     # ------------------------------------------------------------------ MC-dropout pool scoring (T passes)
     res["mc"] = None
+    res["coreset"] = None
     if not args.no_mc:
         model.eval()
         pool_keys = [("pool_%06d" % i).encode("ascii") for i in range(world * args.mc_batches * b)]
@@ -183,7 +258,9 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
                 yield {"image": torch.cat([shard[k][0] for k in chunk]), "label": torch.cat([shard[k][1] for k in chunk])}
 
         selector = ActiveSelectionMCDropout(args.classes, None, s, b, loader_factory=factory)
-        selector.get_vote_entropy_for_images(model, pool_keys, 1, steps=args.mc_steps)  # warm-up
+        # warm-up pool: the first batch of every rank's shard (a contiguous split of this list hands each rank its own keys)
+        warm = [pool_keys[shard_bounds(len(pool_keys), r, world)[0] + i] for r in range(world) for i in range(b)]
+        selector.get_vote_entropy_for_images(model, warm, 1, steps=args.mc_steps)
         barrier()
         t0 = time.perf_counter()
         selected = selector.get_vote_entropy_for_images(model, pool_keys, max(1, len(pool_keys) // 8), steps=args.mc_steps)
@@ -191,11 +268,48 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
         dts = tmax(time.perf_counter() - t0)
         pool_ips = len(pool_keys) / dts
         if rank == 0:
-            log("[%s] mc-dropout T=%d: %.2f pool images/s" % (dtype_name, args.mc_steps, pool_ips))
+            log("[%s] mc-dropout T=%d: %.2f pool images/s (%d images)" % (dtype_name, args.mc_steps, pool_ips, len(pool_keys)))
         res["mc"] = {"metric": "mc_dropout_pool_images_per_s", "value": round(pool_ips, 3), "unit": "images/s",
                      "T": args.mc_steps, "pool_images": len(pool_keys), "seconds": round(dts, 4), "selected": len(selected),
                      "frac_of_mfma_peak": round(pool_ips * MC_GFLOP_PER_IMAGE / 1e3 / (MFMA_PEAK_TFLOPS[engine] * world), 4),
                      "sharding": "contiguous key shards per rank + RCCL all_gather of per-image scores" if world > 1 else "single rank"}
+
+        # -------------------------------------------------------------- config E: core-set features + k-center greedy
+        if not args.no_coreset:
+            from active_selection.core_set import ActiveSelectionCoreSet
+            from dass_hip.dist import ModuleWrapper
+
+            def factory_img(images, include_labels):
+                for i in range(0, len(images), b):
+                    yield torch.cat([shard[k][0] for k in images[i:i + b]])
+
+            cs = ActiveSelectionCoreSet(None, s, b, loader_factory=factory_img)
+            wrapped = ModuleWrapper(model)
+            cs._features(wrapped, warm)
+            barrier()
+            t0 = time.perf_counter()
+            feats = cs._features(wrapped, pool_keys)          # sharded feature pass + all-gather of [n, 2736]
+            barrier()
+            dtf = tmax(time.perf_counter() - t0)
+            # the greedy selection at the full pool size (2975 x 2736, 50 already selected, k = 125: the authors' setting)
+            gk = torch.Generator().manual_seed(5)
+            full = torch.randn(2975, 2736, generator=gk).to(dev)
+            full[: feats.shape[0]] = feats[: min(2975, feats.shape[0])]
+            ops.kcenter_greedy(full, list(range(50)), 4)      # warm-up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            picks, _ = ops.kcenter_greedy(full, list(range(50)), 125)
+            picks = picks.cpu()
+            dtk = time.perf_counter() - t0
+            feat_ips = len(pool_keys) / dtf
+            if rank == 0:
+                log("[%s] core-set: features %.1f pool images/s, k-center k=125 on 2975x2736: %.3f s" % (dtype_name, feat_ips, dtk))
+            res["coreset"] = {"metric": "core_set_feature_images_per_s", "value": round(feat_ips, 2), "unit": "images/s",
+                              "pool_images": len(pool_keys), "feature_seconds": round(dtf, 4),
+                              "kcenter": {"n": 2975, "d": 2736, "preselected": 50, "k": 125, "seconds": round(dtk, 4),
+                                          "hbm_gb_per_s": round(175 * 2975 * 2736 * 4 / dtk / 1e9, 1)},
+                              "selection_2975_pool_seconds_at_this_gpu_count": round(2975.0 / feat_ips + dtk, 3),
+                              "frac_of_mfma_peak": round(feat_ips * 142.5 / 1e3 / (MFMA_PEAK_TFLOPS[engine] * world), 4)}
 
     # ------------------------------------------------------------------ roofline of the dominant kernel
     res["roofline"] = None
@@ -228,10 +342,30 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
             traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
         kname = {"f32": "float,128,128,2,2", "bf16": "bf16,128,128,2,2", "bf16x6": "float,128,128,4,1,split=3",
                  "bf16x3": "float,128,128,2,2,split=2"}[engine]
-        res["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel<%s> (3x3 304->256 @%dx%d, batch %d)" % (kname, h_, h_, n_),
-                           "achieved": round(achieved, 2), "peak": peak, "peak_note": PEAK_NOTE[engine], "unit": "TFLOP/s",
-                           "frac": round(achieved / peak, 4), "frac_of_f32_mfma_peak": round(achieved / MFMA_PEAK_TFLOPS["f32"], 4) if engine != "bf16" else None,
-                           "traffic": traffic, "launch_ms": round(ms, 4), "flops_per_launch": flops,
+        best = {"kernel": "conv_igemm_kernel<%s> (3x3 304->256 @%dx%d, batch %d)" % (kname, h_, h_, n_), "achieved": round(achieved, 2),
+                "frac": round(achieved / peak, 4), "launch_ms": round(ms, 4), "flops_per_launch": flops, "traffic": traffic}
+        del x, w, y
+        agg = conv_aggregate(args, ops, tdt)
+        log("[%s] all conv launches of one train step: %.2f ms (fwd %.2f, dgrad %.2f, wgrad %.2f) = %.1f TFLOP/s"
+            % (dtype_name, agg["ms_per_step"], agg["fwd_ms"], agg["dgrad_ms"], agg["wgrad_ms"], agg["achieved"]))
+        sustained = None
+        cfile = os.path.join(ROOT, "profiles", "r02_clock_probe.json")
+        if os.path.exists(cfile) and engine != "f32":
+            cp = json.load(open(cfile))
+            div = {"bf16x6": 6.0, "bf16x3": 3.0, "bf16": 1.0}[engine]
+            speak = cp["sustained_bf16_mfma_peak_tflops"] / div
+            sustained = {"clock_ghz": cp["sustained_clock_ghz_all_cus_lds_fed"], "peak": round(speak, 1),
+                         "frac": round(agg["achieved"] / speak, 4), "best_launch_frac": round(achieved / speak, 4),
+                         "note": "bf16 MFMA rate at the shader clock the chip holds with all 256 CUs in an LDS-fed MFMA loop "
+                                 "(tools/clock_probe.py, profiles/r02_clock_probe.json); the nominal peak assumes 2.4 GHz"}
+        res["roofline"] = {"bound": "mfma", "kernel": "every groups=1 conv launch of one train step (105 layers x fwd/dgrad/wgrad), time-weighted",
+                           "achieved": agg["achieved"], "peak": peak, "peak_note": PEAK_NOTE[engine], "unit": "TFLOP/s",
+                           "frac": round(agg["achieved"] / peak, 4), "traffic": traffic,
+                           "traffic_note": "HBM bytes of the best_launch shape from the committed PMC passes (profiles/r01_traffic_*.json; that kernel is unchanged since)",
+                           "conv_ms_per_step": agg["ms_per_step"], "conv_gflop_per_step": agg["gflop"],
+                           "conv_ceiling_ms_per_step": round(agg["gflop"] / peak, 3),
+                           "split_ms": {"fwd": agg["fwd_ms"], "dgrad": agg["dgrad_ms"], "wgrad": agg["wgrad_ms"]},
+                           "best_launch": best, "sustained": sustained,
                            "train_step_frac": round(res["train_ips"] * TRAIN_GFLOP_PER_IMAGE / 1e3 / (peak * world), 4)}
     del model, optimizer
     torch.cuda.empty_cache()
@@ -247,8 +381,9 @@ def cpu_baseline(args):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    cores_box = cores
     cores = max(1, min(cores, 16))
-    log("cpu baseline on %d cores ..." % cores)
+    log("cpu baseline on %d of the box's %d usable cores (host reports %s) ..." % (cores, cores_box, os.cpu_count()))
     torch.set_num_threads(cores)
     s = args.size
     om = O.ODeepLab(args.backbone, 16, args.classes)
@@ -270,9 +405,52 @@ def cpu_baseline(args):
         cpu_step()
         nsteps += 1
     dtc = time.perf_counter() - t0
-    return {"value": round(2 * nsteps / dtc, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d train steps (fwd+CE+bwd+SGD) of batch 2 = %d images, %s %dx%d, stock PyTorch CPU fp32 "
-                      "(oracle/deeplab_cpu.py), %.1f s" % (nsteps, 2 * nsteps, args.backbone, s, s, dtc)}
+    out = {"value": round(2 * nsteps / dtc, 4), "unit": "images/s", "cores": cores, "cores_available": cores_box,
+           "cores_host": os.cpu_count(), "kind": "port",
+           "sample": "%d train steps (fwd+CE+bwd+SGD) of batch 2 = %d images, %s %dx%d, stock PyTorch CPU fp32 "
+                     "(oracle/deeplab_cpu.py), %.1f s" % (nsteps, 2 * nsteps, args.backbone, s, s, dtc)}
+    del oopt
+    # ---- (ii) MC-dropout scoring, T passes: the reference way (T full forwards, mc_dropout.py:39-40) and with the
+    # deterministic prefix (backbone + ASPP) computed once per batch; argmax votes + vote entropy included
+    T = args.mc_steps
+    om.eval()
+    with torch.no_grad():
+        m1, m2 = O.dropout_masks(2, T, seed=3)
+        for style in ("reference", "hoisted"):
+            nimg, t0 = 0, time.perf_counter()
+            while nimg < 8 and time.perf_counter() - t0 < 10.0:
+                xi, li = synthetic_batch(2, s, s, args.classes, 100000 + nimg)
+                if style == "reference":
+                    votes = S.mc_votes(om, xi, (m1, m2))
+                else:
+                    hi, low = om.backbone(xi)
+                    a = om.aspp(hi, None)
+                    votes = torch.stack([torch.argmax(O._bilinear(om.decoder(a * m1[t][:, :, None, None], low, m2[t])[0], xi.shape[2:]), dim=1)
+                                         for t in range(T)], dim=1)
+                S.vote_entropy_maps(votes, li, args.classes)
+                nimg += 2
+            dt = time.perf_counter() - t0
+            out["mc_dropout_%s" % style] = {"value": round(nimg / dt, 4), "unit": "pool images/s", "T": T,
+                                            "sample": "%d images in %.1f s" % (nimg, dt)}
+        # ---- (iii) core-set: pooled decoder features + sklearn fp64 k-center (k = 125, 50 pre-selected) on [2975, 2736]
+        om.return_features = True
+        nimg, t0 = 0, time.perf_counter()
+        feats = []
+        while nimg < 8 and time.perf_counter() - t0 < 6.0:
+            xi, _ = synthetic_batch(2, s, s, args.classes, 100000 + nimg)
+            feats.append(S.coreset_features(om(xi)[1], 64))
+            nimg += 2
+        dtf = time.perf_counter() - t0
+        om.return_features = False
+    import numpy as np
+
+    full = np.random.RandomState(5).randn(2975, 2736)
+    t0 = time.perf_counter()
+    S.kcenter_greedy(full, list(range(50)), 125)
+    dtk = time.perf_counter() - t0
+    out["core_set"] = {"feature_images_per_s": round(nimg / dtf, 4), "kcenter_seconds": round(dtk, 3),
+                       "sample": "%d images of feature extraction in %.1f s; sklearn pairwise_distances fp64 k-center, k=125 on 2975x2736" % (nimg, dtf)}
+    return out
 
 
 def main():
@@ -322,13 +500,14 @@ def main():
                            "global_batch": b * world, "parallelism": "dp%d" % world, "bn": "per-GPU",
                            "f32_mma": args.f32_mma if args.dtype == "f32" else None,
                            "final_loss": round(head["final_loss"], 5)},
-                "mc_dropout": head["mc"], "roofline": head["roofline"], "cpu_baseline": cpu}
+                "mc_dropout": head["mc"], "core_set": head["coreset"], "roofline": head["roofline"], "cpu_baseline": cpu}
         notes = {"bf16_perf_mode": "informational; bf16 storage does not meet the parity bar (tests/test_bf16_gpu.py measures the deviation)",
                  "f32_mfma_mode": "same f32 tensors, convs on v_mfma_f32_32x32x2_f32; parity-grade as well",
                  "f32_parity_mode": "the parity mode (f32 tensors)"}
         for name, other in others.items():
             line[name] = {"train_images_per_s": round(other["train_ips"], 3), "ms_per_step": round(other["ms_per_step"], 3),
-                          "final_loss": round(other["final_loss"], 5), "mc_dropout": other["mc"], "roofline": other["roofline"],
+                          "final_loss": round(other["final_loss"], 5), "mc_dropout": other["mc"], "core_set": other["coreset"],
+                          "roofline": other["roofline"],
                           "note": notes[name]}
         print(json.dumps(line))
     if env.dist is not None:

@@ -72,7 +72,7 @@ def test_hip_sgd_refreshes_weight_operands(engine):
             pm.eval()
             fresh.eval()
             assert torch.equal(pm(x).float().cpu(), fresh(x).float().cpu()), name
-        runs[name] = (losses, logits, pm.backbone.layer1[0].conv1.weight.detach().float().cpu().clone())
+        runs[name] = (losses, logits, {k: v.detach().float().cpu().clone() for k, v in pm.named_parameters()})
     lt, lh = runs["torch"][0], runs["hip"][0]
     # large learning rates: a stale step-0 operand in step 1 or 2 moves the loss by O(1)
     tol = 2e-2 if engine == "bf16" else 2e-3
@@ -85,7 +85,9 @@ def test_hip_sgd_refreshes_weight_operands(engine):
     # (the logits of the two trajectories are NOT compared: train-mode BN over 5x5 maps at batch 2 amplifies the optimizers'
     # rounding differences chaotically; the cache-freshness check above is the bit-exact deep-copy comparison)
     wt, wh = runs["torch"][2], runs["hip"][2]
-    assert (wt - wh).abs().max().item() <= 5e-2 * wt.abs().max().item()  # same trajectory, not bit-equal (see above)
+    diffs = sorted((((wt[k] - wh[k]).norm().item() / max(wt[k].norm().item(), 1e-12), k) for k in wt), reverse=True)
+    print("largest parameter differences after 3 steps:", diffs[:6])
+    assert diffs[0][0] <= 5e-2, diffs[:6]  # same trajectory, not bit-equal (see above)
 
 
 def test_bn_eval_cache_sees_running_stat_updates():
