@@ -85,9 +85,10 @@ def test_hip_sgd_refreshes_weight_operands(engine):
     # (the logits of the two trajectories are NOT compared: train-mode BN over 5x5 maps at batch 2 amplifies the optimizers'
     # rounding differences chaotically; the cache-freshness check above is the bit-exact deep-copy comparison)
     wt, wh = runs["torch"][2], runs["hip"][2]
-    diffs = sorted((((wt[k] - wh[k]).norm().item() / max(wt[k].norm().item(), 1e-12), k) for k in wt), reverse=True)
-    print("largest parameter differences after 3 steps:", diffs[:6])
-    assert diffs[0][0] <= 5e-2, diffs[:6]  # same trajectory, not bit-equal (see above)
+    # conv weights only: BN biases start at 0, so their relative distance measures gradient noise, not the optimizer
+    diffs = sorted((((wt[k] - wh[k]).norm().item() / max(wt[k].norm().item(), 1e-12), k) for k in wt if wt[k].dim() == 4), reverse=True)
+    print("largest conv-weight differences after 3 steps:", diffs[:4])
+    assert diffs[0][0] <= 5e-2, diffs[:4]  # same trajectory, not bit-equal (the update arithmetic itself is compared exactly below)
 
 
 def test_bn_eval_cache_sees_running_stat_updates():
@@ -211,3 +212,38 @@ def test_x3_engine_in_training_matches_classic_engine():
     assert abs(res["off"][0] - res["all"][0]) <= 1e-6 * abs(res["off"][0])
     worst = max(((res["all"][1][k] - g).norm().item() / max(g.norm().item(), 1e-12), k) for k, g in res["off"][1].items())
     assert worst[0] <= 1e-4, worst
+
+
+def test_hip_sgd_equals_torch_sgd_on_model_gradients():
+    """the fused multi-tensor update against torch.optim.SGD on a real model's gradient tensors (arena views for conv
+    weights, slices of the BN-sum buffers for gamma / beta, channels_last 1x1 weights): three steps with the SAME gradients
+    must move every parameter identically (momentum 0.9, weight decay, two learning-rate groups)"""
+    ops, O, S = _setup()
+    import copy
+
+    from dass_hip.optim import SGD
+    from models.deeplab import DeepLab
+    from utils.loss import SegmentationLosses
+
+    ncls, n, hw = 19, 2, 65
+    x, lab = O.synthetic_batch(n, hw, hw, ncls, first_index=40)
+    torch.manual_seed(3)
+    pm = DeepLab(backbone="resnet", output_stride=16, num_classes=ncls, sync_bn=False, pretrained=False).cuda().train()
+    SegmentationLosses(cuda=True).build_loss("ce")(pm(x.cuda()), lab.cuda()).backward()
+    ref = copy.deepcopy(pm)
+    for (k, p), q in zip(pm.named_parameters(), ref.parameters()):
+        assert p.grad is not None, k
+        q.grad = p.grad.detach().clone()
+    init = {k: v.detach().clone() for k, v in pm.named_parameters()}
+    groups = lambda m: [{"params": list(m.get_1x_lr_params()), "lr": 0.02}, {"params": list(m.get_10x_lr_params()), "lr": 0.2}]  # noqa: E731
+    a, b = SGD(groups(pm), momentum=0.9, weight_decay=5e-4), torch.optim.SGD(groups(ref), momentum=0.9, weight_decay=5e-4)
+    for _ in range(3):
+        a.step()
+        b.step()
+    worst = (0.0, None)
+    for (k, p), q in zip(pm.named_parameters(), ref.parameters()):
+        upd = (q.detach() - init[k]).abs().max().item()
+        err = (p.detach() - q.detach()).abs().max().item()
+        assert upd > 0, k
+        worst = max(worst, (err / upd, k))
+    assert worst[0] <= 1e-5, worst
