@@ -1180,7 +1180,18 @@ template <typename T, int SPLIT = 0> int dispatch_conv(ConvP &p, hipStream_t st)
 // Work split of the weight gradient.  Every pixel-split adds its whole K x R*S x C tile set into dW with
 // f32 atomics (chip-wide ~1.3 TB/s), so the split count is a trade: enough workgroups to fill 256 CUs,
 // but each one long enough (>= MIN_SLABS slabs of 32 pixels) that the atomic tail stays small.
+// dass_set_deterministic(1): ONE pixel split per weight-gradient tile -- every dW element is then summed by a single
+// workgroup in a fixed order (no f32 atomics between workgroups): bit-reproducible run to run, at the price of fewer, longer
+// workgroups on layers with few output tiles.
+static int g_deterministic = 0;
+extern "C" int dass_set_deterministic(int on) {
+    g_deterministic = on ? 1 : 0;
+    return DASS_OK;
+}
+extern "C" int dass_get_deterministic(void) { return g_deterministic; }
+
 static long wgrad_split(long base, long M, long target_wgs, long min_slabs) {
+    if (g_deterministic) return 1;
     long want = (target_wgs + base - 1) / base;
     long maxsplit = M / (32 * min_slabs);
     if (maxsplit < 1) maxsplit = 1;

@@ -272,6 +272,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void wgrad_x3_kernel(con
 }
 
 static long wx3_split(long base, long M, long target_wgs, long min_slabs) {
+    if (dass_get_deterministic()) return 1;  // one pixel split: no cross-workgroup atomics (conv_igemm.hip)
     long want = (target_wgs + base - 1) / base;
     long maxsplit = M / (32 * min_slabs);
     if (maxsplit < 1) maxsplit = 1;

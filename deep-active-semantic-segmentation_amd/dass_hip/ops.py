@@ -66,6 +66,16 @@ def set_x3_pipeline(mode):
     _state["x3"] = mode
 
 
+def set_deterministic(on):
+    """True: conv weight gradients are summed by ONE workgroup per tile in a fixed order (no cross-workgroup f32 atomics):
+    bit-reproducible training steps, slower on layers with few output tiles.  Default False (DASS_DETERMINISTIC=1 to start on)."""
+    check(lib.dass_set_deterministic(1 if on else 0), "dass_set_deterministic")
+
+
+if os.environ.get("DASS_DETERMINISTIC", "0") == "1":
+    lib.dass_set_deterministic(1)
+
+
 def x3_pipeline(training=False):
     """is the pre-split engine on for an inference call site (training=False) / for a call that records autograd"""
     if _state["f32_mma"] != "bf16x6":

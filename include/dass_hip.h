@@ -337,6 +337,11 @@ int dass_conv2d_x3(const void *x3, const void *w3, void *y, int64_t ldy, void *y
                    const float *shift, const void *residual, int64_t ldr, int N, int H, int W, int C, int OH, int OW,
                    int K, int R, int S, int stride, int pad, int dil, int ustride, int act, float *stat_partial,
                    int *stat_rows, void *workspace, int64_t workspace_bytes, void *stream);
+/* Weight gradients are accumulated over several pixel splits per tile with f32 atomics (fast, but the last bits depend on
+ * arrival order).  dass_set_deterministic(1) makes every weight-gradient launch use ONE split per tile: each dW element is
+ * summed by one workgroup in a fixed order -> bit-reproducible (slower on layers with few output tiles). */
+int dass_set_deterministic(int on);
+int dass_get_deterministic(void);
 /* weight gradient of the same conv from pre-split operands: dw[K][R][S][C] (f32) (+)= sum over output pixels of
  * dy[pix][k] * x[pix @ tap][c]; x3 = the forward input, dy3 = the gradient of the conv output (both x3 rows with their zero
  * row; csrc/wgrad_x3.hip).  zero_first = 1 clears dw, 0 accumulates (pixel splits add with f32 atomics either way). */

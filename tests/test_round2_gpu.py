@@ -244,3 +244,35 @@ def test_hip_sgd_equals_torch_sgd_on_model_gradients():
         assert upd > 0, k
         worst = max(worst, (err / upd, k))
     assert worst[0] <= 1e-4, worst  # fma vs separate multiply-add roundings, relative to the size of the 3-step update
+
+
+def test_deterministic_weight_gradients_are_bit_reproducible():
+    """ops.set_deterministic(True): one pixel split per weight-gradient tile -> two backward passes give bit-identical
+    gradients for every parameter (the default mode accumulates splits with f32 atomics and may differ in the last bits);
+    both modes agree to rounding"""
+    ops, O, S = _setup()
+    from models.deeplab import DeepLab
+    from utils.loss import SegmentationLosses
+
+    ncls, n, hw = 19, 2, 129
+    x, lab = O.synthetic_batch(n, hw, hw, ncls, first_index=90)
+    torch.manual_seed(9)
+    pm = DeepLab(backbone="resnet", output_stride=16, num_classes=ncls, sync_bn=False, pretrained=False).cuda().train()
+    pm.freeze_bn()
+    crit = SegmentationLosses(cuda=True).build_loss("ce")
+    m1, m2 = O.dropout_masks(n, 1, seed=2)
+
+    def grads():
+        pm.zero_grad(set_to_none=True)
+        crit(pm(x.cuda(), dropout_masks=(m1[0].cuda(), m2[0].cuda())), lab.cuda()).backward()
+        return {k: p.grad.detach().clone() for k, p in pm.named_parameters()}
+
+    fast = grads()
+    try:
+        ops.set_deterministic(True)
+        a, b = grads(), grads()
+    finally:
+        ops.set_deterministic(False)
+    assert all(torch.equal(a[k], b[k]) for k in a), [k for k in a if not torch.equal(a[k], b[k])][:5]
+    worst = max(((a[k] - fast[k]).norm().item() / max(fast[k].norm().item(), 1e-12), k) for k in a)
+    assert worst[0] <= 1e-5, worst
