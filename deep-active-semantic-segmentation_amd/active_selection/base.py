@@ -2,10 +2,10 @@
 shares in this build: how the pool is read and how it is sharded over ranks.
 
 Data layer.  The reference selectors build DataLoader(PathsDataset(self.env, keys, crop, labels),
-batch_size, shuffle=False, num_workers=0) themselves (mc_dropout.py:180-181).  The LMDB / transform
-stack is outside this build's scope, so the loader comes from `loader_factory(keys, include_labels)`
-when one is injected (tests, bench: synthetic pools), else from the caller's own
-`dataloaders.dataset.paths_dataset.PathsDataset` exactly as the reference does.
+batch_size, shuffle=False, num_workers=0) themselves (mc_dropout.py:180-181).  Here the loader comes
+from `loader_factory(keys, include_labels)` when one is injected (tests, bench: synthetic pools
+resident in HBM), else from `dataloaders.dataset.paths_dataset.pool_loader` -- this build's
+PathsDataset (records fetched by a thread pool, PIL-exact resize / crop / normalise on the GPU).
 
 Multi-GPU.  Pool scoring is image-independent (eval-mode BN), so with torch.distributed initialised
 (one process per GPU, RCCL) each rank scores a contiguous shard of the key list and the per-image
@@ -64,8 +64,11 @@ class ActiveSelectionBase:
     def make_loader(self, images, include_labels):
         if self.loader_factory is not None:
             return self.loader_factory(images, include_labels)
+        from dataloaders.dataset import paths_dataset  # this build's device-side PathsDataset (or the caller's own package)
+
+        if hasattr(paths_dataset, "pool_loader"):  # records prefetched by threads, resize / crop / normalise on the GPU
+            return paths_dataset.pool_loader(self.env, images, self.crop_size, include_labels, self.dataloader_batch_size)
         from torch.utils.data import DataLoader
-        from dataloaders.dataset import paths_dataset  # the caller's data layer, as in the reference
 
         return DataLoader(paths_dataset.PathsDataset(self.env, images, self.crop_size, include_labels=include_labels),
                           batch_size=self.dataloader_batch_size, shuffle=False, num_workers=0)

@@ -1,0 +1,117 @@
+// Pool reader on the device: one LMDB record = pickle(np.uint8[H, W, 4]) (RGB + label,
+// utils/cityscapes_to_lmdb.py:41-55) -> the normalised f32 crop the scoring loops consume
+// (dataloaders/dataset/paths_dataset.py:27-52 over dataloaders/custom_transforms.py:138-166,214-245,277-297).
+// The reference resizes on the host with scipy.misc.imresize = PIL's resampler, single-threaded (DataLoader(num_workers=0),
+// mc_dropout.py:180-181): ~25 ms per 1024 x 2048 Cityscapes frame, 40 img/s -- far below the scoring rate of the GPU path.
+// Here the raw record is uploaded once (8 MB) and resized by three HBM-bound kernels that reproduce PIL bit for bit:
+//   * bilinear: separable two-pass convolution, horizontal first, triangle filter widened by the down-scale factor,
+//     coefficients in 22-bit fixed point (host-built tables: oracle-checked restatement of Pillow's Resample.c), each
+//     pass rounded to uint8 exactly like Pillow's intermediate image;
+//   * nearest (label plane): source indices from host-built tables (Pillow's running-sum affine path);
+//   * crop / centred paste + Normalize + ToTensor in one pass, in the reference's arithmetic: the label chain
+//     (custom Normalize, numpy) computes (x / 255 in f32, then - mean and / std through float64), the image-only chain
+//     (torchvision ToTensor + Normalize) stays in f32.
+#include "dass_common.h"
+
+namespace {
+
+constexpr int PREC = 22;
+
+// horizontal pass: src [H][W][src_ch] u8 (first 3 channels used) -> dst [H][OW][3] u8
+__global__ __launch_bounds__(256) void resample_h_kernel(const uint8_t *__restrict__ src, int H, int W, int src_ch, uint8_t *__restrict__ dst,
+                                                         int OW, const int *__restrict__ xmin, const int *__restrict__ cnt,
+                                                         const int *__restrict__ kk, int ksize) {
+    const long total = (long)H * OW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / OW), x = (int)(i - (long)y * OW);
+        const int x0 = xmin[x], n = cnt[x];
+        const int *k = kk + (long)x * ksize;
+        int s0 = 1 << (PREC - 1), s1 = s0, s2 = s0;
+        const uint8_t *row = src + ((long)y * W + x0) * src_ch;
+        for (int j = 0; j < n; ++j) {
+            const int c = k[j];
+            s0 += row[j * src_ch] * c;
+            s1 += row[j * src_ch + 1] * c;
+            s2 += row[j * src_ch + 2] * c;
+        }
+        uint8_t *o = dst + i * 3;
+        s0 >>= PREC; s1 >>= PREC; s2 >>= PREC;
+        o[0] = (uint8_t)(s0 < 0 ? 0 : (s0 > 255 ? 255 : s0));
+        o[1] = (uint8_t)(s1 < 0 ? 0 : (s1 > 255 ? 255 : s1));
+        o[2] = (uint8_t)(s2 < 0 ? 0 : (s2 > 255 ? 255 : s2));
+    }
+}
+
+// vertical pass: src [H][OW][3] u8 -> dst [OH][OW][3] u8
+__global__ __launch_bounds__(256) void resample_v_kernel(const uint8_t *__restrict__ src, int H, int OW, uint8_t *__restrict__ dst, int OH,
+                                                         const int *__restrict__ ymin, const int *__restrict__ cnt,
+                                                         const int *__restrict__ kk, int ksize) {
+    const long total = (long)OH * OW * 3;
+    const long pitch = (long)OW * 3;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / pitch);
+        const long col = i - (long)y * pitch;
+        const int y0 = ymin[y], n = cnt[y];
+        const int *k = kk + (long)y * ksize;
+        int s = 1 << (PREC - 1);
+        for (int j = 0; j < n; ++j) s += src[(long)(y0 + j) * pitch + col] * k[j];
+        s >>= PREC;
+        dst[i] = (uint8_t)(s < 0 ? 0 : (s > 255 ? 255 : s));
+    }
+}
+
+// window [S][S] of the resized image placed at (oy0, ox0) in output coordinates (crop: negative offsets = crop origin;
+// padded canvas: positive = paste origin); outside the image: 0 (image) / 255 (label)
+__global__ __launch_bounds__(256) void pool_finalize_kernel(const uint8_t *__restrict__ img, int OH, int OW, const uint8_t *__restrict__ rec,
+                                                            int W, int rec_ch, const int *__restrict__ yidx, const int *__restrict__ xidx,
+                                                            int oy0, int ox0, int S, int divide255, int f64_chain, float *__restrict__ out_img,
+                                                            float *__restrict__ out_lab) {
+    const double mean[3] = {0.485, 0.456, 0.406}, stdv[3] = {0.229, 0.224, 0.225};
+    const long total = (long)S * S;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / S), x = (int)(i - (long)y * S);
+        const int ry = y - oy0, rx = x - ox0;
+        const bool inside = ry >= 0 && ry < OH && rx >= 0 && rx < OW;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = inside ? (float)img[((long)ry * OW + rx) * 3 + c] : 0.f;
+            if (divide255) v = __fdiv_rn(v, 255.0f);
+            if (f64_chain) {  // numpy: float32 array op= float64 constants -> each op in double, stored as float32
+                v = (float)((double)v - mean[c]);
+                v = (float)((double)v / stdv[c]);
+            } else {          // torchvision Normalize: float32 tensors throughout
+                v = __fsub_rn(v, (float)mean[c]);
+                v = __fdiv_rn(v, (float)stdv[c]);
+            }
+            out_img[(long)c * total + i] = v;
+        }
+        if (out_lab) out_lab[i] = inside ? (float)rec[((long)yidx[ry] * W + xidx[rx]) * rec_ch + 3] : 255.f;
+    }
+}
+
+}  // namespace
+
+extern "C" int dass_resample_bilinear_u8(const void *src, int H, int W, int src_ch, void *tmp, void *dst, int OH, int OW, const int *xmin,
+                                         const int *xcnt, const int *xkk, int xksize, const int *ymin, const int *ycnt, const int *ykk,
+                                         int yksize, void *stream) {
+    if (!src || !tmp || !dst || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || src_ch < 3) return DASS_ERR_ARG;
+    if (!xmin || !xcnt || !xkk || !ymin || !ycnt || !ykk || xksize <= 0 || yksize <= 0) return DASS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(resample_h_kernel, dim3(dass_grid_1d((long)H * OW, 256)), dim3(256), 0, st, (const uint8_t *)src, H, W, src_ch,
+                       (uint8_t *)tmp, OW, xmin, xcnt, xkk, xksize);
+    DASS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(resample_v_kernel, dim3(dass_grid_1d((long)OH * OW * 3, 256)), dim3(256), 0, st, (const uint8_t *)tmp, H, OW,
+                       (uint8_t *)dst, OH, ymin, ycnt, ykk, yksize);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_pool_finalize(const void *img, int OH, int OW, const void *rec, int W, int rec_ch, const int *yidx, const int *xidx,
+                                  int oy0, int ox0, int S, int divide255, int f64_chain, float *out_img, float *out_lab, void *stream) {
+    if (!img || !out_img || OH <= 0 || OW <= 0 || S <= 0) return DASS_ERR_ARG;
+    if (out_lab && (!rec || !yidx || !xidx || rec_ch < 4 || W <= 0)) return DASS_ERR_ARG;
+    hipLaunchKernelGGL(pool_finalize_kernel, dim3(dass_grid_1d((long)S * S, 256)), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)img,
+                       OH, OW, (const uint8_t *)rec, W, rec_ch, yidx, xidx, oy0, ox0, S, divide255, f64_chain, out_img, out_lab);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}

@@ -347,6 +347,22 @@ int dass_get_deterministic(void);
  * row; csrc/wgrad_x3.hip).  zero_first = 1 clears dw, 0 accumulates (pixel splits add with f32 atomics either way). */
 int dass_conv2d_wgrad_x3(const void *x3, const void *dy3, float *dw, int N, int H, int W, int C, int OH, int OW, int K,
                          int R, int S, int stride, int pad, int dil, int zero_first, void *stream);
+/* ---------------------------------------------------------------- pool reader
+ * dataloaders/dataset/paths_dataset.py:27-52: a record is uint8 [H][W][4] (RGB + label).  dass_resample_bilinear_u8 =
+ * scipy.misc.imresize(image, (OH, OW)) of custom_transforms.py:153,228,291 = PIL's two-pass bilinear resampler, bit for bit:
+ * src [H][W][src_ch] (first three channels) -> tmp [H][OW][3] -> dst [OH][OW][3]; x / y tables (first source index, tap
+ * count, 22-bit fixed-point taps [out][ksize]) are built on the host (dataloaders/custom_transforms.py:resample_tables).
+ * dass_pool_finalize = centre crop / centred paste + Normalize + ToTensor (+ the nearest-resized label plane read through
+ * yidx / xidx source-index tables): output window [S][S] with the resized image at offset (oy0, ox0) (crop: -y1, -x1;
+ * 512 canvas: +y0, +x0), image 0 / label 255 outside; divide255 / f64_chain select the arithmetic of the label chain
+ * (custom Normalize via numpy float64) or the image-only chain (torchvision, float32).  out_lab nullable. */
+int dass_resample_bilinear_u8(const void *src, int H, int W, int src_ch, void *tmp, void *dst, int OH, int OW,
+                              const int *xmin, const int *xcnt, const int *xkk, int xksize,
+                              const int *ymin, const int *ycnt, const int *ykk, int yksize, void *stream);
+int dass_pool_finalize(const void *img, int OH, int OW, const void *rec, int W, int rec_ch, const int *yidx,
+                       const int *xidx, int oy0, int ox0, int S, int divide255, int f64_chain, float *out_img,
+                       float *out_lab, void *stream);
+
 /* DIAGNOSTIC, not on the product path (tools/clock_probe.py): `blocks` workgroups run a bf16 MFMA loop (use_lds: with
  * LDS fragment reads) and report {shader cycles, 100 MHz ticks} per block into out[2 * blocks] (uint64): the clock the chip
  * sustains under that load = cycles / ticks * 100 MHz. */

@@ -4,6 +4,10 @@ and writes the extra fixtures (existing fixtures are left untouched).
 TEST INFRASTRUCTURE.  Run ONLY in the authoring container (needs /root/reference, read-only):
     python oracle/make_goldens_r2.py
   metrics.npz   utils/metrics.py:6-49 Evaluator on seeded label / prediction maps: confusion matrix + the four metrics
+  pool_reader.npz  dataloaders/dataset/paths_dataset.py:27-52 over the reference's own transform classes
+                (custom_transforms.py FixScaleCrop / ScaleWithPadding / Normalize / ToTensor) on synthetic LMDB-style records;
+                scipy.misc.imresize (removed from SciPy) is supplied as its published two-line body over PIL, torchvision's
+                ToTensor / Normalize (absent here) by their documented float32 arithmetic -- see pool_reader_goldens()
   mc_noise.npz  active_selection/mc_noise.py:21-44 (gaussian input noise) and :62-84 (+ models/deeplab.py:39-56 feature
                 noise) run on the reference DeepLab-MobileNet with numpy's seeded generator: the reference's argmax votes
                 (recorded by a wrapper around the model) and its entropy maps.  The tests replay the same np.random
@@ -41,6 +45,61 @@ class Recorder(torch.nn.Module):
         out = self.module(x)
         self.votes.append(torch.argmax(out, dim=1))
         return out
+
+
+def pool_record(h, w, seed):
+    """synthetic LMDB-style record: smooth-ish RGB + a blocky label plane with some 255 (ignore) pixels, uint8 [h, w, 4]"""
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    rgb = np.stack([(127 + 100 * np.sin(yy / (3.0 + c) + xx / (5.0 - c)) + rng.randint(-20, 21, (h, w))).clip(0, 255) for c in range(3)], 2)
+    lab = ((yy // 7 + xx // 11) % 19).astype(np.uint8)
+    lab[rng.rand(h, w) < 0.03] = 255
+    return np.ascontiguousarray(np.dstack((rgb.astype(np.uint8), lab)))
+
+
+POOL_CASES = [(96, 192, 65, 1), (130, 100, 65, 2), (64, 64, 65, 3), (75, 100, 129, 4), (96, 192, -1, 5), (150, 101, -1, 6)]
+
+
+def pool_reader_goldens(out):
+    """drives the reference's transform classes the way paths_dataset.py:40-52 composes them"""
+    import scipy.misc
+    from PIL import Image
+
+    def imresize(arr, size, interp="bilinear", mode=None):  # scipy.misc.imresize (SciPy <= 1.2) for uint8 input and a size tuple
+        im = Image.fromarray(arr, mode=mode)
+        func = {"nearest": 0, "lanczos": 1, "bilinear": 2, "bicubic": 3, "cubic": 3}
+        return np.asarray(im.resize((size[1], size[0]), resample=func[interp]))
+
+    scipy.misc.imresize = imresize
+    from dataloaders import custom_transforms as rtr
+
+    rtr.imresize = imresize  # the module did `from scipy.misc import imresize` at import time
+    from oracle import transforms_cpu as T
+
+    for h, w, crop, seed in POOL_CASES:
+        rec = pool_record(h, w, seed)
+        image, target = rec[:, :, 0:3], rec[:, :, 3]
+        tag = "%dx%d_c%d" % (h, w, crop)
+        # include_labels=True: scalecrop -> custom Normalize -> custom ToTensor (paths_dataset.py:40-45)
+        scalecrop = rtr.ScaleWithPadding(base_size=512) if crop == -1 else rtr.FixScaleCrop(crop_size=crop)
+        sample = rtr.ToTensor()(rtr.Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])(scalecrop({"image": image, "label": target})))
+        mine = T.pool_sample(rec, crop, True)
+        assert np.array_equal(sample["label"].numpy(), mine["label"]), tag
+        assert np.array_equal(sample["image"].numpy(), mine["image"]), (tag, np.abs(sample["image"].numpy() - mine["image"]).max())
+        # include_labels=False: scalecrop_image_only (reference class) -> torchvision ToTensor + Normalize (restated: f32)
+        only = rtr.ScaleWithPaddingImageOnly(base_size=512) if crop == -1 else rtr.FixScaleCropImageOnly(crop_size=crop)
+        arr = only(image)
+        t = torch.from_numpy(np.ascontiguousarray(arr.transpose(2, 0, 1)))
+        t = t.float().div(255) if arr.dtype == np.uint8 else t.float()
+        mean, std = torch.tensor([0.485, 0.456, 0.406])[:, None, None], torch.tensor([0.229, 0.224, 0.225])[:, None, None]
+        t = t.sub(mean).div(std)
+        mine_img = T.pool_sample(rec, crop, False)
+        assert np.array_equal(t.numpy(), mine_img), tag
+        sub = slice(None, None, 3) if crop == -1 else slice(None)   # the 512 canvas is stored subsampled
+        out["pool_%s_image" % tag] = sample["image"].numpy()[:, sub, sub]
+        out["pool_%s_label" % tag] = sample["label"].numpy()[sub, sub].astype(np.uint8)
+        out["pool_%s_image_only" % tag] = t.numpy()[:, sub, sub]
+    return out
 
 
 def main():
@@ -134,7 +193,8 @@ def main():
     out["meta"] = np.array([n, hw, ncls, T])
     np.savez_compressed(os.path.join(OUT, "mc_noise.npz"), **out)
     ref["constants"].MC_STEPS = 20
-    print("metrics.npz, mc_noise.npz written; oracle == reference")
+    np.savez_compressed(os.path.join(OUT, "pool_reader.npz"), **pool_reader_goldens({}))
+    print("metrics.npz, mc_noise.npz, pool_reader.npz written; oracle == reference")
 
 
 if __name__ == "__main__":

@@ -158,6 +158,54 @@ def test_oracle_metrics_and_noise_goldens():
     assert np.abs(S.region_features(f, [(0, 0, 48, 48), (0, 0, 48, 48)], 48) - f.double().mean(dim=(2, 3)).numpy()).max() < 1e-12
 
 
+POOL_CASES = [(96, 192, 65, 1), (130, 100, 65, 2), (64, 64, 65, 3), (75, 100, 129, 4), (96, 192, -1, 5), (150, 101, -1, 6)]
+
+
+def pool_record(h, w, seed):
+    """the synthetic LMDB-style record of oracle/make_goldens_r2.py (uint8 [h, w, 4] = RGB + label)"""
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    rgb = np.stack([(127 + 100 * np.sin(yy / (3.0 + c) + xx / (5.0 - c)) + rng.randint(-20, 21, (h, w))).clip(0, 255) for c in range(3)], 2)
+    lab = ((yy // 7 + xx // 11) % 19).astype(np.uint8)
+    lab[rng.rand(h, w) < 0.03] = 255
+    return np.ascontiguousarray(np.dstack((rgb.astype(np.uint8), lab)))
+
+
+def test_oracle_pool_reader_goldens_and_tables():
+    """the oracle's restatement of PathsDataset.__getitem__ (PIL-exact integer resampler, crop / padded
+    canvas, both normalisation chains) reproduces the fixtures written from the reference's transform classes; the product's
+    host-side tables (what the HIP kernels consume) equal the oracle's; the resampler equals Pillow where Pillow is present"""
+    from oracle import transforms_cpu as T
+
+    g = np.load(os.path.join(GOLD, "pool_reader.npz"))
+    for h, w, crop, seed in POOL_CASES:
+        rec = pool_record(h, w, seed)
+        tag = "%dx%d_c%d" % (h, w, crop)
+        sub = slice(None, None, 3) if crop == -1 else slice(None)
+        s = T.pool_sample(rec, crop, True)
+        assert np.array_equal(s["image"][:, sub, sub], g["pool_%s_image" % tag]), tag
+        assert np.array_equal(s["label"][sub, sub].astype(np.uint8), g["pool_%s_label" % tag]), tag
+        assert np.array_equal(T.pool_sample(rec, crop, False)[:, sub, sub], g["pool_%s_image_only" % tag]), tag
+    from dataloaders import custom_transforms as tr
+
+    for a, b in ((2048, 1026), (1024, 513), (500, 684), (375, 513), (100, 65), (37, 65), (64, 65), (30, 7), (512, 512), (192, 512)):
+        for x, y in zip(T.resample_coeffs(a, b), tr.resample_tables(a, b)):
+            assert np.array_equal(x, y), (a, b)
+        assert np.array_equal(T.nearest_indices(a, b), tr.nearest_table(a, b))
+    assert tr.fix_scale_crop(1024, 2048, 513) == (513, 1026, 0, 256) and T.fix_scale_crop_geometry(1024, 2048, 513) == (513, 1026, 0, 256)
+    assert tr.scale_with_padding(375, 500) == T.pad_scale_geometry(375, 500) == (384, 512, 64, 0)
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    rng = np.random.RandomState(0)
+    for (h, w, oh, ow) in ((96, 192, 65, 130), (100, 37, 175, 65), (256, 512, 129, 258), (30, 30, 7, 9), (375, 500, 513, 684)):
+        a = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        assert np.array_equal(T.resize_bilinear_u8(a, oh, ow), np.asarray(Image.fromarray(a).resize((ow, oh), resample=Image.BILINEAR)))
+        lab = rng.randint(0, 20, (h, w)).astype(np.uint8)
+        assert np.array_equal(T.resize_nearest_u8(lab, oh, ow), np.asarray(Image.fromarray(lab).resize((ow, oh), resample=Image.NEAREST)))
+
+
 def test_hash_fill_is_stable():
     u = O._hash_uniform(5, 7)
     assert u.dtype == np.float32 and np.all((u >= 0) & (u < 1))
