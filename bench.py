@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--mc-steps", type=int, default=10, help="T of the MC-dropout scoring leg")
     ap.add_argument("--mc-batches", type=int, default=47, help="timed scoring batches per rank (47 x 8 = 376 >= config D's 372 per GPU)")
     ap.add_argument("--no-coreset", action="store_true")
+    ap.add_argument("--no-pool-reader", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="headline mode (f32 = parity mode)")
     ap.add_argument("--f32-mma", default="bf16x6", choices=["bf16x6", "f32", "bf16x3"],
                     help="conv engine of the f32 headline (bf16x6 = exact three-way split, the default parity engine)")
@@ -372,6 +373,61 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
     return res
 
 
+def pool_reader_leg(args, dev):
+    """1024 x 2048 Cityscapes-shaped records (pickled uint8 [H, W, 4], the LMDB wire format) -> normalised
+    513 x 513 crops + labels on the GPU through dataloaders.dataset.paths_dataset.pool_loader (unpickle, 8 MB host->device
+    copy per frame, PIL-exact resize / crop / normalise kernels), against the reference's host pipeline on ONE core
+    (DataLoader(num_workers=0), mc_dropout.py:180-181: PIL bilinear + nearest resize, numpy Normalize)"""
+    import pickle
+
+    import numpy as np
+    from dataloaders.dataset.paths_dataset import DictEnv, pool_loader
+
+    rng = np.random.RandomState(0)
+    base = rng.randint(0, 256, (1024, 2048, 4)).astype(np.uint8)
+    recs = {}
+    for i in range(32):
+        r = np.roll(base, 37 * i, axis=1)
+        r[:, :, 3] = (r[:, :, 3] % 20)
+        recs[("frame_%03d" % i).encode("ascii")] = pickle.dumps(r, protocol=3)
+    keys = sorted(recs)
+    env = DictEnv(recs)
+    for _ in pool_loader(env, keys[:8], args.size, True, args.batch):
+        pass
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 0
+    for batch in pool_loader(env, keys, args.size, True, args.batch):
+        n += batch["image"].shape[0]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"metric": "pool_reader_images_per_s", "value": round(n / dt, 2), "unit": "images/s", "records": n,
+           "record": "1024x2048x4 uint8 (8 MB) -> 3x%dx%d f32 + label" % (args.size, args.size),
+           "note": "host->device copy of the raw record included (PCIe); resize / crop / normalise on the GPU"}
+    try:
+        from PIL import Image
+
+        torch.set_num_threads(1)
+        t0 = time.perf_counter()
+        m = 0
+        while m < 8 and time.perf_counter() - t0 < 5.0:
+            rec = pickle.loads(recs[keys[m]])
+            img = np.asarray(Image.fromarray(rec[:, :, :3]).resize((1026, 513), resample=Image.BILINEAR))[:, 256:769]
+            lab = np.asarray(Image.fromarray(rec[:, :, 3]).resize((1026, 513), resample=Image.NEAREST))[:, 256:769]
+            x = img.astype(np.float32)
+            x /= 255.0
+            x -= (0.485, 0.456, 0.406)
+            x /= (0.229, 0.224, 0.225)
+            torch.from_numpy(np.ascontiguousarray(x.transpose(2, 0, 1))), torch.from_numpy(lab.astype(np.float32))
+            m += 1
+        out["cpu_reference_style"] = {"value": round(m / (time.perf_counter() - t0), 2), "unit": "images/s", "cores": 1,
+                                      "sample": "%d frames, PIL resize + numpy Normalize on one core (the reference's num_workers=0 loader)" % m}
+    except ImportError:
+        out["cpu_reference_style"] = None
+    log("pool reader: %.1f images/s on the GPU path%s" % (out["value"], (", %.1f on one host core" % out["cpu_reference_style"]["value"]) if out["cpu_reference_style"] else ""))
+    return out
+
+
 def cpu_baseline(args):
     from oracle import deeplab_cpu as O
     from oracle import selection_cpu as S
@@ -485,7 +541,9 @@ def main():
             others["bf16_perf_mode"] = run_mode(args, env, "bf16", k2, 4)  # 4 warm-up steps: the allocator re-grows after empty_cache()
         else:
             others["f32_parity_mode"] = run_mode(args, env, "f32", k2, 4, args.f32_mma)
-    cpu = None
+    cpu = reader = None
+    if env.rank == 0 and env.world == 1 and not args.no_pool_reader:
+        reader = pool_reader_leg(args, env.dev)
     if env.rank == 0 and env.world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
 
@@ -500,7 +558,8 @@ def main():
                            "global_batch": b * world, "parallelism": "dp%d" % world, "bn": "per-GPU",
                            "f32_mma": args.f32_mma if args.dtype == "f32" else None,
                            "final_loss": round(head["final_loss"], 5)},
-                "mc_dropout": head["mc"], "core_set": head["coreset"], "roofline": head["roofline"], "cpu_baseline": cpu}
+                "mc_dropout": head["mc"], "core_set": head["coreset"], "pool_reader": reader, "roofline": head["roofline"],
+                "cpu_baseline": cpu}
         notes = {"bf16_perf_mode": "informational; bf16 storage does not meet the parity bar (tests/test_bf16_gpu.py measures the deviation)",
                  "f32_mfma_mode": "same f32 tensors, convs on v_mfma_f32_32x32x2_f32; parity-grade as well",
                  "f32_parity_mode": "the parity mode (f32 tensors)"}
