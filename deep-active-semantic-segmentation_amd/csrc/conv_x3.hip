@@ -40,6 +40,10 @@ struct X3P {
     int cc_out;
     int N, H, W, CC, OH, OW, K, R, S, stride, pad, dil, act;
     int M, mtiles, ntiles, sk_wgs;
+    int dp_tiles, sk_part;          // tiles [0, dp_tiles) go one per workgroup and round; the rest is cut into sk_part slab ranges
+    int group_rows, mt_per_group;   // per-image mode: M-tiles never straddle an image; group_rows = M otherwise
+    unsigned w3_group_stride;       // per-image mode: byte offset between the weight operands of consecutive images
+    const int *cc_limit;            // per-image mode: channel slabs of image g that hold anything (the others are skipped)
     int OHs, OWs, o_mul, oy_add, ox_add, ustride;
     unsigned long long tap_allow;
 };
@@ -162,17 +166,34 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     // ---- this workgroup's range of (tile, slab) units
     const int wgid = xcd_remap(blockIdx.x, gridDim.x);
     const long S_tile = (long)p.CC * ntaps;
-    const long U = (long)p.mtiles * p.ntiles * S_tile;
-    const long u_begin = U * wgid / p.sk_wgs, u_end = U * (wgid + 1) / p.sk_wgs;
-    int seg_idx = 0;
-    for (long u = u_begin; u < u_end; ++seg_idx) {
-    const int tile = (int)(u / S_tile);
-    const int s_lo = (int)(u - (long)tile * S_tile);
-    const int s_hi = (int)((u_end - u) < (S_tile - s_lo) ? s_lo + (u_end - u) : S_tile);
-    u += s_hi - s_lo;
+    const long U = ((long)p.mtiles * p.ntiles - p.dp_tiles) * S_tile;  // units of the stream-K region
+    const long u_begin = wgid < p.sk_part ? U * wgid / p.sk_part : U, u_end = wgid < p.sk_part ? U * (wgid + 1) / p.sk_part : U;
+    const int dp_rounds = p.dp_tiles / p.sk_wgs;
+    int seg_idx = 0;  // stream-K segments done so far
+    long u = u_begin;
+    for (int round = 0; round < dp_rounds || u < u_end; ++round) {
+    int tile, s_lo, s_hi;
+    if (round < dp_rounds) {  // data-parallel part: whole tiles, fused epilogue, no workspace traffic
+        tile = round * p.sk_wgs + wgid;
+        s_lo = 0;
+        s_hi = (int)S_tile;
+    } else {
+        tile = p.dp_tiles + (int)(u / S_tile);
+        s_lo = (int)(u - (long)(tile - p.dp_tiles) * S_tile);
+        s_hi = (int)((u_end - u) < (S_tile - s_lo) ? s_lo + (u_end - u) : S_tile);
+        u += s_hi - s_lo;
+    }
     const bool complete = s_lo == 0 && s_hi == (int)S_tile;
+    const int sk_seg = round < dp_rounds ? 0 : seg_idx++;
     const int mt_i = tile / p.ntiles, nt_i = tile - mt_i * p.ntiles;
-    const int m0 = mt_i * BM, n0 = nt_i * BN;
+    const int grp = mt_i / p.mt_per_group;
+    const int m0 = grp * p.group_rows + (mt_i - grp * p.mt_per_group) * BM, n0 = nt_i * BN;
+    const int m_end = (grp + 1) * p.group_rows < p.M ? (grp + 1) * p.group_rows : p.M;
+    if (p.cc_limit) {  // slabs are channel-slab major: dropping the slabs >= limit truncates the range
+        const int lim = p.cc_limit[grp] * ntaps;
+        s_lo = s_lo < lim ? s_lo : lim;
+        s_hi = s_hi < lim ? s_hi : lim;
+    }
     __syncthreads();  // the previous segment's epilogue is done with the ring; tap_delta is visible
 
     unsigned rb_off[RG];
@@ -188,7 +209,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
         rb_off[j] = 0u;
         if (q < AG) {
             const int m = m0 + q * 16 + r16;
-            a_ok[j] = m < p.M;
+            a_ok[j] = m < m_end;
             const int mm = a_ok[j] ? m : 0;
             const int n = mm / ohw;
             const int rem = mm - n * ohw;
@@ -200,7 +221,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
         } else {
             int k = n0 + (q - AG) * 16 + r16;
             if (k >= p.K) k = p.K - 1;  // columns >= K are never stored: any finite row will do
-            rb_off[j] = (unsigned)k * (unsigned)(ntaps * p.CC * 192) + chunk_off;
+            rb_off[j] = (unsigned)grp * p.w3_group_stride + (unsigned)k * (unsigned)(ntaps * p.CC * 192) + chunk_off;
         }
     }
 
@@ -390,7 +411,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     static_assert(NT % PBLK == 0, "column blocks per pass");
     float *patch = reinterpret_cast<float *>(smem) + wave * 32 * PITCH;
     const bool vec_ok = (!y || (p.ldy & 3) == 0) && ((p.K & 3) == 0) && (!res || (p.ldr & 3) == 0);
-    float *slab = complete ? nullptr : p.ws + ((long)wgid * 2 + (seg_idx > 0 ? 1 : 0)) * (BM * BN);
+    float *slab = complete ? nullptr : p.ws + ((long)wgid * 2 + (sk_seg > 0 ? 1 : 0)) * (BM * BN);
     if (p.y3 && tile == 0 && s_lo == 0)  // the zero row consumers point padded taps at
         for (int i = tid; i < p.cc_out * 12; i += 64 * NW)
             *reinterpret_cast<uint4 *>(p.y3 + (long)p.M * p.cc_out * 192 + i * 16) = make_uint4(0u, 0u, 0u, 0u);
@@ -419,7 +440,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
                     continue;
                 }
                 const int m = m0 + lr, k = n0 + lc;
-                if (m >= p.M || k >= p.K) continue;
+                if (m >= m_end || k >= p.K) continue;
                 x3_store_out(p, v, m, k, ohw, vec_ok);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -436,16 +457,19 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
 template <int BM, int BN> __global__ __launch_bounds__(256) void conv_x3_fixup_kernel(const X3P p) {
     const int ntaps = p.R * p.S;
     const long S_tile = (long)p.CC * ntaps;
-    const long U = (long)p.mtiles * p.ntiles * S_tile;
+    const long U = ((long)p.mtiles * p.ntiles - p.dp_tiles) * S_tile;
     const int i = blockIdx.x;
-    auto bound = [&](int w) -> long { return U * w / p.sk_wgs; };
+    auto bound = [&](int w) -> long { return U * w / p.sk_part; };
     const long b1 = bound(i + 1);
-    const int tile = (int)(b1 / S_tile);
-    const long t_lo = (long)tile * S_tile, t_hi = t_lo + S_tile;
+    const int rtile = (int)(b1 / S_tile);  // tile index inside the stream-K region
+    const long t_lo = (long)rtile * S_tile, t_hi = t_lo + S_tile;
     if (b1 == t_lo || b1 >= U) return;   // boundary on a tile edge: nothing is split here
     if (bound(i) > t_lo) return;         // an earlier boundary already lies inside this tile: its block does the work
+    const int tile = p.dp_tiles + rtile;
     const int mt_i = tile / p.ntiles, nt_i = tile - mt_i * p.ntiles;
-    const int m0 = mt_i * BM, n0 = nt_i * BN;
+    const int grp = mt_i / p.mt_per_group;
+    const int m0 = grp * p.group_rows + (mt_i - grp * p.mt_per_group) * BM, n0 = nt_i * BN;
+    const int m_end = (grp + 1) * p.group_rows < p.M ? (grp + 1) * p.group_rows : p.M;
     const int ohw = p.OHs * p.OWs;
     const float *res = reinterpret_cast<const float *>(p.res);
     const float *y = reinterpret_cast<const float *>(p.y);
@@ -457,7 +481,7 @@ template <int BM, int BN> __global__ __launch_bounds__(256) void conv_x3_fixup_k
     const int tid = threadIdx.x;
     if (tid == 0) {
         int nc = 0;
-        for (int w = i; w < p.sk_wgs && nc < 256; ++w) {
+        for (int w = i; w < p.sk_part && nc < 256; ++w) {
             const long bw = bound(w);
             if (bw >= t_hi) break;
             if (bound(w + 1) == bw) continue;  // a workgroup with an empty range wrote nothing
@@ -469,13 +493,15 @@ template <int BM, int BN> __global__ __launch_bounds__(256) void conv_x3_fixup_k
     const int nc = ncontrib;
     const int c4 = tid % C4, r0 = tid / C4;
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-    for (int lr = r0; lr < BM; lr += RPP) {
+    // blockIdx.y cuts the tile's rows (more blocks in flight: the pass is latency-bound); BN statistics need the whole tile
+    const int rows_per_block = BM / gridDim.y, row_lo = blockIdx.y * rows_per_block;
+    for (int lr = row_lo + r0; lr < row_lo + rows_per_block; lr += RPP) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         for (int c = 0; c < nc; ++c) v += *reinterpret_cast<const f32x4 *>(contrib[c] + lr * BN + c4 * 4);
         s1 += v;
         s2 += v * v;
         const int m = m0 + lr, k = n0 + c4 * 4;
-        if (m < p.M && k < p.K) x3_store_out(p, v, m, k, ohw, vec_ok);
+        if (m < m_end && k < p.K) x3_store_out(p, v, m, k, ohw, vec_ok);
     }
     if (p.stat_partial) {  // rows >= M of the slabs are exact zeros
         constexpr int NR = RPP;
@@ -538,24 +564,36 @@ static int g_cus = 0;  // compute units of the current device (stream-K launches
 template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE> int launch_x3(X3P &p, hipStream_t st, int mode, long ws_bytes) {
     constexpr int LDS = NSTAGE * (BM + BN) * 192 + 256;
     constexpr int RES = (160 * 1024) / LDS >= 4 ? 4 : (160 * 1024) / LDS;  // resident workgroups per CU (LDS-limited)
-    p.mtiles = (p.M + BM - 1) / BM;
+    p.mt_per_group = (p.group_rows + BM - 1) / BM;
+    p.mtiles = p.mt_per_group * ((p.M + p.group_rows - 1) / p.group_rows);
     p.ntiles = (p.K + BN - 1) / BN;
     const long tiles = (long)p.mtiles * p.ntiles, slots = (long)g_cus * RES;
     const long units = tiles * p.CC * p.R * p.S;
     // one tile per workgroup when that quantises well (or the problem is tiny); equal slab ranges per resident slot otherwise
-    bool stream = mode == 2;
+    bool stream = mode >= 2;  // 3 = stream-K over ALL tiles (no whole-round part): segment ends, hence epilogues, are staggered
     if (mode == 0) {
         const long rounds = (tiles + slots - 1) / slots;
         const double eff = (double)tiles / (double)(rounds * slots);  // busy share of the last-round-limited schedule
         stream = eff < 0.92 && units >= 6 * slots && (long)p.CC * p.R * p.S >= 4;
     }
     if (stream && (!p.ws || ws_bytes < 2 * slots * (long)BM * BN * 4)) stream = false;
-    if (stream && (long)p.CC * p.R * p.S / (units / slots > 0 ? units / slots : 1) + 2 > 256) stream = false;  // fix-up contributor table
+    // stream-K: whole rounds of tiles go one per workgroup (fused epilogue, no workspace), only the remainder -- less than
+    // one round -- is cut into equal slab ranges, each at least 4 slabs long (bounds the fix-up's contributor table)
     p.sk_wgs = stream ? (int)slots : (int)tiles;
+    p.dp_tiles = stream && mode != 3 && !p.stat_partial ? (int)(tiles / slots * slots) : 0;  // (the statistics fix-up is one block per tile)
+    p.sk_part = p.sk_wgs;
+    if (stream) {
+        const long s_tile = (long)p.CC * p.R * p.S, ur = (tiles - p.dp_tiles) * s_tile;
+        if (ur / 4 < p.sk_part) p.sk_part = ur / 4 > 0 ? (int)(ur / 4) : 1;
+        if (p.dp_tiles == tiles) stream = false;  // the tile count is a whole number of rounds
+        else if (s_tile / (ur / p.sk_part > 0 ? ur / p.sk_part : 1) + 2 > 256) return DASS_ERR_UNSUPPORTED;  // cannot happen for S_tile <= 1016
+    }
     hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE>), dim3(p.sk_wgs), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
     DASS_LAUNCH_CHECK();
     if (stream) {
-        hipLaunchKernelGGL((conv_x3_fixup_kernel<BM, BN>), dim3(p.sk_wgs), dim3(256), 0, st, p);
+        constexpr int RPP = 256 / (BN / 4);
+        const int row_split = p.stat_partial ? 1 : (BM / RPP >= 8 ? 8 : BM / RPP);
+        hipLaunchKernelGGL((conv_x3_fixup_kernel<BM, BN>), dim3(p.sk_part, row_split), dim3(256), 0, st, p);
         DASS_LAUNCH_CHECK();
     }
     return DASS_OK;
@@ -622,10 +660,10 @@ extern "C" int dass_split3_rows(const float *x, int64_t ld, void *out, int64_t M
     return DASS_OK;
 }
 
-extern "C" int dass_conv2d_x3(const void *x3, const void *w3, void *y, int64_t ldy, void *y3, const float *scale, const float *shift,
-                              const void *residual, int64_t ldr, int N, int H, int W, int C, int OH, int OW, int K, int R, int S,
-                              int stride, int pad, int dil, int ustride, int act, float *stat_partial, int *stat_rows, void *workspace,
-                              int64_t workspace_bytes, void *stream) {
+static int conv_x3_impl(const void *x3, const void *w3, void *y, int64_t ldy, void *y3, const float *scale, const float *shift,
+                        const void *residual, int64_t ldr, int N, int H, int W, int C, int OH, int OW, int K, int R, int S, int stride,
+                        int pad, int dil, int ustride, int act, float *stat_partial, int *stat_rows, void *workspace,
+                        int64_t workspace_bytes, void *stream, bool per_image, const int *cc_limit) {
     if (!x3 || !w3 || (!y && !y3)) return DASS_ERR_ARG;
     if (workspace && ((uintptr_t)workspace & 15)) return DASS_ERR_ARG;
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || K <= 0 || R <= 0 || S <= 0) return DASS_ERR_ARG;
@@ -633,7 +671,8 @@ extern "C" int dass_conv2d_x3(const void *x3, const void *w3, void *y, int64_t l
     if (((uintptr_t)x3 & 15) || ((uintptr_t)w3 & 15) || ((uintptr_t)y3 & 15)) return DASS_ERR_ARG;
     if ((long)N * OH * OW >= (1l << 31)) return DASS_ERR_ARG;
     const int CC = (C + 31) / 32;
-    const long xbytes = ((long)N * H * W + 1) * CC * 192, wbytes = (long)K * R * S * CC * 192;
+    const long xbytes = ((long)N * H * W + 1) * CC * 192, wbytes = (long)K * R * S * CC * 192 * (per_image ? N : 1);
+    if (per_image && ustride != 1) return DASS_ERR_UNSUPPORTED;
     if (xbytes >= (1l << 32) || wbytes >= (1l << 32)) return DASS_ERR_UNSUPPORTED;  // 32-bit buffer offsets
     if (y3 && (K & 3)) return DASS_ERR_ARG;
     if (!y && residual && (ldr & 3)) return DASS_ERR_ARG;
@@ -657,6 +696,9 @@ extern "C" int dass_conv2d_x3(const void *x3, const void *w3, void *y, int64_t l
     p.N = N; p.H = H; p.W = W; p.CC = CC; p.OH = OH; p.OW = OW; p.K = K; p.R = R; p.S = S;
     p.stride = stride; p.pad = pad; p.dil = dil; p.act = act; p.ustride = ustride;
     p.M = N * OH * OW;
+    p.group_rows = per_image ? OH * OW : p.M;
+    p.w3_group_stride = per_image ? (unsigned)((long)K * R * S * CC * 192) : 0u;
+    p.cc_limit = per_image ? cc_limit : nullptr;
     p.OHs = OH; p.OWs = OW; p.o_mul = 1; p.oy_add = 0; p.ox_add = 0;
     p.tap_allow = ~0ull;
     hipStream_t st = (hipStream_t)stream;
@@ -687,6 +729,7 @@ extern "C" int dass_conv2d_x3(const void *x3, const void *w3, void *y, int64_t l
                 q.o_mul = ustride; q.oy_add = py; q.ox_add = px;
                 q.tap_allow = masks[py][px];
                 q.M = N * q.OHs * q.OWs;
+                q.group_rows = q.M;
                 const int rc = dispatch_x3(q, st, workspace_bytes);
                 if (rc != DASS_OK) return rc;
             }
@@ -695,4 +738,157 @@ extern "C" int dass_conv2d_x3(const void *x3, const void *w3, void *y, int64_t l
     const int rc = dispatch_x3(p, st, workspace_bytes);
     if (stat_rows) *stat_rows = p.mtiles;
     return rc;
+}
+
+extern "C" int dass_conv2d_x3(const void *x3, const void *w3, void *y, int64_t ldy, void *y3, const float *scale, const float *shift,
+                              const void *residual, int64_t ldr, int N, int H, int W, int C, int OH, int OW, int K, int R, int S,
+                              int stride, int pad, int dil, int ustride, int act, float *stat_partial, int *stat_rows, void *workspace,
+                              int64_t workspace_bytes, void *stream) {
+    return conv_x3_impl(x3, w3, y, ldy, y3, scale, shift, residual, ldr, N, H, W, C, OH, OW, K, R, S, stride, pad, dil, ustride, act,
+                        stat_partial, stat_rows, workspace, workspace_bytes, stream, false, nullptr);
+}
+
+// Per-image weight operands: image g multiplies with w3 + g * (K * R * S * CC * 192) and only its first cc_limit[g] channel
+// slabs (device array, nullable = all) enter the reduction.  This is the Dropout2d-sparse form of the MC-dropout tail conv
+// (active_selection/mc_dropout.py:38-51 runs T passes through models/decoder.py:23-36 with half of the ASPP channels zeroed):
+// the surviving channels of every image are packed to the front (dass_dropout_compact / dass_split3_rows_packed /
+// dass_w3_pack_per_image), dropped channels contribute exact zeros and are skipped instead of multiplied.
+extern "C" int dass_conv2d_x3_per_image(const void *x3, const void *w3, const int *cc_limit, void *y, int64_t ldy, void *y3,
+                                        const float *scale, const float *shift, const void *residual, int64_t ldr, int N, int H, int W,
+                                        int C, int OH, int OW, int K, int R, int S, int stride, int pad, int dil, int act,
+                                        void *workspace, int64_t workspace_bytes, void *stream) {
+    return conv_x3_impl(x3, w3, y, ldy, y3, scale, shift, residual, ldr, N, H, W, C, OH, OW, K, R, S, stride, pad, dil, 1, act, nullptr,
+                        nullptr, workspace, workspace_bytes, stream, true, cc_limit);
+}
+
+namespace {
+
+// mask [N][C] (0 = dropped, else the multiplier) -> order [N][CC * 32]: the surviving channel indices in ascending order,
+// then -1; cc_limit[n] = slabs of 32 that hold a survivor.  One wave per image.
+__global__ __launch_bounds__(64) void dropout_compact_kernel(const float *__restrict__ mask, int C, int CC, int *__restrict__ order,
+                                                             int *__restrict__ cc_limit) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const float *m = mask + (long)n * C;
+    int *o = order + (long)n * CC * 32;
+    int kept = 0;
+    for (int base = 0; base < C; base += 64) {
+        const int c = base + lane;
+        const bool keep = c < C && m[c] != 0.f;
+        const unsigned long long b = __ballot(keep);
+        if (keep) o[kept + __builtin_popcountll(b & ((1ull << lane) - 1ull))] = c;
+        kept += __builtin_popcountll(b);
+    }
+    for (int j = kept + lane; j < CC * 32; j += 64) o[j] = -1;
+    if (lane == 0) cc_limit[n] = (kept + 31) / 32;
+}
+
+// f32 rows -> x3 rows with the channels of image n permuted by order[n] and multiplied by mask[n]; slabs >= cc_limit[n] are
+// not written (the conv never reads them); the zero row M is (by the last block).  A block works inside ONE image: thread t
+// owns 8 packed channels (unit t % (CC * 4)) -- their source indices and multipliers are fetched once -- and walks the rows
+// t / (CC * 4), + 256 / (CC * 4), ... of the block's row range.
+__global__ __launch_bounds__(256) void split3_rows_packed_kernel(const float *__restrict__ x, long ld, char *__restrict__ out, long M, int C,
+                                                                 int CC, const float *__restrict__ mask, const int *__restrict__ order,
+                                                                 const int *__restrict__ cc_limit, long rows_per_image, int chunks) {
+    const int n = blockIdx.x / chunks, chunk = blockIdx.x - n * chunks;
+    const int upr = CC * 4, unit = threadIdx.x % upr, rstep = blockDim.x / upr;
+    const int cc = unit >> 2, oct = unit & 3;
+    if ((long)n * rows_per_image >= M) {  // the extra block: the zero row
+        for (int i = threadIdx.x; i < CC * 12; i += blockDim.x) *reinterpret_cast<uint4 *>(out + M * CC * 192 + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
+    if (threadIdx.x >= upr * rstep || cc >= cc_limit[n]) return;
+    const int *o = order + ((long)n * CC + cc) * 32 + oct * 8;
+    int ci[8];
+    float sc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        ci[e] = o[e];
+        sc[e] = ci[e] >= 0 ? mask[(long)n * C + ci[e]] : 0.f;
+        ci[e] = ci[e] >= 0 ? ci[e] : 0;
+    }
+    const long per = (rows_per_image + chunks - 1) / chunks;
+    const long r_lo = chunk * per, r_hi = r_lo + per < rows_per_image ? r_lo + per : rows_per_image;
+    for (long r = r_lo + threadIdx.x / upr; r < r_hi; r += rstep) {
+        const long m = (long)n * rows_per_image + r;
+        const float *src = x + m * ld;
+        f32x4 v0, v1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v0[e] = src[ci[e]] * sc[e];
+            v1[e] = src[ci[4 + e]] * sc[4 + e];
+        }
+        uint2 a0, a1, a2, b0, b1, b2;
+        split3_4(v0, a0, a1, a2);
+        split3_4(v1, b0, b1, b2);
+        char *d = out + (m * CC + cc) * 192 + oct * 16;
+        *reinterpret_cast<uint4 *>(d) = make_uint4(a0.x, a0.y, b0.x, b0.y);
+        *reinterpret_cast<uint4 *>(d + 64) = make_uint4(a1.x, a1.y, b1.x, b1.y);
+        *reinterpret_cast<uint4 *>(d + 128) = make_uint4(a2.x, a2.y, b2.x, b2.y);
+    }
+}
+
+// pre-split weights [rows = K * taps][CC][3][32] -> per image [N][rows][CC][3][32] with the channel order of that image
+__global__ __launch_bounds__(256) void w3_pack_per_image_kernel(const unsigned short *__restrict__ w3, unsigned short *__restrict__ out,
+                                                                long rows, int CC, int N, const int *__restrict__ order,
+                                                                const int *__restrict__ cc_limit) {
+    const long units = (long)N * rows * CC * 4;  // 8 packed channels x 3 parts
+    for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (long)gridDim.x * blockDim.x) {
+        const int oct = (int)(u & 3);
+        long rc = u >> 2;
+        const int cc = (int)(rc % CC);
+        rc /= CC;
+        const long row = rc % rows;
+        const int n = (int)(rc / rows);
+        if (cc >= cc_limit[n]) continue;
+        const int *o = order + ((long)n * CC + cc) * 32 + oct * 8;
+        const unsigned short *src = w3 + row * CC * 96;
+        unsigned short v[3][8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = o[e];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) v[pl][e] = c >= 0 ? src[(c >> 5) * 96 + pl * 32 + (c & 31)] : (unsigned short)0;
+        }
+        unsigned short *d = out + (((long)n * rows + row) * CC + cc) * 96 + oct * 8;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            *reinterpret_cast<uint4 *>(d + pl * 32) = make_uint4(v[pl][0] | ((unsigned)v[pl][1] << 16), v[pl][2] | ((unsigned)v[pl][3] << 16),
+                                                                 v[pl][4] | ((unsigned)v[pl][5] << 16), v[pl][6] | ((unsigned)v[pl][7] << 16));
+    }
+}
+
+}  // namespace
+
+extern "C" int dass_dropout_compact(const float *mask, int N, int C, int *order, int *cc_limit, void *stream) {
+    if (!mask || !order || !cc_limit || N <= 0 || C <= 0) return DASS_ERR_ARG;
+    hipLaunchKernelGGL(dropout_compact_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, mask, C, (C + 31) / 32, order, cc_limit);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_split3_rows_packed(const float *x, int64_t ld, void *out, int64_t M, int C, const float *mask, const int *order,
+                                       const int *cc_limit, int64_t rows_per_image, void *stream) {
+    if (!x || !out || !mask || !order || !cc_limit || M <= 0 || C <= 0 || ld < C || rows_per_image <= 0) return DASS_ERR_ARG;
+    if (((uintptr_t)out & 15) || M % rows_per_image) return DASS_ERR_ARG;
+    const int CC = (C + 31) / 32;
+    if (CC * 4 > 256) return DASS_ERR_UNSUPPORTED;  // one thread per 8 packed channels of a row: C <= 2048
+    const long images = M / rows_per_image;
+    long chunks = (4096 + images - 1) / images;  // ~4096 blocks; at least 8 rows each
+    const long max_chunks = (rows_per_image + 7) / 8;
+    if (chunks > max_chunks) chunks = max_chunks;
+    hipLaunchKernelGGL(split3_rows_packed_kernel, dim3((unsigned)(images * chunks + 1)), dim3(256), 0, (hipStream_t)stream, x, (long)ld,
+                       (char *)out, (long)M, C, CC, mask, order, cc_limit, (long)rows_per_image, (int)chunks);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_w3_pack_per_image(const void *w3, void *out, int64_t rows, int C, int N, const int *order, const int *cc_limit,
+                                      void *stream) {
+    if (!w3 || !out || !order || !cc_limit || rows <= 0 || C <= 0 || N <= 0) return DASS_ERR_ARG;
+    if (((uintptr_t)out & 15) || ((uintptr_t)w3 & 1)) return DASS_ERR_ARG;
+    const int CC = (C + 31) / 32;
+    hipLaunchKernelGGL(w3_pack_per_image_kernel, dim3(dass_grid_1d((long)N * rows * CC * 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short *)w3, (unsigned short *)out, (long)rows, CC, N, order, cc_limit);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
 }

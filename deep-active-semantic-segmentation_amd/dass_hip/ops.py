@@ -20,7 +20,7 @@ F32, BF16, F32X3, F32X6 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 
 _state = {"dtype": torch.float32, "f32_mma": os.environ.get("DASS_F32_MMA", "bf16x6"),
-          "x3": os.environ.get("DASS_X3", "infer")}
+          "x3": os.environ.get("DASS_X3", "infer"), "mc_sparse": os.environ.get("DASS_MC_SPARSE", "1") != "0"}
 assert _state["x3"] in ("off", "infer", "all"), "DASS_X3 must be off, infer or all"
 assert _state["f32_mma"] in ("f32", "bf16x3", "bf16x6"), "DASS_F32_MMA must be f32, bf16x3 or bf16x6"
 
@@ -64,6 +64,17 @@ def set_x3_pipeline(mode):
     mode = {True: "all", False: "off"}.get(mode, mode)
     assert mode in ("off", "infer", "all")
     _state["x3"] = mode
+
+
+def set_mc_sparse(on):
+    """MC-dropout tail (pre-split engine): True (default, DASS_MC_SPARSE) skips the input channels the ASPP Dropout2d mask
+    zeroes instead of multiplying the zeros (dass_conv2d_x3_per_image); False runs the masked dense conv.  Both are the
+    same sum of the surviving products, accumulated in a different order."""
+    _state["mc_sparse"] = bool(on)
+
+
+def mc_sparse():
+    return _state.get("mc_sparse", True)
 
 
 def set_deterministic(on):
@@ -180,6 +191,41 @@ def conv_x3_launch(x3, w3, y, ldy, dims, y3=None, scale=None, shift=None, residu
                              r, s, stride, pad, dil, ustride, act, _p(stats), ctypes.byref(nrows) if stats is not None else None,
                              _p(ws), ws.numel(), _stream()), "dass_conv2d_x3")
     return nrows.value
+
+
+def dropout_pack(mask):
+    """Dropout2d mask [N, C] (0 / multiplier) -> (order int32 [N, ceil(C/32)*32], cc_limit int32 [N]) on the device"""
+    n, c = mask.shape
+    cc = (c + 31) // 32
+    order = torch.empty((n, cc * 32), dtype=torch.int32, device=mask.device)
+    lim = torch.empty((n,), dtype=torch.int32, device=mask.device)
+    check(lib.dass_dropout_compact(_p(mask), n, c, _p(order), _p(lim), _stream()), "dass_dropout_compact")
+    return order, lim
+
+
+def split3_rows_packed(x, ld, m, c, mask, order, lim, rows_per_image):
+    """x3 rows of the surviving channels (packed per image, multiplied by the mask); slabs beyond lim[n] stay unwritten"""
+    out = x3_alloc(m, c, x.device)
+    check(lib.dass_split3_rows_packed(_p(x), ld, _p(out), m, c, _p(mask), _p(order), _p(lim), rows_per_image, _stream()),
+          "dass_split3_rows_packed")
+    return out
+
+
+def w3_pack_per_image(w3, rows, c, order, lim):
+    """pre-split weight operand -> one copy per image in that image's channel order"""
+    n = order.shape[0]
+    out = torch.empty((n * rows * ((c + 31) // 32) * 192,), dtype=torch.uint8, device=order.device)
+    check(lib.dass_w3_pack_per_image(_p(w3), _p(out), rows, c, n, _p(order), _p(lim), _stream()), "dass_w3_pack_per_image")
+    return out
+
+
+def conv_x3_per_image_launch(x3, w3n, lim, y, ldy, dims, y3=None, scale=None, shift=None, residual=None, ldr=0, act=ACT_NONE):
+    """dass_conv2d_x3_per_image: image n uses weight copy n over its first lim[n] channel slabs (Dropout2d-sparse conv)"""
+    n, h, w, c, oh, ow, k, r, s, stride, pad, dil = dims
+    ws = _x3_workspace(x3.device)
+    check(lib.dass_conv2d_x3_per_image(_p(x3), _p(w3n), _p(lim), _p(y), ldy, _p(y3), _p(scale), _p(shift), _p(residual), ldr,
+                                       n, h, w, c, oh, ow, k, r, s, stride, pad, dil, act, _p(ws), ws.numel(), _stream()),
+          "dass_conv2d_x3_per_image")
 
 
 _x3_ws = {}

@@ -98,10 +98,22 @@ class Decoder(nn.Module):
         if ops.x3_pipeline():
             # pre-split engine: the ASPP mask rides in the conversion pass of the 256 masked channels (exact: the
             # multipliers are 0 and 2), the first conv hands its result to the second as x3 rows (no f32 round trip)
+            # A channel the mask drops contributes exact zeros: the survivors of every image are packed to the front
+            # (operand rows and a per-image copy of the weights alike) and the reduction stops after them -- about half
+            # of this conv's multiplications are never issued.
             m = n * h * w
-            xa3 = ops.split3_rows(xa, lda, m, 256, nc_scale=m1.contiguous(), rows_per_image=h * w)
+            m1 = m1.contiguous()
             h1_3 = ops.x3_alloc(m, 256, feats.device)
-            ops.conv_x3_launch(xa3, wa, None, 0, dims, y3=h1_3, scale=st.scale, shift=st.shift, residual=yb, ldr=256, act=ops.ACT_RELU)
+            if ops.mc_sparse():
+                order, lim = ops.dropout_pack(m1)
+                xa3 = ops.split3_rows_packed(xa, lda, m, 256, m1, order, lim, h * w)
+                wan = ops.w3_pack_per_image(wa, 256 * 9, 256, order, lim)
+                ops.conv_x3_per_image_launch(xa3, wan, lim, None, 0, dims, y3=h1_3, scale=st.scale, shift=st.shift, residual=yb,
+                                             ldr=256, act=ops.ACT_RELU)
+            else:
+                xa3 = ops.split3_rows(xa, lda, m, 256, nc_scale=m1, rows_per_image=h * w)
+                ops.conv_x3_launch(xa3, wa, None, 0, dims, y3=h1_3, scale=st.scale, shift=st.shift, residual=yb, ldr=256,
+                                   act=ops.ACT_RELU)
             st2 = ops.bn_eval_state(lc[4], 256, feats.device)
             h2 = ops.new_act(n, 256, h, w, torch.float32, feats.device)
             ops.conv_x3_launch(h1_3, ops.weight_operand(lc[3].weight, 0, torch.float32, cpad=256), h2, 256, dims,

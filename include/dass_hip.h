@@ -318,7 +318,8 @@ int dass_sgd_step_multi(void *const *p, const void *const *g, void *const *buf, 
  * nc_scale[m / rows_per_image][c] first (Dropout2d mask of the producer, aspp.py:89 / decoder.py:35). */
 int64_t dass_x3_bytes(int64_t rows, int C);
 /* tuning / test knob: tile + 10 * mode.  tile 0 = the dispatcher's choice, 1..7 = force one tile variant of
- * dass_conv2d_x3 (csrc/conv_x3.hip); mode 0 = auto, 1 = one output tile per workgroup, 2 = stream-K slab ranges */
+ * dass_conv2d_x3 (csrc/conv_x3.hip); mode 0 = auto, 1 = one output tile per workgroup, 2 = stream-K (whole rounds of
+ * tiles one per workgroup + the remainder as equal slab ranges), 3 = stream-K slab ranges over all tiles */
 int dass_x3_force_tile(int tile);
 /* bytes of scratch dass_conv2d_x3 wants for its stream-K schedule (partial tiles of split output tiles) */
 int64_t dass_conv2d_x3_workspace_bytes(void);
@@ -337,6 +338,26 @@ int dass_conv2d_x3(const void *x3, const void *w3, void *y, int64_t ldy, void *y
                    const float *shift, const void *residual, int64_t ldr, int N, int H, int W, int C, int OH, int OW,
                    int K, int R, int S, int stride, int pad, int dil, int ustride, int act, float *stat_partial,
                    int *stat_rows, void *workspace, int64_t workspace_bytes, void *stream);
+/* Dropout2d-sparse form of the same conv for the MC-dropout tail (active_selection/mc_dropout.py:38-51: T stochastic
+ * passes through models/decoder.py:23-36 with the ASPP Dropout2d(0.5) of models/aspp.py:89 active).  A dropped input
+ * channel contributes exact zeros, so instead of multiplying zeros the surviving channels of every image are packed to the
+ * front and the reduction stops after them:
+ *   dass_dropout_compact     mask [N][C] (0 = dropped, else the multiplier 1/(1-p)) -> order [N][ceil(C/32)*32] (surviving
+ *                            channel indices ascending, then -1) and cc_limit[N] (32-channel slabs that hold a survivor);
+ *   dass_split3_rows_packed  f32 rows -> x3 rows whose channel j of image n is x[.., order[n][j]] * mask[n][order[n][j]];
+ *   dass_w3_pack_per_image   pre-split weights [rows = K*R*S][ceil(C/32)][192 B] -> N copies [N][rows][..] in image n's order;
+ *   dass_conv2d_x3_per_image image n multiplies with ITS weight copy over its first cc_limit[n] slabs; output tiles never
+ *                            straddle two images.  Everything stays on the device (no host read of the mask).
+ * The packed result differs from the masked dense one only in the order the surviving products are accumulated. */
+int dass_dropout_compact(const float *mask, int N, int C, int *order, int *cc_limit, void *stream);
+int dass_split3_rows_packed(const float *x, int64_t ld, void *out, int64_t M, int C, const float *mask, const int *order,
+                            const int *cc_limit, int64_t rows_per_image, void *stream);
+int dass_w3_pack_per_image(const void *w3, void *out, int64_t rows, int C, int N, const int *order, const int *cc_limit,
+                           void *stream);
+int dass_conv2d_x3_per_image(const void *x3, const void *w3, const int *cc_limit, void *y, int64_t ldy, void *y3,
+                             const float *scale, const float *shift, const void *residual, int64_t ldr, int N, int H,
+                             int W, int C, int OH, int OW, int K, int R, int S, int stride, int pad, int dil, int act,
+                             void *workspace, int64_t workspace_bytes, void *stream);
 /* Weight gradients are accumulated over several pixel splits per tile with f32 atomics (fast, but the last bits depend on
  * arrival order).  dass_set_deterministic(1) makes every weight-gradient launch use ONE split per tile: each dW element is
  * summed by one workgroup in a fixed order -> bit-reproducible (slower on layers with few output tiles). */

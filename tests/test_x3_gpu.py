@@ -225,3 +225,90 @@ def test_x3_wgrad_vs_f64(case):
     check(lib.dass_conv2d_wgrad_x3(ops._p(x3), ops._p(dy3), ops._p(dw), n, h, wd, c, oh, ow, k, ks, ks, stride, pad, dil, 0, ops._stream()),
           "dass_conv2d_wgrad_x3")
     assert _rel(dw, 2 * ref) <= 4e-6
+
+
+@pytest.mark.parametrize("with_stats", [False, True])
+@pytest.mark.parametrize("code", [24, 26, 21, 11])
+def test_x3_stream_k_hybrid_rounds_plus_remainder(code, with_stats):
+    """more output tiles than resident workgroups: whole rounds run one tile per workgroup, only the remainder is cut into
+    slab ranges and fixed up.  (2, 64, 129, 129) -> 128 channels: 1042 tiles of 64 x 64 on 768 / 512 slots (codes 24 / 26),
+    131 tiles of 256 x 128 (pure stream-K, code 21).  The x3 output rides along; with BN partial sums requested every
+    tile of the stream-K region is fixed up by one block (no whole-round part)."""
+    from dass_hip import ops
+    from dass_hip._lib import lib
+
+    case = (2, 64, 129, 129, 128, 3, 1, 1, 1)
+    n, c, h, wd, k, ks, stride, pad, dil = case
+    x, w = _inputs(case)
+    x3, w3 = _x3_of(ops, x), ops.prepare_conv_weight(w.permute(0, 2, 3, 1).contiguous().cuda())
+    dims = (n, h, wd, c, h, wd, k, ks, ks, stride, pad, dil)
+    ref = F.conv2d(x.double().cuda(), w.double().cuda(), None, stride, pad, dil).permute(0, 2, 3, 1)
+    m = n * h * wd
+    outs = []
+    for _ in range(2):
+        lib.dass_x3_force_tile(code)
+        y = torch.full((n, h, wd, k), float("nan"), device="cuda")
+        y3 = ops.x3_alloc(m, k, "cuda")
+        stats = torch.full((lib.dass_conv2d_igemm_stats_rows(m), 2, k), float("nan"), device="cuda")
+        rows = ops.conv_x3_launch(x3, w3, y, k, dims, y3=y3, stats=stats if with_stats else None)
+        outs.append((y, stats[:rows].clone(), y3))
+    y, st, y3 = outs[0]
+    assert torch.equal(y, outs[1][0]) and torch.equal(st, outs[1][1])
+    assert (y.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    assert _rel(y, ref.cpu()) <= 2e-6
+    flat = ref.reshape(m, k)
+    if with_stats:
+        assert (st[:, 0].double().sum(0) - flat.sum(0)).abs().max().item() <= 1e-4 * flat.abs().sum(0).max().item()
+        assert (st[:, 1].double().sum(0) - (flat * flat).sum(0)).abs().max().item() <= 1e-5 * (flat * flat).sum(0).max().item()
+    dec, zero = _decode_x3(y3, m, k)
+    assert torch.equal(dec, y.reshape(m, k)) and not zero.any()
+
+
+@pytest.mark.parametrize("code", [0, 11, 14, 21, 24])
+def test_x3_per_image_dropout_sparse_conv(code):
+    """dass_conv2d_x3_per_image (+ dass_dropout_compact / dass_split3_rows_packed / dass_w3_pack_per_image): the conv of a
+    Dropout2d-masked input with the dropped channels skipped, against the f64 conv of the masked tensor.  Images with all,
+    half, three and none of the channels kept; 17 x 19 maps so image boundaries fall inside what would be one tile."""
+    from dass_hip import ops
+    from dass_hip._lib import lib
+
+    n, c, h, wd, k = 5, 256, 17, 19, 96
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, c, h, wd, generator=g)
+    w = torch.randn(k, c, 3, 3, generator=g) * (2.0 / (c * 9)) ** 0.5
+    mask = (torch.rand(n, c, generator=g) < 0.5).float() * 2.0
+    mask[0] = 2.0
+    mask[2] = 0.0
+    mask[2, [7, 100, 255]] = 2.0
+    mask[3] = 0.0
+    res = torch.randn(n, h, wd, k, generator=g)
+    scale, shift = torch.rand(k, generator=g) + 0.5, torch.randn(k, generator=g)
+    ref = F.conv2d((x * mask[:, :, None, None]).double(), w.double(), None, 1, 1, 1).permute(0, 2, 3, 1)
+    ref = torch.relu(ref * scale.double() + shift.double() + res.double())
+
+    lib.dass_x3_force_tile(code)
+    xr = x.permute(0, 2, 3, 1).contiguous().cuda()
+    mk = mask.cuda()
+    order, lim = ops.dropout_pack(mk)
+    kept = [int((mask[i] != 0).sum()) for i in range(n)]
+    assert lim.tolist() == [(v + 31) // 32 for v in kept]
+    for i in range(n):
+        assert order[i, :kept[i]].tolist() == torch.nonzero(mask[i]).flatten().tolist() and (order[i, kept[i]:] == -1).all()
+    m = n * h * wd
+    x3 = ops.split3_rows_packed(xr, c, m, c, mk, order, lim, h * wd)
+    w3 = ops.prepare_conv_weight(w.permute(0, 2, 3, 1).contiguous().cuda())
+    w3n = ops.w3_pack_per_image(w3, k * 9, c, order, lim)
+    y = torch.full((n, h, wd, k), float("nan"), device="cuda")
+    y3 = ops.x3_alloc(m, k, "cuda")
+    ops.conv_x3_per_image_launch(x3, w3n, lim, y, k, (n, h, wd, c, h, wd, k, 3, 3, 1, 1, 1), y3=y3, scale=scale.cuda(),
+                                 shift=shift.cuda(), residual=res.cuda(), ldr=k, act=ops.ACT_RELU)
+    assert (y.double().cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item(), code
+    assert _rel(y, ref) <= 2e-6
+    dec, zero = _decode_x3(y3, m, k)
+    assert torch.equal(dec, y.reshape(m, k)) and not zero.any()
+    # the masked dense conv is the same sum in another order
+    xd3 = ops.split3_rows(xr, c, m, c, nc_scale=mk, rows_per_image=h * wd)
+    yd = torch.empty_like(y)
+    ops.conv_x3_launch(xd3, w3, yd, k, (n, h, wd, c, h, wd, k, 3, 3, 1, 1, 1), scale=scale.cuda(), shift=shift.cuda(),
+                       residual=res.cuda(), ldr=k, act=ops.ACT_RELU)
+    assert (y - yd).abs().max().item() <= 1e-5 * ref.abs().max().item()
