@@ -702,12 +702,19 @@ class _ConvBnAct(torch.autograd.Function):
                                   state.invstd if state is not None else None,
                                   state.scale if state is not None else None,
                                   state.shift if state is not None else None, x3_saved)
+        if getattr(spec, "fork", False):
+            # the input is handed back as a second output: the gradients of both uses of x (this conv and the
+            # identity branch of a residual block) then arrive in ONE backward call, where the input-gradient conv adds
+            # the identity gradient in its epilogue instead of autograd running a separate add pass over the tensor
+            return out, x
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, d_fork=None):
         xs, weight, gamma, y_raw, out, nc_scale, mean, invstd, bn_scale, bn_shift, x3_in = ctx.saved_tensors
         spec = ctx.spec
+        if dout is None:  # only the forked alias of the input was used downstream
+            return d_fork, None, None, None, None, None, None, None, None
         n, h, w, c, oh, ow, k, ldx, ldo, c_in = ctx.dims
         dt = out.dtype
         dev = out.device
@@ -838,12 +845,21 @@ class _ConvBnAct(torch.autograd.Function):
                 w_t = weight_operand(wsrc, 1, dt) if wsrc is weight else _dgrad_operand_uncached(wsrc, dt)
                 dx = new_act(n, c, h, w, dt, dev)
                 pad_t = spec.dil * (r - 1) - spec.pad
+                # forked input: its other gradient rides in as the epilogue's residual (stride-1 launches)
+                add_t = add_ld = None
+                if d_fork is not None and spec.stride == 1 and d_fork.dtype == dx.dtype:
+                    add_t, add_ld = rows(d_fork)
+                    if add_ld % 4 != 0:
+                        add_t = None
+                    else:
+                        d_fork = None
                 # dgrad = stride-1 conv over dy with flipped/transposed taps; ustride re-inserts the stride
                 if ctx.x3_on and dt == torch.float32 and c > 32 and kk == k and lddy % 4 == 0:
                     dy3 = x3_operand(dy, dy, lddy, m, kk)
-                    conv_x3_launch(dy3, w_t, dx, c, (n, oh, ow, kk, h, w, c, r, s, 1, pad_t, spec.dil), ustride=spec.stride)
+                    conv_x3_launch(dy3, w_t, dx, c, (n, oh, ow, kk, h, w, c, r, s, 1, pad_t, spec.dil), ustride=spec.stride,
+                                   residual=add_t, ldr=add_ld or 0)
                 else:
-                    check(lib.dass_conv2d_igemm(_p(dy), lddy, _p(w_t), _p(dx), c, None, None, None, 0, None, n, oh, ow,
+                    check(lib.dass_conv2d_igemm(_p(dy), lddy, _p(w_t), _p(dx), c, None, None, _p(add_t), add_ld or 0, None, n, oh, ow,
                                                 kk, h, w, c, r, s, 1, pad_t, spec.dil, spec.stride, ACT_NONE, _cdt(dx),
                                                 _stream()), "dass_conv2d_igemm(dgrad)")
             if ctx.needs_input_grad[1] and getattr(spec, "rowtap", False):
@@ -859,6 +875,8 @@ class _ConvBnAct(torch.autograd.Function):
                     dw = dw.contiguous(memory_format=torch.channels_last)
         if dx is not None and ctx.x_dtype != dx.dtype:
             dx = dx.to(ctx.x_dtype)
+        if d_fork is not None and ctx.needs_input_grad[0]:  # not folded into the launch above
+            dx = d_fork if dx is None else dx + d_fork.to(dx.dtype)
         return dx, dw, dgamma, dbeta, dbias, dres, None, None, None
 
 
@@ -917,11 +935,16 @@ def _dgrad_operand_uncached(wsrc, dtype):
 
 
 def conv_bn_act(x, conv, bn=None, act=ACT_NONE, residual=None, nc_scale=None, extra_pad=0, image_input=False,
-                in_scale=None, emit_x3=True):
+                in_scale=None, emit_x3=True, fork=False):
     """in_scale: [N,C] f32 multipliers applied to the INPUT while it is staged (inference only): a
-    Dropout2d mask of the producer folded into this conv's loader (MC-dropout tail, SURVEY 8a note iii)."""
+    Dropout2d mask of the producer folded into this conv's loader (MC-dropout tail, SURVEY 8a note iii).
+    fork=True -> (out, x'): x' is x again, to be used for the OTHER consumer of x (the identity branch of a residual
+    block): both gradients of x then meet in this op's backward and are summed inside the input-gradient launch."""
     spec = ConvSpec(conv, bn, act, extra_pad)
     spec.grad_enabled = torch.is_grad_enabled()
+    spec.fork = bool(fork) and spec.grad_enabled and x.requires_grad
+    if fork and not spec.fork:
+        return conv_bn_act(x, conv, bn, act, residual, nc_scale, extra_pad, image_input, in_scale, emit_x3), x
     spec.emit_x3 = emit_x3  # False where the consumer is not a dense conv (concat / pool / upsample / classifier)
     if in_scale is not None:
         assert bn is None or not bn_use_batch_stats(bn), "in_scale needs eval-mode BN"

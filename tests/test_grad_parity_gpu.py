@@ -50,7 +50,8 @@ class _GateReplay(object):
         def wrapped(x, conv, bn=None, act=ops.ACT_NONE, **kw):
             out = rec._orig_cba(x, conv, bn, act, **kw)
             if act == ops.ACT_RELU:
-                rec.gates.append((out.detach() > 0).cpu())
+                first = out[0] if isinstance(out, tuple) else out  # fork=True: (out, the input again)
+                rec.gates.append((first.detach() > 0).cpu())
             return out
 
         ops.conv_bn_act = wrapped
