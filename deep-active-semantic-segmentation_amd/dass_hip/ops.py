@@ -20,8 +20,8 @@ F32, BF16, F32X3, F32X6 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 
 _state = {"dtype": torch.float32, "f32_mma": os.environ.get("DASS_F32_MMA", "bf16x6"),
-          "x3": os.environ.get("DASS_X3", "infer"), "mc_sparse": os.environ.get("DASS_MC_SPARSE", "1") != "0"}
-assert _state["x3"] in ("off", "infer", "all"), "DASS_X3 must be off, infer or all"
+          "x3": os.environ.get("DASS_X3", "select"), "mc_sparse": os.environ.get("DASS_MC_SPARSE", "1") != "0"}
+assert _state["x3"] in ("off", "infer", "select", "all"), "DASS_X3 must be off, infer, select or all"
 assert _state["f32_mma"] in ("f32", "bf16x3", "bf16x6"), "DASS_F32_MMA must be f32, bf16x3 or bf16x6"
 
 
@@ -56,13 +56,17 @@ def set_x3_pipeline(mode):
     """bf16x6 engine only -- where the dense convs run the pipelined pre-split kernels (csrc/conv_x3.hip, wgrad_x3.hip:
     activations converted ONCE to three bf16 parts by the producing pass, LDS-DMA ring, no conversion in the MFMA loop)
     instead of the classic kernel that converts inside its loop (csrc/conv_igemm.hip):
-      "infer" (default, DASS_X3) forward passes without autograd (pool scoring, validation): measured +8..25 % there;
-      "all"   training too (forward, input and weight gradients; the BN passes then also write split rows): measured
-              no faster than the classic engine on the R101 train step (DESIGN.md 5), offered for experiments;
-      "off"   never.
+      "infer"  forward passes without autograd (pool scoring, validation): measured +8..25 % there;
+      "select" (default, DASS_X3) "infer" + in training the forward and input-gradient launches of the 3x3 convs that
+               reduce over >= 256 channels (layer-3/4 conv2, ASPP branches, decoder): there the one conversion pass
+               (dass_split3_rows; the gradient's split rows come out of the BN-backward pass) costs a few percent of
+               the conv it speeds up by 15..40 %; every other layer and all weight gradients stay on the classic kernels;
+      "all"    every dense conv in training too (forward, input and weight gradients; the BN passes then also write
+               split rows): measured no faster than the classic engine on the R101 train step (DESIGN.md 5);
+      "off"    never.
     Same six products in the same order either way: results agree to the last bit or two."""
     mode = {True: "all", False: "off"}.get(mode, mode)
-    assert mode in ("off", "infer", "all")
+    assert mode in ("off", "infer", "select", "all")
     _state["x3"] = mode
 
 
@@ -91,7 +95,14 @@ def x3_pipeline(training=False):
     """is the pre-split engine on for an inference call site (training=False) / for a call that records autograd"""
     if _state["f32_mma"] != "bf16x6":
         return False
-    return _state["x3"] == "all" or (_state["x3"] == "infer" and not training)
+    return _state["x3"] == "all" or (_state["x3"] in ("infer", "select") and not training)
+
+
+def _x3_train_layer(taps, red_channels):
+    """training launches that go to the pre-split engine: all of them ("all") or the long 3x3 reductions ("select")"""
+    if _state["f32_mma"] != "bf16x6":
+        return False
+    return _state["x3"] == "all" or (_state["x3"] == "select" and taps >= 9 and red_channels >= 256)
 
 
 def _cdt(t):
@@ -608,8 +619,10 @@ class _ConvBnAct(torch.autograd.Function):
         batch_stats = bn is not None and bn_use_batch_stats(bn)
         fuse = (not spec.depthwise) and (not rowtap) and (bn is None or (not batch_stats and not need_grad))
         # pipelined pre-split engine: dense convs of the bf16x6 engine with enough output channels for its tiles
-        x3_on = x3_pipeline(training=need_grad)
-        use_x3 = (x3_on and dt == torch.float32 and not spec.depthwise and not rowtap and not image_input and k > 32)
+        taps = r * weight.shape[3]
+        x3_on = x3_pipeline(training=need_grad)  # the whole network runs pre-split: producers hand split rows on
+        x3_fwd = x3_on or (need_grad and _x3_train_layer(taps, c))
+        use_x3 = (x3_fwd and dt == torch.float32 and not spec.depthwise and not rowtap and not image_input and k > 32)
         dims = (n, h, w, c, oh, ow, k, r, weight.shape[3], spec.stride, spec.pad, spec.dil)
         if fuse and use_x3:
             scale = shift = None
@@ -653,7 +666,7 @@ class _ConvBnAct(torch.autograd.Function):
             fused_stats = None
             if use_x3:
                 x3 = x3_operand(x, xs, ldx, n * h * w, c)
-                x3_saved = x3
+                x3_saved = x3 if x3_on else None  # "select": the weight gradient stays on the classic kernel (f32 rows)
                 w_op = weight_operand(weight, 0, dt, cpad=c)
                 partial = None
                 if batch_stats:
@@ -689,6 +702,7 @@ class _ConvBnAct(torch.autograd.Function):
         if need_grad:
             ctx.spec = spec
             ctx.x3_on = x3_on
+            ctx.x3_dgrad = x3_on or _x3_train_layer(taps, k)  # the input gradient reduces over k x taps
             ctx.image_input = image_input
             ctx.dims = (n, h, w, c, oh, ow, k, ldx, ldo, c_in)
             ctx.train_stats = batch_stats
@@ -780,8 +794,9 @@ class _ConvBnAct(torch.autograd.Function):
                     dbeta, dgamma = db.clone(), dg.clone()
                     _allreduce_bn_grads(sums, ctx.sync_world)
             dy3 = None
-            if (ctx.x3_on and dt == torch.float32 and not spec.depthwise and not ctx.image_input and k >= 32
-                    and ((ctx.needs_input_grad[0] and c > 32) or (ctx.needs_input_grad[1] and x3_in is not None))):
+            if (dt == torch.float32 and not spec.depthwise and not ctx.image_input and k >= 32
+                    and ((ctx.x3_dgrad and ctx.needs_input_grad[0] and c > 32)
+                         or (ctx.x3_on and ctx.needs_input_grad[1] and x3_in is not None))):
                 dy3 = x3_alloc_for(m, k, dev)  # dy also as split rows: operand of the input- and weight-gradient launches
             if gate:
                 check(lib.dass_bn_bwd_apply_gate(_p(dout_r), lddo, _p(y_raw), k, _p(mean_v), _p(invstd_v), _p(gamma_v.detach()), _p(db), _p(dg),
@@ -854,7 +869,7 @@ class _ConvBnAct(torch.autograd.Function):
                     else:
                         d_fork = None
                 # dgrad = stride-1 conv over dy with flipped/transposed taps; ustride re-inserts the stride
-                if ctx.x3_on and dt == torch.float32 and c > 32 and kk == k and lddy % 4 == 0:
+                if ctx.x3_dgrad and dt == torch.float32 and c > 32 and kk == k and lddy % 4 == 0:
                     dy3 = x3_operand(dy, dy, lddy, m, kk)
                     conv_x3_launch(dy3, w_t, dx, c, (n, oh, ow, kk, h, w, c, r, s, 1, pad_t, spec.dil), ustride=spec.stride,
                                    residual=add_t, ldr=add_ld or 0)

@@ -252,13 +252,14 @@ def test_config_b_r101_769_forward_and_mc_dropout():
     x, lab = O.synthetic_batch(n, hw, hw, 19, first_index=30)
     xd = x.cuda()
     outs = {}
+    keep = ops._state["x3"]
     try:
         for mode in ("infer", "off"):
             ops.set_x3_pipeline(mode)
             with torch.no_grad():
                 outs[mode] = pm(xd).float()
     finally:
-        ops.set_x3_pipeline("infer")
+        ops.set_x3_pipeline(keep)
     a, b = outs["infer"], outs["off"]
     assert a.shape == (n, 19, hw, hw) and torch.isfinite(a).all()
     scale = a.abs().max().item()
