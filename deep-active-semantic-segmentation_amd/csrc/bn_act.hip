@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void colstat_kernel(const T *__restrict__ x, l
                                                       const float *__restrict__ nc_scale, long M, int K,
                                                       long rows_per_image, int act, float *__restrict__ partial,
                                                       const float *__restrict__ gate_scale = nullptr,
-                                                      const float *__restrict__ gate_shift = nullptr) {
+                                                      const float *__restrict__ gate_shift = nullptr,
+                                                      double *__restrict__ sums = nullptr) {
     __shared__ float red[2][16][64 + 1];
     const int tid = threadIdx.x;
     const int cx = tid & 15, ry = tid >> 4;
@@ -75,7 +76,11 @@ __global__ __launch_bounds__(256) void colstat_kernel(const T *__restrict__ x, l
 #pragma unroll
         for (int i = 0; i < 16; ++i) a += red[which][i][c];
         const int kk = blockIdx.y * 64 + c;
-        if (kk < K) partial[((long)blockIdx.x * 2 + which) * K + kk] = a;
+        if (kk < K) {
+            // sums: [2][K] f64 accumulators shared by all slabs (hardware f64 atomics) -- no partial rows, no finalize launch
+            if (sums) unsafeAtomicAdd(sums + (long)which * K + kk, (double)a);
+            else partial[((long)blockIdx.x * 2 + which) * K + kk] = a;
+        }
     }
 }
 
@@ -190,6 +195,68 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const T *__restric
     }
 }
 
+// Train-mode BatchNorm apply straight from the f64 channel sums the producing conv accumulated (dass_conv2d_igemm_sums /
+// dass_conv2d_x3_sums / dass_channel_sums): every block derives the K scale / shift pairs into LDS (f64, as the finalize
+// kernel does), block 0 also stores mean / invstd / scale / shift for the backward and updates the running statistics --
+// the separate finalize launch of every BN layer is gone.  Loop body = scale_shift_act_kernel.
+constexpr int BN_KMAX = 2048;
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_train_kernel(const T *__restrict__ x, long ldx, T *__restrict__ out, long ldo,
+                                                             const double *__restrict__ sums, double count, const float *gamma,
+                                                             const float *beta, float *running_mean, float *running_var,
+                                                             float momentum, float eps, float *mean, float *invstd, float *scale_o,
+                                                             float *shift_o, const T *__restrict__ res, long ldr,
+                                                             const float *__restrict__ nc_scale, long M, int K, long rows_per_image,
+                                                             int act, char *__restrict__ out3) {
+    __shared__ __attribute__((aligned(16))) float s_scale[BN_KMAX];
+    __shared__ __attribute__((aligned(16))) float s_shift[BN_KMAX];
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const double mu = sums[k] / count;
+        double var = sums[K + k] / count - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const double is = 1.0 / sqrt(var + (double)eps);
+        const float g = gamma ? gamma[k] : 1.f, b = beta ? beta[k] : 0.f;
+        const float sc = (float)((double)g * is), sh = (float)((double)b - mu * (double)g * is);
+        s_scale[k] = sc;
+        s_shift[k] = sh;
+        if (blockIdx.x == 0) {
+            mean[k] = (float)mu;
+            invstd[k] = (float)is;
+            scale_o[k] = sc;
+            shift_o[k] = sh;
+            if (momentum >= 0.f && running_mean && running_var) {
+                const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+                running_mean[k] = (1.f - momentum) * running_mean[k] + momentum * (float)mu;
+                running_var[k] = (1.f - momentum) * running_var[k] + momentum * (float)unb;
+            }
+        }
+    }
+    __syncthreads();
+    if (out3 && blockIdx.x == 0) x3_zero_row(out3, M, (K + 31) >> 5);
+    const int cc3 = (K + 31) >> 5;
+    const int kv = K >> 2;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long dm = stride / kv;
+    const int dk = (int)(stride - dm * kv);
+    long m = i0 / kv;
+    int kq = (int)(i0 - m * kv);
+    for (; m < M; m += dm, kq += dk) {
+        if (kq >= kv) {
+            kq -= kv;
+            if (++m >= M) break;
+        }
+        const int k = kq << 2;
+        f32x4 v = bn_affine(ld4<T>(x + m * ldx + k), *reinterpret_cast<const f32x4 *>(s_scale + k), *reinterpret_cast<const f32x4 *>(s_shift + k));
+        if (res) v += ld4<T>(res + m * ldr + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
+        if (nc_scale) v *= *reinterpret_cast<const f32x4 *>(nc_scale + (m / rows_per_image) * K + k);
+        if (out) st4<T>(out + m * ldo + k, v);
+        if (out3) x3_store4(out3, m, cc3, k, v);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__ dout, long lddo,
                                                            const T *__restrict__ out, long ldo,
@@ -204,8 +271,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
                                                            long rows_per_image, float inv_count, int train, int act,
                                                            const float *__restrict__ gate_scale = nullptr,
                                                            const float *__restrict__ gate_shift = nullptr,
-                                                           char *__restrict__ dx3 = nullptr) {
+                                                           char *__restrict__ dx3 = nullptr,
+                                                           const double *__restrict__ sums = nullptr,
+                                                           float *__restrict__ dbeta_out = nullptr,
+                                                           float *__restrict__ dgamma_out = nullptr) {
     if (dx3 && blockIdx.x == 0) x3_zero_row(dx3, M, (K + 31) >> 5);
+    if (sums && blockIdx.x == 0)  // the f64 sums of dass_bn_bwd_reduce_sums, rounded once: the parameter gradients
+        for (int k = threadIdx.x; k < K; k += blockDim.x) {
+            if (dbeta_out) dbeta_out[k] = (float)sums[k];
+            if (dgamma_out) dgamma_out[k] = (float)sums[K + k];
+        }
     const int cc3 = (K + 31) >> 5;
     const int kv = K >> 2;
     const long stride = (long)gridDim.x * blockDim.x;
@@ -237,8 +312,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
             if (train) {
                 const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + k);
                 const f32x4 xh = (xin - mu) * is;
-                const f32x4 db = *reinterpret_cast<const f32x4 *>(dbeta + k);
-                const f32x4 dg = *reinterpret_cast<const f32x4 *>(dgamma + k);
+                f32x4 db, dg;
+                if (sums) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        db[e] = (float)sums[k + e];
+                        dg[e] = (float)sums[K + k + e];
+                    }
+                } else {
+                    db = *reinterpret_cast<const f32x4 *>(dbeta + k);
+                    dg = *reinterpret_cast<const f32x4 *>(dgamma + k);
+                }
                 r = g - (db + xh * dg) * inv_count;
             }
             const f32x4 dxv = r * (ga * is);
@@ -496,6 +580,103 @@ extern "C" int dass_colsum(const void *x, int64_t ldx, int64_t M, int K, float *
     if (rc != DASS_OK) return rc;
     hipLaunchKernelGGL(bwd_finalize_kernel, dim3((K + FIN_CH - 1) / FIN_CH), dim3(1024), 0, (hipStream_t)stream, partial,
                        dass_stat_rows(M), K, out, nullptr);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+// ---- train-mode BN without finalize launches: the statistics live in [2][K] f64 accumulators (zeroed by the caller) that
+// the producing kernels add to with hardware f64 atomics; the apply kernels read them directly.  Same arithmetic as the
+// partial-row path (f32 sums per tile / slab, f64 across them); only the order of the f64 additions is not fixed --
+// dass_set_deterministic callers keep the partial-row entry points.
+extern "C" int dass_channel_sums(const void *x, int64_t ldx, int64_t M, int K, double *sums, int dtype, void *stream) {
+    if (!x || !sums || M <= 0 || !ok4(K, ldx)) return DASS_ERR_ARG;
+    dim3 grid((unsigned)dass_stat_rows(M), (unsigned)((K + 63) / 64));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DASS_F32)
+        hipLaunchKernelGGL((colstat_kernel<float, 0>), grid, dim3(256), 0, st, (const float *)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr,
+                           nullptr, M, K, 1, 0, nullptr, nullptr, nullptr, sums);
+    else if (dtype == DASS_BF16)
+        hipLaunchKernelGGL((colstat_kernel<bf16_t, 0>), grid, dim3(256), 0, st, (const bf16_t *)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr,
+                           nullptr, M, K, 1, 0, nullptr, nullptr, nullptr, sums);
+    else
+        return DASS_ERR_UNSUPPORTED;
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+extern "C" int dass_bn_apply_train(const void *x, int64_t ldx, void *out, int64_t ldo, const double *sums, double count, const float *gamma,
+                                   const float *beta, float *running_mean, float *running_var, float momentum, float eps, float *mean,
+                                   float *invstd, float *scale, float *shift, const void *residual, int64_t ldr, const float *nc_scale,
+                                   int64_t M, int K, int64_t rows_per_image, int act, int dtype, void *out3, void *stream) {
+    if (!x || (!out && !out3) || !sums || count <= 0 || !mean || !invstd || !scale || !shift || M <= 0 ||
+        !ok4(K, ldx, out ? ldo : 4, residual ? ldr : 4) || rows_per_image <= 0)
+        return DASS_ERR_ARG;
+    if (K > BN_KMAX) return DASS_ERR_UNSUPPORTED;
+    if (out3 && (dtype != DASS_F32 || ((uintptr_t)out3 & 15))) return DASS_ERR_ARG;
+    const int grid = dass_grid_1d(M * (K / 4), 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DASS_F32)
+        hipLaunchKernelGGL(bn_apply_train_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, ldx, (float *)out, ldo, sums, count,
+                           gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, (const float *)residual, ldr,
+                           nc_scale, M, K, rows_per_image, act, (char *)out3);
+    else if (dtype == DASS_BF16)
+        hipLaunchKernelGGL(bn_apply_train_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)x, ldx, (bf16_t *)out, ldo, sums, count,
+                           gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, (const bf16_t *)residual, ldr,
+                           nc_scale, M, K, rows_per_image, act, (char *)nullptr);
+    else
+        return DASS_ERR_UNSUPPORTED;
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+// out == NULL: the activation gate is re-derived from x with gate_scale / gate_shift (f32 only), as dass_bn_bwd_reduce_gate
+extern "C" int dass_bn_bwd_reduce_sums(const void *dout, int64_t lddo, const void *out, int64_t ldo, const void *x, int64_t ldx,
+                                       const float *mean, const float *invstd, const float *gate_scale, const float *gate_shift,
+                                       const float *nc_scale, int64_t M, int K, int64_t rows_per_image, int act, double *sums, int dtype,
+                                       void *stream) {
+    if (!dout || !x || !mean || !invstd || !sums || M <= 0 || !ok4(K, lddo, out ? ldo : 4, ldx) || rows_per_image <= 0) return DASS_ERR_ARG;
+    if (!out && (!gate_scale || !gate_shift || dtype != DASS_F32)) return DASS_ERR_ARG;
+    dim3 grid((unsigned)dass_stat_rows(M), (unsigned)((K + 63) / 64));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DASS_F32)
+        hipLaunchKernelGGL((colstat_kernel<float, 1>), grid, dim3(256), 0, st, (const float *)x, ldx, (const float *)dout, lddo,
+                           (const float *)out, ldo, mean, invstd, nc_scale, M, K, rows_per_image, act, nullptr, gate_scale, gate_shift, sums);
+    else if (dtype == DASS_BF16)
+        hipLaunchKernelGGL((colstat_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t *)x, ldx, (const bf16_t *)dout, lddo,
+                           (const bf16_t *)out, ldo, mean, invstd, nc_scale, M, K, rows_per_image, act, nullptr, nullptr, nullptr, sums);
+    else
+        return DASS_ERR_UNSUPPORTED;
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+// train-mode dx (and dres) from the f64 sums; dbeta_out / dgamma_out receive the parameter gradients (f32)
+extern "C" int dass_bn_bwd_apply_sums(const void *dout, int64_t lddo, const void *out, int64_t ldo, const void *x, int64_t ldx,
+                                      const float *mean, const float *invstd, const float *gamma, const double *sums, float *dbeta_out,
+                                      float *dgamma_out, const float *gate_scale, const float *gate_shift, const float *nc_scale,
+                                      void *dx, int64_t lddx, void *dres, int64_t lddr, int64_t M, int K, int64_t rows_per_image,
+                                      double count, int act, int dtype, void *dx3, void *stream) {
+    if (!dout || !x || !dx || !mean || !invstd || !sums || count <= 0 || M <= 0 || !ok4(K, lddo, out ? ldo : 4, ldx, lddx) ||
+        rows_per_image <= 0)
+        return DASS_ERR_ARG;
+    if (!out && (!gate_scale || !gate_shift || dtype != DASS_F32)) return DASS_ERR_ARG;
+    if (dres && lddr % 4) return DASS_ERR_ARG;
+    if (dx3 && (dtype != DASS_F32 || ((uintptr_t)dx3 & 15))) return DASS_ERR_ARG;
+    const int grid = dass_grid_1d(M * (K / 4), 256);
+    const float inv_count = (float)(1.0 / count);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DASS_F32)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)dout, lddo, (const float *)out, ldo,
+                           (const float *)x, ldx, mean, invstd, gamma, (const float *)nullptr, (const float *)nullptr, nc_scale, (float *)dx,
+                           lddx, (float *)dres, lddr, M, K, rows_per_image, inv_count, 1, act, gate_scale, gate_shift, (char *)dx3, sums,
+                           dbeta_out, dgamma_out);
+    else if (dtype == DASS_BF16)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)dout, lddo, (const bf16_t *)out, ldo,
+                           (const bf16_t *)x, ldx, mean, invstd, gamma, (const float *)nullptr, (const float *)nullptr, nc_scale,
+                           (bf16_t *)dx, lddx, (bf16_t *)dres, lddr, M, K, rows_per_image, inv_count, 1, act, (const float *)nullptr,
+                           (const float *)nullptr, (char *)nullptr, sums, dbeta_out, dgamma_out);
+    else
+        return DASS_ERR_UNSUPPORTED;
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }

@@ -33,6 +33,7 @@ struct ConvP {
     const char *res;
     const float *in_scale;
     float *stat_partial;  // optional [mtiles][2][K]: per-tile column sums / sums of squares of the RAW output (train-mode BN)
+    double *stat_sums;    // or: [2][K] f64 accumulators every tile adds its column sums to (hardware f64 atomics)
     long ldx, ldy, ldr;
     long wk_stride;  // R*S*C
     int N, H, W, C, OH, OW, K, R, S, stride, pad, dil, ustride, act;
@@ -481,7 +482,7 @@ void conv_igemm_kernel(const ConvP p) {
     }
 #endif
 
-    if (p.stat_partial) {
+    if (p.stat_partial || p.stat_sums) {
         // BatchNorm batch statistics fused into the producer: per-channel sum and sum of squares of this tile's
         // rows straight from the accumulators (rows >= M hold zeros), one partial row per M-tile; the f64
         // finalize kernel reduces them.  Saves the separate read of the conv output.
@@ -511,7 +512,10 @@ void conv_igemm_kernel(const ConvP p) {
             float a = 0.f;
 #pragma unroll
             for (int q = 0; q < WM; ++q) a += red[(q * 2 + which) * BN + col];
-            if (n0 + col < p.K) p.stat_partial[((long)mt_i * 2 + which) * p.K + n0 + col] = a;
+            if (n0 + col < p.K) {
+                if (p.stat_sums) unsafeAtomicAdd(p.stat_sums + (long)which * p.K + n0 + col, (double)a);
+                else p.stat_partial[((long)mt_i * 2 + which) * p.K + n0 + col] = a;
+            }
         }
     }
 
@@ -1281,7 +1285,8 @@ static int run_conv(ConvP &p, int dtype, hipStream_t st) {
 static int conv_entry(const void *x, int64_t ldx, const void *w, void *y, int64_t ldy, const float *scale,
                       const float *shift, const void *residual, int64_t ldr, const float *in_scale, int N,
                       int H, int W, int C, int OH, int OW, int K, int R, int S, int stride, int pad,
-                      int dil, int ustride, int act, int dtype, void *stream, float *stat_partial, int *stat_rows) {
+                      int dil, int ustride, int act, int dtype, void *stream, float *stat_partial, int *stat_rows,
+                      double *stat_sums = nullptr) {
     if (!x || !w || !y) return DASS_ERR_ARG;
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || K <= 0 || R <= 0 || S <= 0) return DASS_ERR_ARG;
     if (R * S > 64 || stride < 1 || dil < 1 || ustride < 1) return DASS_ERR_ARG;
@@ -1298,6 +1303,7 @@ static int conv_entry(const void *x, int64_t ldx, const void *w, void *y, int64_
     p.res = (const char *)residual;
     p.in_scale = in_scale;
     p.stat_partial = stat_partial;
+    p.stat_sums = stat_sums;
     p.ldx = ldx;
     p.ldy = ldy;
     p.ldr = ldr;
@@ -1369,6 +1375,15 @@ extern "C" int dass_conv2d_igemm_stats(const void *x, int64_t ldx, const void *w
     if (!stat_partial || !stat_rows) return DASS_ERR_ARG;
     return conv_entry(x, ldx, w, y, ldy, nullptr, nullptr, nullptr, 0, nullptr, N, H, W, C, OH, OW, K, R, S, stride, pad, dil, 1,
                       DASS_ACT_NONE, dtype, stream, stat_partial, stat_rows);
+}
+
+/* the same conv with the batch statistics added into [2][K] f64 accumulators (zeroed by the caller): see dass_bn_apply_train */
+extern "C" int dass_conv2d_igemm_sums(const void *x, int64_t ldx, const void *w, void *y, int64_t ldy, int N, int H, int W, int C,
+                                      int OH, int OW, int K, int R, int S, int stride, int pad, int dil, int dtype, double *stat_sums,
+                                      void *stream) {
+    if (!stat_sums) return DASS_ERR_ARG;
+    return conv_entry(x, ldx, w, y, ldy, nullptr, nullptr, nullptr, 0, nullptr, N, H, W, C, OH, OW, K, R, S, stride, pad, dil, 1,
+                      DASS_ACT_NONE, dtype, stream, nullptr, nullptr, stat_sums);
 }
 
 static int wgrad_entry(const void *x, int64_t ldx, const void *dy, int64_t lddy, float *dw, int N, int H, int W, int C, int OH, int OW, int K, int R,
@@ -1447,7 +1462,7 @@ extern "C" int dass_conv2d_rowtap(const void *x, const void *w, void *y, int64_t
     if (R > 64 || S * Cin > 32 || stride < 1 || (long)N * OH * OW >= (1l << 31)) return DASS_ERR_ARG;
     ConvP p;
     p.x = (const char *)x; p.w = (const char *)w; p.y = (char *)y;
-    p.scale = nullptr; p.shift = nullptr; p.res = nullptr; p.in_scale = nullptr; p.stat_partial = nullptr;
+    p.scale = nullptr; p.shift = nullptr; p.res = nullptr; p.in_scale = nullptr; p.stat_partial = nullptr; p.stat_sums = nullptr;
     p.ldx = Cin; p.ldy = ldy; p.ldr = 0;
     p.wk_stride = (long)R * S * Cin;
     p.N = N; p.H = H; p.W = W; p.C = S * Cin; p.OH = OH; p.OW = OW; p.K = K; p.R = R; p.S = 1;

@@ -34,6 +34,7 @@ struct X3P {
     const float *shift;
     const char *res;
     float *stat_partial;
+    double *stat_sums;  // alternative to stat_partial: [2][K] f64 accumulators (hardware atomics), see dass_bn_apply_train
     float *ws;  // stream-K workspace: 2 slabs of BM x BN f32 per workgroup of the main launch
     long ldy, ldr;
     unsigned x3_bytes, w3_bytes, zero_off, row_pitch;  // row_pitch = CC * 192
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     wait_vmcnt<0>();
     __syncthreads();  // all waves out of the main loop: the ring is free for the epilogue
 
-    if (p.stat_partial && complete) {
+    if ((p.stat_partial || p.stat_sums) && complete) {
         // BatchNorm batch statistics of the RAW output, one partial row per M-tile (rows >= M are zero: their taps all
         // read the zero row)
         float *red = reinterpret_cast<float *>(smem);  // [WARPS_M][2][BN]
@@ -397,7 +398,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
             float a = 0.f;
 #pragma unroll
             for (int q = 0; q < WARPS_M; ++q) a += red[(q * 2 + which) * BN + col];
-            if (n0 + col < p.K) p.stat_partial[((long)mt_i * 2 + which) * p.K + n0 + col] = a;
+            if (n0 + col < p.K) {
+                if (p.stat_sums) unsafeAtomicAdd(p.stat_sums + (long)which * p.K + n0 + col, (double)a);
+                else p.stat_partial[((long)mt_i * 2 + which) * p.K + n0 + col] = a;
+            }
         }
         __syncthreads();
     }
@@ -503,7 +507,7 @@ template <int BM, int BN> __global__ __launch_bounds__(256) void conv_x3_fixup_k
         const int m = m0 + lr, k = n0 + c4 * 4;
         if (m < m_end && k < p.K) x3_store_out(p, v, m, k, ohw, vec_ok);
     }
-    if (p.stat_partial) {  // rows >= M of the slabs are exact zeros
+    if (p.stat_partial || p.stat_sums) {  // rows >= M of the slabs are exact zeros
         constexpr int NR = RPP;
         for (int e = 0; e < 4; ++e) {
             red[0][r0][c4 * 4 + e] = s1[e];
@@ -514,7 +518,10 @@ template <int BM, int BN> __global__ __launch_bounds__(256) void conv_x3_fixup_k
             const int which = j / BN, col = j - which * BN;
             float a = 0.f;
             for (int q = 0; q < NR; ++q) a += red[which][q][col];
-            if (n0 + col < p.K) p.stat_partial[((long)mt_i * 2 + which) * p.K + n0 + col] = a;
+            if (n0 + col < p.K) {
+                if (p.stat_sums) unsafeAtomicAdd(p.stat_sums + (long)which * p.K + n0 + col, (double)a);  // (this block's rows)
+                else p.stat_partial[((long)mt_i * 2 + which) * p.K + n0 + col] = a;
+            }
         }
     }
 }
@@ -663,7 +670,7 @@ extern "C" int dass_split3_rows(const float *x, int64_t ld, void *out, int64_t M
 static int conv_x3_impl(const void *x3, const void *w3, void *y, int64_t ldy, void *y3, const float *scale, const float *shift,
                         const void *residual, int64_t ldr, int N, int H, int W, int C, int OH, int OW, int K, int R, int S, int stride,
                         int pad, int dil, int ustride, int act, float *stat_partial, int *stat_rows, void *workspace,
-                        int64_t workspace_bytes, void *stream, bool per_image, const int *cc_limit) {
+                        int64_t workspace_bytes, void *stream, bool per_image, const int *cc_limit, double *stat_sums = nullptr) {
     if (!x3 || !w3 || (!y && !y3)) return DASS_ERR_ARG;
     if (workspace && ((uintptr_t)workspace & 15)) return DASS_ERR_ARG;
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || K <= 0 || R <= 0 || S <= 0) return DASS_ERR_ARG;
@@ -685,6 +692,7 @@ static int conv_x3_impl(const void *x3, const void *w3, void *y, int64_t ldy, vo
     p.shift = shift;
     p.res = (const char *)residual;
     p.stat_partial = stat_partial;
+    p.stat_sums = stat_sums;
     p.ws = (float *)workspace;
     p.ldy = ldy;
     p.ldr = ldr;
@@ -704,7 +712,7 @@ static int conv_x3_impl(const void *x3, const void *w3, void *y, int64_t ldy, vo
     hipStream_t st = (hipStream_t)stream;
     if (ustride > 1) {
         // dgrad of a strided conv, phase-decomposed exactly like conv_igemm.hip: one launch per output parity phase
-        if (stride != 1 || scale || shift || residual || act != DASS_ACT_NONE || stat_partial || y3 || !y) return DASS_ERR_UNSUPPORTED;
+        if (stride != 1 || scale || shift || residual || act != DASS_ACT_NONE || stat_partial || stat_sums || y3 || !y) return DASS_ERR_UNSUPPORTED;
         if (ldy != K) return DASS_ERR_UNSUPPORTED;
         bool any_empty = false;
         unsigned long long masks[8][8];
@@ -746,6 +754,15 @@ extern "C" int dass_conv2d_x3(const void *x3, const void *w3, void *y, int64_t l
                               int64_t workspace_bytes, void *stream) {
     return conv_x3_impl(x3, w3, y, ldy, y3, scale, shift, residual, ldr, N, H, W, C, OH, OW, K, R, S, stride, pad, dil, ustride, act,
                         stat_partial, stat_rows, workspace, workspace_bytes, stream, false, nullptr);
+}
+
+/* plain conv + batch statistics added into [2][K] f64 accumulators (zeroed by the caller): see dass_bn_apply_train */
+extern "C" int dass_conv2d_x3_sums(const void *x3, const void *w3, void *y, int64_t ldy, int N, int H, int W, int C, int OH, int OW, int K,
+                                   int R, int S, int stride, int pad, int dil, double *stat_sums, void *workspace, int64_t workspace_bytes,
+                                   void *stream) {
+    if (!stat_sums || !y) return DASS_ERR_ARG;
+    return conv_x3_impl(x3, w3, y, ldy, nullptr, nullptr, nullptr, nullptr, 0, N, H, W, C, OH, OW, K, R, S, stride, pad, dil, 1, DASS_ACT_NONE,
+                        nullptr, nullptr, workspace, workspace_bytes, stream, false, nullptr, stat_sums);
 }
 
 // Per-image weight operands: image g multiplies with w3 + g * (K * R * S * CC * 192) and only its first cc_limit[g] channel

@@ -320,10 +320,31 @@ def flush_bn_counters():
         torch._foreach_add_(pend, 1)
 
 
-def bn_train_state(x, ld, m, k, bn, rep=1.0, stats=None):
-    """stats: (partial, rows) already produced by the conv epilogue (dass_conv2d_igemm_stats)"""
-    partial, nrows = stats if stats is not None else channel_stats(x, ld, m, k)
-    st = BNState(k, x.device)
+_bn_sum_arena = {"buf": None, "off": 0, "on": os.environ.get("DASS_BN_SUMS", "1") == "1"}
+
+
+def bn_sums_path(bn, k):
+    """train-mode BN of this layer through f64 channel accumulators (dass_conv2d_*_sums -> dass_bn_apply_train, backward
+    dass_bn_bwd_reduce_sums -> dass_bn_bwd_apply_sums): no finalize launches.  Not for SyncBN across ranks (the sums are
+    exchanged there), not in deterministic mode (atomic order), not beyond 2048 channels (LDS table of the apply kernel)."""
+    return (_bn_sum_arena["on"] and k <= 2048 and k % 4 == 0 and sync_bn_world(bn) == 1
+            and not lib.dass_get_deterministic())
+
+
+def _bn_sums(k, dev):
+    """a zeroed [2][k] f64 slice: cut from an arena cleared by one memset per ~20 train steps (never handed out twice)"""
+    a = _bn_sum_arena
+    need = (2 * k + 63) // 64 * 64
+    if a["buf"] is None or a["buf"].device != dev or a["off"] + need > a["buf"].numel():
+        a["buf"] = torch.zeros((max(1 << 22, need),), dtype=torch.float64, device=dev)
+        a["off"] = 0
+    out = a["buf"][a["off"]:a["off"] + 2 * k]
+    a["off"] += need
+    return out
+
+
+def _bn_running(bn):
+    """(momentum or -1, running_mean, running_var) of a train-mode BN call + the num_batches_tracked bookkeeping"""
     mom = -1.0
     rm = rv = None
     if bn.track_running_stats and bn.running_mean is not None:
@@ -332,6 +353,14 @@ def bn_train_state(x, ld, m, k, bn, rep=1.0, stats=None):
         _pending_counters.append(bn.num_batches_tracked)
         if _defer["depth"] == 0 or len(_pending_counters) >= 512:
             flush_bn_counters()
+    return mom, rm, rv
+
+
+def bn_train_state(x, ld, m, k, bn, rep=1.0, stats=None):
+    """stats: (partial, rows) already produced by the conv epilogue (dass_conv2d_igemm_stats)"""
+    partial, nrows = stats if stats is not None else channel_stats(x, ld, m, k)
+    st = BNState(k, x.device)
+    mom, rm, rv = _bn_running(bn)
     world = sync_bn_world(bn)
     if world > 1:
         # SyncBN: local sums -> one RCCL all-reduce of [2K] floats -> global mean / clamp(var, eps)^-1/2.
@@ -664,7 +693,24 @@ class _ConvBnAct(torch.autograd.Function):
             assert k % 4 == 0, "BN epilogue needs K % 4 == 0"
             y_raw = new_act(n, k, oh, ow, dt, dev)
             fused_stats = None
-            if use_x3:
+            sums = _bn_sums(k, dev) if batch_stats and bn_sums_path(bn, k) else None
+            if sums is not None:
+                # statistics as f64 accumulators the conv adds to; scale / shift derived inside the apply launch below
+                if spec.depthwise or rowtap:
+                    _conv_forward_raw(spec, xs, ldx, n, h, w, c, weight, y_raw, k, oh, ow)
+                    check(lib.dass_channel_sums(_p(y_raw), k, m, k, _p(sums), _dt(y_raw), _stream()), "dass_channel_sums")
+                elif use_x3:
+                    x3 = x3_operand(x, xs, ldx, n * h * w, c)
+                    x3_saved = x3 if x3_on else None
+                    ws = _x3_workspace(dev)
+                    check(lib.dass_conv2d_x3_sums(_p(x3), _p(weight_operand(weight, 0, dt, cpad=c)), _p(y_raw), k, n, h, w, c, oh, ow, k, r,
+                                                  weight.shape[3], spec.stride, spec.pad, spec.dil, _p(sums), _p(ws), ws.numel(),
+                                                  _stream()), "dass_conv2d_x3_sums")
+                else:
+                    check(lib.dass_conv2d_igemm_sums(_p(xs), ldx, _p(weight_operand(weight, 0, dt, cpad=c)), _p(y_raw), k, n, h, w, c, oh,
+                                                     ow, k, r, weight.shape[3], spec.stride, spec.pad, spec.dil, _cdt(y_raw), _p(sums),
+                                                     _stream()), "dass_conv2d_igemm_sums")
+            elif use_x3:
                 x3 = x3_operand(x, xs, ldx, n * h * w, c)
                 x3_saved = x3 if x3_on else None  # "select": the weight gradient stays on the classic kernel (f32 rows)
                 w_op = weight_operand(weight, 0, dt, cpad=c)
@@ -686,17 +732,26 @@ class _ConvBnAct(torch.autograd.Function):
                 fused_stats = (partial, nrows.value)
             else:
                 _conv_forward_raw(spec, xs, ldx, n, h, w, c, weight, y_raw, k, oh, ow)
-            if bn is not None:
+            if bn is not None and sums is None:
                 state = (bn_train_state(y_raw, k, m, k, bn, stats=fused_stats) if batch_stats
                          else bn_eval_state(bn, k, dev))
                 scale, shift = state.scale, state.shift
-            else:
+            elif bn is None:
                 scale, shift = None, (bias.detach().float() if bias is not None else None)
             out3 = None
             if x3_on and dt == torch.float32 and getattr(spec, "emit_x3", True) and k >= 32 and kpad == k:
                 out3 = x3_alloc_for(m, k, dev)  # the consumer is (almost always) the next dense conv: hand it split rows
-            scale_shift_act(y_raw, k, out, ldo, m, k, scale, shift, residual=res_t, ldr=ldr or 0,
-                            nc_scale=nc_scale, rows_per_image=oh * ow, act=spec.act, out3=out3)
+            if sums is not None:
+                state = BNState(k, dev)
+                mom, rm, rv = _bn_running(bn)
+                check(lib.dass_bn_apply_train(_p(y_raw), k, _p(out), ldo, _p(sums), float(m), _p(bn.weight), _p(bn.bias), _p(rm), _p(rv),
+                                              mom, float(bn.eps), _p(state.mean), _p(state.invstd), _p(state.scale), _p(state.shift),
+                                              _p(res_t), ldr or 0, _p(nc_scale), m, k, oh * ow, spec.act, _dt(out), _p(out3), _stream()),
+                      "dass_bn_apply_train")
+                _running_stats_written(bn, rm, rv)
+            else:
+                scale_shift_act(y_raw, k, out, ldo, m, k, scale, shift, residual=res_t, ldr=ldr or 0,
+                                nc_scale=nc_scale, rows_per_image=oh * ow, act=spec.act, out3=out3)
             if out3 is not None:
                 attach_x3(out, out3, m, k)
         if need_grad:
@@ -706,6 +761,7 @@ class _ConvBnAct(torch.autograd.Function):
             ctx.image_input = image_input
             ctx.dims = (n, h, w, c, oh, ow, k, ldx, ldo, c_in)
             ctx.train_stats = batch_stats
+            ctx.bn_sums = batch_stats and bn_sums_path(bn, k)
             ctx.sync_world = sync_bn_world(bn) if batch_stats else 1
             ctx.has_bn = bn is not None
             ctx.has_bias = bias is not None
@@ -769,7 +825,16 @@ class _ConvBnAct(torch.autograd.Function):
             # (bit-identical), so neither pass reads `out`
             gate = (ctx.has_bn and not ctx.has_res and y_raw is not None and dt == torch.float32 and bn_scale is not None
                     and spec.act != ACT_NONE)
-            if need_red:
+            bsums = None
+            if need_red and ctx.has_bn and ctx.train_stats and getattr(ctx, "bn_sums", False) and ctx.sync_world == 1:
+                # (sum dz, sum dz * xhat) as f64 accumulators: the apply launch reads them, no finalize launch
+                bsums = _bn_sums(k, dev)
+                check(lib.dass_bn_bwd_reduce_sums(_p(dout_r), lddo, _p(None if gate else out), ldo, _p(y_raw), k, _p(mean_v), _p(invstd_v),
+                                                  _p(bn_scale if gate else None), _p(bn_shift if gate else None), _p(nc_scale), m, k,
+                                                  oh * ow, spec.act, _p(bsums), _dt(out), _stream()), "dass_bn_bwd_reduce_sums")
+                pg = torch.empty((2, k), dtype=torch.float32, device=dev)
+                dbeta, dgamma = pg[0], pg[1]
+            elif need_red:
                 nrows = lib.dass_stat_rows(m)
                 partial = torch.empty((nrows, 2, k), dtype=torch.float32, device=dev)
                 if gate:
@@ -798,7 +863,12 @@ class _ConvBnAct(torch.autograd.Function):
                     and ((ctx.x3_dgrad and ctx.needs_input_grad[0] and c > 32)
                          or (ctx.x3_on and ctx.needs_input_grad[1] and x3_in is not None))):
                 dy3 = x3_alloc_for(m, k, dev)  # dy also as split rows: operand of the input- and weight-gradient launches
-            if gate:
+            if bsums is not None:
+                check(lib.dass_bn_bwd_apply_sums(_p(dout_r), lddo, _p(None if gate else out), ldo, _p(y_raw), k, _p(mean_v), _p(invstd_v),
+                                                 _p(gamma_v.detach()), _p(bsums), _p(dbeta), _p(dgamma), _p(bn_scale if gate else None),
+                                                 _p(bn_shift if gate else None), _p(nc_scale), _p(dy), lddy, _p(dres), k, m, k, oh * ow,
+                                                 float(m), spec.act, _dt(out), _p(dy3), _stream()), "dass_bn_bwd_apply_sums")
+            elif gate:
                 check(lib.dass_bn_bwd_apply_gate(_p(dout_r), lddo, _p(y_raw), k, _p(mean_v), _p(invstd_v), _p(gamma_v.detach()), _p(db), _p(dg),
                                                  _p(bn_scale), _p(bn_shift), _p(nc_scale), _p(dy), lddy, m, k, oh * ow,
                                                  float(m) * ctx.sync_world, 1 if ctx.train_stats else 0, spec.act, _dt(out), _p(dy3),

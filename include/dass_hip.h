@@ -156,6 +156,41 @@ int dass_bn_rows_fwd(const float *x, int N, int K, double rep, const float *gamm
                      float *mean, float *invstd, float *scale, float *shift, void *stream);
 int dass_bn_rows_bwd(const float *g, const float *x, const float *mean, const float *invstd, const float *gamma,
                      int N, int K, int train, float *dx, float *dgamma, float *dbeta, void *stream);
+/* ---- train-mode BN without finalize launches (world size 1, dass_get_deterministic() == 0).  The batch statistics of a
+ * layer live in `sums`: [2][K] f64 accumulators (sum, sum of squares of the raw conv output), zeroed by the caller;
+ * the producing kernel adds to them with hardware f64 atomics and the apply kernel reads them directly:
+ *   dass_conv2d_igemm_sums / dass_conv2d_x3_sums   the conv of dass_conv2d_igemm_stats / dass_conv2d_x3 (plain output);
+ *   dass_channel_sums                              the standalone statistics pass (depthwise / stem producers);
+ *   dass_bn_apply_train                            dass_bn_finalize + dass_scale_shift_act in one launch: every block
+ *                                                  derives scale / shift (f64) into LDS, block 0 stores mean / invstd /
+ *                                                  scale / shift for the backward and updates the running statistics
+ *                                                  (F.batch_norm(training=True) semantics, momentum < 0: no update);
+ *   dass_bn_bwd_reduce_sums / dass_bn_bwd_apply_sums   the backward pair of dass_bn_bwd_reduce(_gate) / _apply(_gate)
+ *                                                  with sums = (sum dz, sum dz * xhat); dbeta_out / dgamma_out get them
+ *                                                  rounded to f32.  out == NULL selects the gate-from-x form (f32).
+ * Arithmetic is that of the partial-row entry points (f32 inside a tile / slab, f64 across); only the order of the f64
+ * additions is unspecified.  K <= 2048 for dass_bn_apply_train (DASS_ERR_UNSUPPORTED beyond). */
+int dass_conv2d_igemm_sums(const void *x, int64_t ldx, const void *w, void *y, int64_t ldy, int N, int H, int W, int C,
+                           int OH, int OW, int K, int R, int S, int stride, int pad, int dil, int dtype,
+                           double *stat_sums, void *stream);
+int dass_conv2d_x3_sums(const void *x3, const void *w3, void *y, int64_t ldy, int N, int H, int W, int C, int OH, int OW,
+                        int K, int R, int S, int stride, int pad, int dil, double *stat_sums, void *workspace,
+                        int64_t workspace_bytes, void *stream);
+int dass_channel_sums(const void *x, int64_t ldx, int64_t M, int K, double *sums, int dtype, void *stream);
+int dass_bn_apply_train(const void *x, int64_t ldx, void *out, int64_t ldo, const double *sums, double count,
+                        const float *gamma, const float *beta, float *running_mean, float *running_var, float momentum,
+                        float eps, float *mean, float *invstd, float *scale, float *shift, const void *residual,
+                        int64_t ldr, const float *nc_scale, int64_t M, int K, int64_t rows_per_image, int act, int dtype,
+                        void *out3, void *stream);
+int dass_bn_bwd_reduce_sums(const void *dout, int64_t lddo, const void *out, int64_t ldo, const void *x, int64_t ldx,
+                            const float *mean, const float *invstd, const float *gate_scale, const float *gate_shift,
+                            const float *nc_scale, int64_t M, int K, int64_t rows_per_image, int act, double *sums,
+                            int dtype, void *stream);
+int dass_bn_bwd_apply_sums(const void *dout, int64_t lddo, const void *out, int64_t ldo, const void *x, int64_t ldx,
+                           const float *mean, const float *invstd, const float *gamma, const double *sums,
+                           float *dbeta_out, float *dgamma_out, const float *gate_scale, const float *gate_shift,
+                           const float *nc_scale, void *dx, int64_t lddx, void *dres, int64_t lddr, int64_t M, int K,
+                           int64_t rows_per_image, double count, int act, int dtype, void *dx3, void *stream);
 /* eval-mode BN folded to scale/shift from running stats */
 int dass_bn_eval_scale_shift(const float *gamma, const float *beta, const float *running_mean,
                              const float *running_var, float eps, int K,

@@ -281,3 +281,44 @@ def test_deterministic_weight_gradients_are_bit_reproducible():
     assert all(torch.equal(a[k], b[k]) for k in a), [k for k in a if not torch.equal(a[k], b[k])][:5]
     worst = max(((a[k] - fast[k]).norm().item() / max(fast[k].norm().item(), 1e-12), k) for k in a)
     assert worst[0] <= 1e-5, worst
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 33, 33, 256, 1), (2, 256, 17, 17, 256, 3), (3, 32, 19, 23, 96, 3)])
+@pytest.mark.parametrize("residual", [False, True])
+def test_bn_sums_path_equals_partial_row_path(shape, residual):
+    """train-mode BN through the f64 accumulators (dass_conv2d_igemm_sums / _x3_sums -> dass_bn_apply_train, backward
+    dass_bn_bwd_reduce_sums -> dass_bn_bwd_apply_sums) against the partial-row + finalize launches it replaces: same
+    f32-inside-a-tile / f64-across arithmetic, so outputs, running statistics and all gradients agree to rounding."""
+    from dass_hip import ops
+
+    n, c, h, w, k, ks = shape
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(c, k, ks, padding=ks // 2, bias=False).cuda()
+    x0 = torch.randn(n, c, h, w, device="cuda").contiguous(memory_format=torch.channels_last)
+    res0 = torch.randn(n, k, h, w, device="cuda").contiguous(memory_format=torch.channels_last) if residual else None
+    gout = torch.randn(n, k, h, w, device="cuda").contiguous(memory_format=torch.channels_last)
+    runs = {}
+    keep = ops._bn_sum_arena["on"]
+    try:
+        for on in (False, True):
+            ops._bn_sum_arena["on"] = on
+            bn = torch.nn.BatchNorm2d(k).cuda()
+            with torch.no_grad():
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.normal_()
+            bn.train()
+            conv.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            res = res0.clone().requires_grad_(True) if residual else None
+            assert ops.bn_sums_path(bn, k) == on
+            out = ops.conv_bn_act(x, conv, bn, ops.ACT_RELU, residual=res)
+            out.backward(gout)
+            runs[on] = dict(out=out.detach(), rm=bn.running_mean.clone(), rv=bn.running_var.clone(), dx=x.grad, dw=conv.weight.grad,
+                            dg=bn.weight.grad, db=bn.bias.grad, dres=res.grad if residual else None)
+    finally:
+        ops._bn_sum_arena["on"] = keep
+    for key, a in runs[False].items():
+        if a is None:
+            continue
+        b = runs[True][key]
+        assert (a - b).abs().max().item() <= 2e-6 * max(a.abs().max().item(), 1e-3), key
