@@ -155,9 +155,22 @@ def conv_aggregate(args, ops, tdt):
                                         else wt.permute(3, 1, 2, 0).flip(1, 2).contiguous())
         stream = ops._stream()
         pad_t = dil * (ks - 1) - pad
-        tot["fwd"] += cnt * timeit(lambda: ops.conv_launch(x, c, wop, y, k, (n, h, w, c, oh, ow, k, ks, ks, st, pad, dil)))
-        tot["dgrad"] += cnt * timeit(lambda: check(lib.dass_conv2d_igemm(ops._p(dy), k, ops._p(wop_t), ops._p(dx), c, None, None, None, 0, None,
-                                                                        n, oh, ow, k, h, w, c, ks, ks, 1, pad_t, dil, st, 0, ops._cdt(dx), stream), "dgrad"))
+        # the engine the train step uses for this layer (DASS_X3=select: pre-split kernels on the long 3x3 reductions; the
+        # forward then pays the conversion pass of its input, the input gradient gets dy's split rows from the BN backward)
+        x3_fwd = tdt == torch.float32 and ops._x3_train_layer(ks * ks, c) and k > 32
+        x3_dg = tdt == torch.float32 and ops._x3_train_layer(ks * ks, k) and c > 32
+        if x3_fwd:
+            tot["fwd"] += cnt * timeit(lambda: ops.conv_x3_launch(ops.split3_rows(x, c, n * h * w, c), wop, y, k,
+                                                                   (n, h, w, c, oh, ow, k, ks, ks, st, pad, dil)))
+        else:
+            tot["fwd"] += cnt * timeit(lambda: ops.conv_launch(x, c, wop, y, k, (n, h, w, c, oh, ow, k, ks, ks, st, pad, dil)))
+        if x3_dg:
+            dy3 = ops.split3_rows(dy, k, n * oh * ow, k)
+            tot["dgrad"] += cnt * timeit(lambda: ops.conv_x3_launch(dy3, wop_t, dx, c, (n, oh, ow, k, h, w, c, ks, ks, 1, pad_t, dil), ustride=st))
+            del dy3
+        else:
+            tot["dgrad"] += cnt * timeit(lambda: check(lib.dass_conv2d_igemm(ops._p(dy), k, ops._p(wop_t), ops._p(dx), c, None, None, None, 0, None,
+                                                                            n, oh, ow, k, h, w, c, ks, ks, 1, pad_t, dil, st, 0, ops._cdt(dx), stream), "dgrad"))
         tot["wgrad"] += cnt * timeit(lambda: check(lib.dass_conv2d_wgrad(ops._p(x), c, ops._p(dy), k, ops._p(dw), n, h, w, c, oh, ow, k, ks, ks,
                                                                         st, pad, dil, ops._cdt(dy), stream), "wgrad"))
         gflop += cnt * 2.0 * n * oh * ow * k * ks * ks * c / 1e9
@@ -322,14 +335,20 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
         y = torch.empty((n_, h_, h_, k_), device=dev, dtype=tdt)
         dims = (n_, h_, h_, c_, h_, h_, k_, 3, 3, 1, 1, 1)
         w = ops.prepare_conv_weight(w)  # bf16x6 multiplies pre-split weights (once per optimizer step in training)
+        x3_best = tdt == torch.float32 and ops._x3_train_layer(9, c_)  # this layer runs on the pre-split kernel in the train step
+        if x3_best:
+            x3_ = ops.split3_rows(x, c_, n_ * h_ * h_, c_)
+            launch = lambda: ops.conv_x3_launch(x3_, w, y, k_, dims)  # noqa: E731
+        else:
+            launch = lambda: ops.conv_launch(x, c_, w, y, k_, dims)  # noqa: E731
         for _ in range(3):
-            ops.conv_launch(x, c_, w, y, k_, dims)
+            launch()
         reps = 20
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
         for _ in range(reps):
-            ops.conv_launch(x, c_, w, y, k_, dims)
+            launch()
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
@@ -338,13 +357,18 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
         peak = round(MFMA_PEAK_TFLOPS[engine], 1)
         log("[%s] dominant conv kernel: %.3f ms/launch = %.1f TFLOP/s" % (dtype_name, ms, achieved))
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % engine)
+        tfile = os.path.join(ROOT, "profiles", "r02_traffic_x3.json" if x3_best else "r01_traffic_%s.json" % engine)
         if os.path.exists(tfile):  # HBM bytes per launch from the rocprofv3 --pmc passes (collected offline, see profiles/)
             traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
         kname = {"f32": "float,128,128,2,2", "bf16": "bf16,128,128,2,2", "bf16x6": "float,128,128,4,1,split=3",
                  "bf16x3": "float,128,128,2,2,split=2"}[engine]
-        best = {"kernel": "conv_igemm_kernel<%s> (3x3 304->256 @%dx%d, batch %d)" % (kname, h_, h_, n_), "achieved": round(achieved, 2),
+        if x3_best:
+            kname_full = "conv_x3_kernel<256,128,4,2,2> + fix-up, pre-split operands (3x3 304->256 @%dx%d, batch %d)" % (h_, h_, n_)
+        else:
+            kname_full = "conv_igemm_kernel<%s> (3x3 304->256 @%dx%d, batch %d)" % (kname, h_, h_, n_)
+        best = {"kernel": kname_full, "achieved": round(achieved, 2),
                 "frac": round(achieved / peak, 4), "launch_ms": round(ms, 4), "flops_per_launch": flops, "traffic": traffic}
+        launch = x3_ = None
         del x, w, y
         agg = conv_aggregate(args, ops, tdt)
         log("[%s] all conv launches of one train step: %.2f ms (fwd %.2f, dgrad %.2f, wgrad %.2f) = %.1f TFLOP/s"
@@ -362,7 +386,7 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
         res["roofline"] = {"bound": "mfma", "kernel": "every groups=1 conv launch of one train step (105 layers x fwd/dgrad/wgrad), time-weighted",
                            "achieved": agg["achieved"], "peak": peak, "peak_note": PEAK_NOTE[engine], "unit": "TFLOP/s",
                            "frac": round(agg["achieved"] / peak, 4), "traffic": traffic,
-                           "traffic_note": "HBM bytes of the best_launch shape from the committed PMC passes (profiles/r01_traffic_*.json; that kernel is unchanged since)",
+                           "traffic_note": "HBM bytes of the best_launch shape from the committed rocprofv3 --pmc passes (%s)" % os.path.basename(tfile),
                            "conv_ms_per_step": agg["ms_per_step"], "conv_gflop_per_step": agg["gflop"],
                            "conv_ceiling_ms_per_step": round(agg["gflop"] / peak, 3),
                            "split_ms": {"fwd": agg["fwd_ms"], "dgrad": agg["dgrad_ms"], "wgrad": agg["wgrad_ms"]},
