@@ -102,7 +102,10 @@ def _x3_train_layer(taps, red_channels):
     """training launches that go to the pre-split engine: all of them ("all") or the long 3x3 reductions ("select")"""
     if _state["f32_mma"] != "bf16x6":
         return False
-    return _state["x3"] == "all" or (_state["x3"] == "select" and taps >= 9 and red_channels >= 256)
+    return _state["x3"] == "all" or (_state["x3"] == "select" and taps >= _SELECT[0] and red_channels >= _SELECT[1])
+
+
+_SELECT = (int(os.environ.get("DASS_X3_SELECT_TAPS", "9")), int(os.environ.get("DASS_X3_SELECT_C", "256")))  # measured optimum
 
 
 def _cdt(t):
