@@ -1,14 +1,25 @@
 #!/usr/bin/env python
 """per-kernel totals from a rocprofv3 rocpd sqlite file: rocpd_stats.py results.db [steps] [rows] [name-substring grid_x]
--> markdown table; with a name substring and a grid size (threads) also the average duration of exactly those launches
+-> markdown table; `--after NAME COUNT` (anywhere on the line) drops everything up to and including the COUNT-th launch of a
+kernel whose name contains NAME -- e.g. `--after sgd_multi 18` skips 3 warm-up train steps (6 optimizer launches each), so
+one-time work (operand caches, first-step allocations) stays out of the per-step table; with a name substring and a grid size (threads) also the average duration of exactly those launches
 (bench.py's roofline leg launches the dominant kernel on ONE shape: grid_x = ceil(M/128)*ceil(K/128)*256)"""
 import sqlite3, sys, re
+after = None
+if "--after" in sys.argv:
+    i = sys.argv.index("--after")
+    after = (sys.argv[i + 1], int(sys.argv[i + 2]))
+    del sys.argv[i:i + 3]
 db = sqlite3.connect(sys.argv[1])
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 cur = db.cursor()
 cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
 name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
-rows = cur.execute("select %s, count(*), sum(end - start), avg(end - start) from kernels group by %s order by 3 desc" % (name_col, name_col)).fetchall()
+where = ""
+if after is not None:
+    marks = [r[0] for r in cur.execute("select start from kernels where %s like ? order by start" % name_col, ("%" + after[0] + "%",))]
+    where = " where start > %d" % marks[after[1] - 1]
+rows = cur.execute("select %s, count(*), sum(end - start), avg(end - start) from kernels%s group by %s order by 3 desc" % (name_col, where, name_col)).fetchall()
 total = sum(r[2] for r in rows)
 print("total kernel time %.1f ms = %.2f ms/step" % (total / 1e6, total / 1e6 / steps))
 print("| kernel | calls | ms/step | avg us | % |\n|---|---|---|---|---|")
