@@ -22,6 +22,7 @@
 // (models/backbone/resnet.py:11-15, models/aspp.py:13-14,57-68, models/decoder.py:23-36).
 #include "dass_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -119,10 +120,14 @@ __device__ __forceinline__ void x3_store_out(const X3P &p, f32x4 v, int m, int k
 // (deterministic) and runs the same epilogue.  With sk_wgs = CUs every CU gets the same number of slabs whatever the tile
 // count (M = 8712 layers: 138 tiles on 256 CUs; 133128-row layers: 1042 tiles = 4.07 rounds); with sk_wgs = tiles it
 // degenerates to one tile per workgroup and no workspace traffic.
-template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE>
+// M16: the products run on v_mfma_f32_16x16x32_bf16 (one 32-k slab per instruction) instead of v_mfma_f32_32x32x16_bf16: the
+// same FLOPs per cycle, but the chip holds a ~10 % higher clock under that shape (tools/mfma_shape_probe.py: 2.17 vs 1.97 GHz
+// with two LDS-fed waves per SIMD on all CUs; MI355X_MICROARCH.md measures 1.12-1.14 x).
+template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE, bool M16>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(const X3P p) {
     constexpr int NW = WARPS_M * WARPS_N;
     constexpr int TMW = BM / WARPS_M, TNW = BN / WARPS_N, MT = TMW / 32, NT = TNW / 32;
+    constexpr int MT16 = TMW / 16, NT16 = TNW / 16, MH = MT16 / 2, NH = NT16 / 2;  // M16: 16 x 16 blocks, handled in halves
     constexpr int AG = BM / 16, BG = BN / 16, RG = (AG + BG) / NW;
     static_assert((AG + BG) % NW == 0, "rowgroups must divide over the waves");
     static_assert(MT >= 1 && NT >= 1 && NSTAGE >= 2 && NSTAGE <= 4, "tile");
@@ -163,6 +168,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     const int a_lane1 = (wm * (TMW / 16)) * 3072 + f_row + (((2 + fh) ^ fsw) * 16);
     const int b_lane0 = A_BYTES + (wn * (TNW / 16)) * 3072 + f_row + (((0 + fh) ^ fsw) * 16);
     const int b_lane1 = A_BYTES + (wn * (TNW / 16)) * 3072 + f_row + (((2 + fh) ^ fsw) * 16);
+    // M16: lane (r = lane & 15, g = lane >> 4) reads row r, chunk g (k = 8 g .. 8 g + 7) of a 16-row piece: the 64 lanes cover
+    // the 1 KiB piece exactly once (conflict-free under the same XOR swizzle)
+    const int l16 = (lane & 15) * 64 + (((lane >> 4) ^ (((lane & 15) >> 2) & 3)) * 16);
+    const int a16 = (wm * MT16) * 3072 + l16, b16 = A_BYTES + (wn * NT16) * 3072 + l16;
 
     // ---- this workgroup's range of (tile, slab) units
     const int wgid = xcd_remap(blockIdx.x, gridDim.x);
@@ -251,13 +260,18 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     };
     const int total = active_below(s_hi) - active_below(s_lo);
 
-    f32x16 acc[MT][NT];
+    f32x16 acc[M16 ? 1 : MT][M16 ? 1 : NT];
+    f32x4 acc16[M16 ? MT16 : 1][M16 ? NT16 : 1];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < (M16 ? 1 : MT); ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < (M16 ? 1 : NT); ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < (M16 ? MT16 : 1); ++i)
+#pragma unroll
+        for (int j = 0; j < (M16 ? NT16 : 1); ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- slab iterator of the LOADER (the 9 taps of a 3x3 re-read the same neighbourhood back to back, so the re-reads
     // are L2 hits).  The uniform offsets of the NEXT slab to issue are computed one slab ahead (the tap table lives in
@@ -265,7 +279,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     int it_cc = s_lo / ntaps, nx_t = 0;
     unsigned long long it_mask = tapmask & ~((1ull << (s_lo - it_cc * ntaps)) - 1ull);
     unsigned nx_a_uni = 0u, nx_b_uni = 0u;
-    auto advance = [&]() {
+    auto advance = [&]() __attribute__((always_inline)) {
         if (!it_mask) {
             ++it_cc;
             it_mask = tapmask;
@@ -275,7 +289,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
         nx_a_uni = tap_delta[nx_t] + (unsigned)(it_cc * 192);
         nx_b_uni = (unsigned)((nx_t * p.CC + it_cc) * 192);
     };
-    auto issue_rowgroup = [&](int j, int stage) {  // the three parts of rowgroup wave + j * NW of the next slab
+    auto issue_rowgroup = [&](auto jc, int stage) __attribute__((always_inline)) {  // the three parts of rowgroup wave + j * NW of the next slab (j: int or integral_constant)
+        const int j = jc;
         const unsigned st = smem_base + (unsigned)(stage * STAGE);
         const int q = wave + j * NW;
         if (q < AG) {
@@ -309,6 +324,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     // k-step 1 (operands already in registers) run, and those of k-step 1 while k-step 0 multiplies, so the LDS read
     // latency is covered; the DMA issue of the slab NSTAGE-1 ahead is cut into its rowgroups and placed BETWEEN the
     // MFMA groups of the first half (an in-order wave issues them in the shadow of the running MFMAs).
+    if constexpr (!M16) {
     uint4 a0[3][MT], b0[3][NT], a1[3][MT], b1[3][NT];
     auto load_frags = [&](const char *ap, const char *bp, uint4(&a)[3][MT], uint4(&b)[3][NT]) {
 #pragma unroll
@@ -367,6 +383,147 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
         nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
     }
     if (total > 0) multiply(a1, b1, nothing);
+    } else {
+    // ---- M16 main loop.  A slab is multiplied in four quadrant steps over (row half, column half) of the wave's blocks; the
+    // order alternates with the slab's parity -- even: (lo,lo) (lo,hi) (hi,hi) (hi,lo), odd: (lo,hi) (lo,lo) (hi,lo) (hi,hi)
+    // -- so that between ANY two consecutive steps, slab boundaries included, the operand halves that change are dead
+    // registers: four fragment sets (a_lo, a_hi, b_lo, b_hi; 96 VGPRs for a 64 x 64 wave tile) are enough to have every
+    // ds_read issued one full step (24 MFMAs) ahead of its use.  Steps 3 and 4 of slab s-1 run after the barrier of slab s
+    // (the skew of the 32x32 loop), with the DMA issue of the slab NSTAGE-1 ahead between their MFMA groups.
+    uint4 a_lo[3][MH], a_hi[3][MH], b_lo[3][NH], b_hi[3][NH];
+    // the loader's per-rowgroup state as plain values (the optimizer left rb_off[] / vmask[] in scratch memory when they were
+    // reached through the nested closures of this loop: a scratch load in front of every DMA issue, with a vmcnt(0) behind it)
+    static_assert(RG <= 4, "rowgroups per wave");
+    const unsigned rbv0 = rb_off[0], rbv1 = rb_off[RG > 1 ? 1 : 0], rbv2 = rb_off[RG > 2 ? 2 : 0], rbv3 = rb_off[RG > 3 ? 3 : 0];
+    const unsigned long long vmv0 = vmask[0], vmv1 = vmask[RG > 1 ? 1 : 0], vmv2 = vmask[RG > 2 ? 2 : 0], vmv3 = vmask[RG > 3 ? 3 : 0];
+    auto issue16 = [&, rbv0, rbv1, rbv2, rbv3, vmv0, vmv1, vmv2, vmv3](auto jc, int stage) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        const unsigned rbo = j == 0 ? rbv0 : j == 1 ? rbv1 : j == 2 ? rbv2 : rbv3;
+        const unsigned long long vm = j == 0 ? vmv0 : j == 1 ? vmv1 : j == 2 ? vmv2 : vmv3;
+        const unsigned st = smem_base + (unsigned)(stage * STAGE);
+        const int q = wave + j * NW;
+        if (q < AG) {
+            const bool valid = (vm >> nx_t) & 1ull;
+            const unsigned voff = valid ? rbo + nx_a_uni : p.zero_off + chunk_off;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(st + q * 3072);
+            dma16(rsa, dst, voff);
+            dma16(rsa, dst + 1024, voff + 64);
+            dma16(rsa, dst + 2048, voff + 128);
+        } else {
+            const unsigned voff = rbo + nx_b_uni;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(st + A_BYTES + (q - AG) * 3072);
+            dma16(rsb, dst, voff);
+            dma16(rsb, dst + 1024, voff + 64);
+            dma16(rsb, dst + 2048, voff + 128);
+        }
+    };
+    auto rd_a = [&](const char *st, uint4(&a)[3][MH], int half) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i2 = 0; i2 < MH; ++i2) a[pl][i2] = *reinterpret_cast<const uint4 *>(st + a16 + (half * MH + i2) * 3072 + pl * 1024);
+    };
+    auto rd_b = [&](const char *st, uint4(&b)[3][NH], int half) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int j2 = 0; j2 < NH; ++j2) b[pl][j2] = *reinterpret_cast<const uint4 *>(st + b16 + (half * NH + j2) * 3072 + pl * 1024);
+    };
+    // one quadrant: blocks (I0 + i, J0 + j); six products, smallest first; `between(term)` runs after each term's MFMAs
+    // (the term index travels as a TYPE: an index the optimizer only sees as a loop variable made it keep rb_off[] / vmask[]
+    // in scratch memory, and scratch traffic shares the vmcnt counter the DMA waits are counted on)
+    auto quad = [&](const uint4(&a)[3][MH], const uint4(&b)[3][NH], auto I0, auto J0, auto between) __attribute__((always_inline)) {
+        __builtin_amdgcn_s_setprio(1);
+        auto one = [&](auto T) __attribute__((always_inline)) {
+            constexpr int term = decltype(T)::value;
+            constexpr int PA_OF[6] = {0, 2, 1, 0, 1, 0}, PB_OF[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+            for (int i2 = 0; i2 < MH; ++i2)
+#pragma unroll
+                for (int j2 = 0; j2 < NH; ++j2)
+                    acc16[decltype(I0)::value + i2][decltype(J0)::value + j2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        *reinterpret_cast<const bf16x8 *>(&a[PA_OF[term]][i2]), *reinterpret_cast<const bf16x8 *>(&b[PB_OF[term]][j2]),
+                        acc16[decltype(I0)::value + i2][decltype(J0)::value + j2], 0, 0, 0);
+            between(T);
+        };
+        one(std::integral_constant<int, 0>{});
+        one(std::integral_constant<int, 1>{});
+        one(std::integral_constant<int, 2>{});
+        one(std::integral_constant<int, 3>{});
+        one(std::integral_constant<int, 4>{});
+        one(std::integral_constant<int, 5>{});
+        __builtin_amdgcn_s_setprio(0);
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using CMH = std::integral_constant<int, MH>;
+    using CNH = std::integral_constant<int, NH>;
+    auto nothing = [](auto) {};
+    int cur = 0, nxt = NSTAGE - 1;
+    // slab s with FIRST = the column half its steps 1 and 4 use (bf), SECOND = the other (bs); the previous slab had them swapped
+    auto slab = [&](int s, uint4(&bf)[3][NH], uint4(&bs)[3][NH], auto JF, auto JS, int hf, int hs) __attribute__((always_inline)) {
+        const int later = issued - s - 1;
+        if (NSTAGE >= 4 && later >= 2) wait_vmcnt<(NSTAGE >= 4 ? 2 * G : 0)>();
+        else if (NSTAGE >= 3 && later >= 1) wait_vmcnt<(NSTAGE >= 3 ? G : 0)>();
+        else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const char *st = smem + cur * STAGE;
+        const bool more = issued < total;  // block-uniform
+        // (sched_barriers pin the order: hoisting a fragment read above the MFMAs that still use its registers costs the
+        // compiler extra registers, and this kernel has none to spare -- a spill inside the loop would also put scratch
+        // traffic on the vmcnt counter the DMA waits are counted on)
+        rd_a(st, a_lo, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s > 0) {
+            quad(a_hi, bf, CMH{}, JF, [&](auto T) __attribute__((always_inline)) {  // step 3 of slab s-1: (hi rows, ITS second half = this slab's first)
+                if constexpr (decltype(T)::value < RG) {
+                    if (more) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue16(T, nxt);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            rd_b(st, bf, hf);
+            __builtin_amdgcn_sched_barrier(0);
+            quad(a_hi, bs, CMH{}, JS, nothing);      // step 4 of slab s-1
+        } else {
+            if (more) {
+                static_assert(RG <= 4, "rowgroups per wave");
+                if constexpr (RG > 0) issue16(std::integral_constant<int, 0>{}, nxt);
+                if constexpr (RG > 1) issue16(std::integral_constant<int, 1>{}, nxt);
+                if constexpr (RG > 2) issue16(std::integral_constant<int, 2>{}, nxt);
+                if constexpr (RG > 3) issue16(std::integral_constant<int, 3>{}, nxt);
+            }
+            rd_b(st, bf, hf);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more && ++issued < total) advance();
+        rd_b(st, bs, hs);
+        rd_a(st, a_hi, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        quad(a_lo, bf, C0{}, JF, nothing);           // step 1
+        __builtin_amdgcn_sched_barrier(0);
+        quad(a_lo, bs, C0{}, JS, nothing);           // step 2
+        __builtin_amdgcn_sched_barrier(0);
+        cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+        nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
+    };
+    int s = 0;
+    for (; s + 1 < total; s += 2) {
+        slab(s, b_lo, b_hi, C0{}, CNH{}, 0, 1);
+        slab(s + 1, b_hi, b_lo, CNH{}, C0{}, 1, 0);
+    }
+    if (s < total) {
+        slab(s, b_lo, b_hi, C0{}, CNH{}, 0, 1);
+        quad(a_hi, b_hi, CMH{}, CNH{}, nothing);     // steps 3, 4 of the last (even) slab
+        quad(a_hi, b_lo, CMH{}, C0{}, nothing);
+    } else if (total > 0) {
+        quad(a_hi, b_lo, CMH{}, C0{}, nothing);      // steps 3, 4 of the last (odd) slab: (hi, lo) then (hi, hi)
+        quad(a_hi, b_hi, CMH{}, CNH{}, nothing);
+    }
+    }
     wait_vmcnt<0>();
     __syncthreads();  // all waves out of the main loop: the ring is free for the epilogue
 
@@ -374,6 +531,28 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
         // BatchNorm batch statistics of the RAW output, one partial row per M-tile (rows >= M are zero: their taps all
         // read the zero row)
         float *red = reinterpret_cast<float *>(smem);  // [WARPS_M][2][BN]
+        if constexpr (M16) {
+#pragma unroll
+            for (int j2 = 0; j2 < NT16; ++j2) {  // a lane holds column lane & 15 of its four rows of every block
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i2 = 0; i2 < MT16; ++i2)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const float v = acc16[i2][j2][reg];
+                        s1 += v;
+                        s2 += v * v;
+                    }
+                s1 += __shfl_xor(s1, 16, 64);
+                s2 += __shfl_xor(s2, 16, 64);
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (lane < 16) {
+                    red[(wm * 2 + 0) * BN + wn * TNW + j2 * 16 + lane] = s1;
+                    red[(wm * 2 + 1) * BN + wn * TNW + j2 * 16 + lane] = s2;
+                }
+            }
+        } else {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             float s1 = 0.f, s2 = 0.f;
@@ -391,6 +570,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
                 red[(wm * 2 + 0) * BN + wn * TNW + nt * 32 + lane] = s1;
                 red[(wm * 2 + 1) * BN + wn * TNW + nt * 32 + lane] = s2;
             }
+        }
         }
         __syncthreads();
         for (int i = tid; i < 2 * BN; i += 64 * NW) {
@@ -423,6 +603,15 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int ntp = 0; ntp < NT; ntp += PBLK) {
+            if constexpr (M16) {  // C/D layout of the 16x16 blocks: col = lane & 15, row = 4 (lane >> 4) + reg
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                    for (int jb = 0; jb < 2 * PBLK; ++jb)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg)
+                            patch[(ib * 16 + (lane >> 4) * 4 + reg) * PITCH + jb * 16 + (lane & 15)] = acc16[mt * 2 + ib][ntp * 2 + jb][reg];
+            } else {
 #pragma unroll
             for (int q = 0; q < PBLK; ++q)
 #pragma unroll
@@ -430,6 +619,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
                     const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
                     patch[row * PITCH + q * 32 + (lane & 31)] = acc[mt][ntp + q][reg];
                 }
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -568,7 +758,7 @@ __global__ __launch_bounds__(256) void split3_rows_kernel(const float *__restric
 
 static int g_cus = 0;  // compute units of the current device (stream-K launches one workgroup per resident slot)
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE> int launch_x3(X3P &p, hipStream_t st, int mode, long ws_bytes) {
+template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE> int launch_x3(X3P &p, hipStream_t st, int mode, long ws_bytes, bool m16) {
     constexpr int LDS = NSTAGE * (BM + BN) * 192 + 256;
     constexpr int RES = (160 * 1024) / LDS >= 4 ? 4 : (160 * 1024) / LDS;  // resident workgroups per CU (LDS-limited)
     p.mt_per_group = (p.group_rows + BM - 1) / BM;
@@ -595,7 +785,10 @@ template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE> int launch_x3(X3
         if (p.dp_tiles == tiles) stream = false;  // the tile count is a whole number of rounds
         else if (s_tile / (ur / p.sk_part > 0 ? ur / p.sk_part : 1) + 2 > 256) return DASS_ERR_UNSUPPORTED;  // cannot happen for S_tile <= 1016
     }
-    hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE>), dim3(p.sk_wgs), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
+    if (m16)
+        hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE, true>), dim3(p.sk_wgs), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
+    else
+        hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE, false>), dim3(p.sk_wgs), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
     DASS_LAUNCH_CHECK();
     if (stream) {
         constexpr int RPP = 256 / (BN / 4);
@@ -606,18 +799,25 @@ template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE> int launch_x3(X3
     return DASS_OK;
 }
 
+static int g_x3_m16 = 1;      // default MFMA shape of the pre-split kernels: 16x16x32 (DASS_X3_MFMA=32 selects 32x32x16)
 static int g_x3_force = -1;  // tuning / test knob: dass_x3_force_tile(); -1 = take DASS_X3_TILE from the environment once
 
 // force = tile + 10 * mode: tile 0 = model's choice, 1..7 = variant; mode 0 = auto, 1 = one tile per workgroup, 2 = stream-K
 static int dispatch_x3(X3P &p, hipStream_t st, long ws_bytes) {
-    if (g_x3_force < 0) g_x3_force = getenv("DASS_X3_TILE") ? atoi(getenv("DASS_X3_TILE")) : 0;
+    if (g_x3_force < 0) {
+        g_x3_force = getenv("DASS_X3_TILE") ? atoi(getenv("DASS_X3_TILE")) : 0;
+        if (getenv("DASS_X3_MFMA")) g_x3_m16 = atoi(getenv("DASS_X3_MFMA")) != 32;
+    }
     if (!g_cus) {
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return DASS_ERR_LAUNCH;
         g_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    int mode = g_x3_force / 10;
+    // force = tile + 10 * mode + 100 * shape: shape 0 = default MFMA shape, 1 = 32x32x16, 2 = 16x16x32
+    const int shape = g_x3_force / 100;
+    const bool m16 = shape == 2 || (shape == 0 && g_x3_m16);
+    int mode = (g_x3_force / 10) % 10;
     int pick = g_x3_force % 10;
     if (!pick) {
         // measured on every DeepLab-R101 shape (tools/x3_time.py).  The chip is power-limited under MFMA load (all 256 CUs
@@ -633,13 +833,13 @@ static int dispatch_x3(X3P &p, hipStream_t st, long ws_bytes) {
         else { pick = 4; if (!mode) mode = 1; }  // short reductions: segments would be too short to amortise the fix-up
     }
     switch (pick) {
-    case 1: return launch_x3<256, 128, 4, 2, 2>(p, st, mode, ws_bytes);
-    case 2: return launch_x3<128, 128, 4, 2, 3>(p, st, mode, ws_bytes);
-    case 3: return launch_x3<128, 64, 4, 1, 2>(p, st, mode, ws_bytes);
-    case 5: return launch_x3<128, 128, 2, 2, 3>(p, st, mode, ws_bytes);
-    case 6: return launch_x3<64, 64, 2, 2, 3>(p, st, mode, ws_bytes);
-    case 7: return launch_x3<128, 128, 4, 2, 2>(p, st, mode, ws_bytes);
-    default: return launch_x3<64, 64, 2, 2, 2>(p, st, mode, ws_bytes);
+    case 1: return launch_x3<256, 128, 4, 2, 2>(p, st, mode, ws_bytes, m16);
+    case 2: return launch_x3<128, 128, 4, 2, 3>(p, st, mode, ws_bytes, m16);
+    case 3: return launch_x3<128, 64, 4, 1, 2>(p, st, mode, ws_bytes, m16);
+    case 5: return launch_x3<128, 128, 2, 2, 3>(p, st, mode, ws_bytes, m16);
+    case 6: return launch_x3<64, 64, 2, 2, 3>(p, st, mode, ws_bytes, m16);
+    case 7: return launch_x3<128, 128, 4, 2, 2>(p, st, mode, ws_bytes, m16);
+    default: return launch_x3<64, 64, 2, 2, 2>(p, st, mode, ws_bytes, m16);
     }
 }
 

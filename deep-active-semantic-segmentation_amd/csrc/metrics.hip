@@ -105,6 +105,31 @@ __global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long *ou
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
     uint4 a = *reinterpret_cast<const uint4 *>(&lds[(threadIdx.x * 4) & 4095]);
     uint4 b = *reinterpret_cast<const uint4 *>(&lds[(threadIdx.x * 4 + 1024) & 4095]);
+    if (use_lds & 2) {  // the same FLOPs per iteration from v_mfma_f32_16x16x32_bf16 (8 per iteration, 8 accumulators)
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+        f32x4_t ac[8];
+        for (int j = 0; j < 8; ++j)
+            for (int e = 0; e < 4; ++e) ac[j][e] = 0.f;
+        const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+        for (int it = 0; it < iters; ++it) {
+            if (use_lds & 1) {
+                a = *reinterpret_cast<const uint4 *>(&lds[(threadIdx.x * 4 + it * 64) & 4095]);
+                b = *reinterpret_cast<const uint4 *>(&lds[(threadIdx.x * 4 + it * 64 + 2048) & 4095]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                ac[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&a), *reinterpret_cast<const bf16x8 *>(&b), ac[j], 0, 0, 0);
+        }
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        float keep = 0.f;
+        for (int j = 0; j < 8; ++j) keep += ac[j][threadIdx.x & 3];
+        if (threadIdx.x == 0) {
+            out[blockIdx.x * 2] = c1 - c0;
+            out[blockIdx.x * 2 + 1] = r1 - r0;
+        }
+        if (keep == 123.456f) out[0] = 0;
+        return;
+    }
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
         if (use_lds) {  // two 16-B fragment reads per four MFMAs, like a 64 x 64 wave tile

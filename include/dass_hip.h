@@ -352,7 +352,7 @@ int dass_sgd_step_multi(void *const *p, const void *const *g, void *const *buf, 
  * dass_x3_bytes: allocation size.  dass_split3_rows: f32 rows -> x3 rows; nc_scale (nullable) multiplies row m by
  * nc_scale[m / rows_per_image][c] first (Dropout2d mask of the producer, aspp.py:89 / decoder.py:35). */
 int64_t dass_x3_bytes(int64_t rows, int C);
-/* tuning / test knob: tile + 10 * mode.  tile 0 = the dispatcher's choice, 1..7 = force one tile variant of
+/* tuning / test knob: tile + 10 * mode + 100 * shape (shape 0 = default MFMA shape = 16x16x32, 1 = 32x32x16, 2 = 16x16x32; DASS_X3_MFMA=32 makes 32x32x16 the default).  tile 0 = the dispatcher's choice, 1..7 = force one tile variant of
  * dass_conv2d_x3 (csrc/conv_x3.hip); mode 0 = auto, 1 = one output tile per workgroup, 2 = stream-K (whole rounds of
  * tiles one per workgroup + the remainder as equal slab ranges), 3 = stream-K slab ranges over all tiles */
 int dass_x3_force_tile(int tile);

@@ -18,8 +18,9 @@ CASES = [(8, 256, 33, 33, 256, 3, 1, 1, 1),      # layer3 3x3 at full size: M = 
          (2, 128, 35, 35, 128, 3, 2, 1, 1),      # stride 2
          (2, 48, 19, 23, 40, 3, 1, 1, 1),        # C = 48 (1.5 slabs), K = 40
          (1, 96, 9, 9, 320, 1, 1, 2, 1)]         # 1x1 over a zero-padded border (MobileNet fixed_padding form)
-# dass_x3_force_tile codes: tile + 10 * mode (mode 1 = one tile per workgroup, 2 = stream-K slab ranges, 0 = auto)
-TILES = [11, 12, 13, 14, 15, 16, 17, 21, 22, 23, 24, 0]
+# dass_x3_force_tile codes: tile + 10 * mode + 100 * shape (mode 1 = one tile per workgroup, 2 = stream-K slab ranges, 0 = auto;
+# shape 0 = the default MFMA shape (16x16x32), 1 = 32x32x16, 2 = 16x16x32)
+TILES = [11, 12, 13, 14, 15, 16, 17, 21, 22, 23, 24, 0, 111, 113, 114, 115, 121, 124, 100]
 
 
 @pytest.fixture(autouse=True)
