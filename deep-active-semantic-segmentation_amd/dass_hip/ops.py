@@ -261,6 +261,10 @@ def x3_operand(t, xs, ld, m, c, nc_scale=None, rows_per_image=1):
         hit = t.__dict__.get("_dass_x3") if hasattr(t, "__dict__") else None
         if hit is not None and hit[0] == (t.data_ptr(), t._version, m, c):
             return hit[1]
+        buf = split3_rows(xs, ld, m, c)
+        if hasattr(t, "__dict__"):
+            attach_x3(t, buf, m, c)  # other consumers of the same tensor (the ASPP branches share their input) reuse the rows
+        return buf
     return split3_rows(xs, ld, m, c, nc_scale, rows_per_image)
 
 
@@ -742,7 +746,8 @@ class _ConvBnAct(torch.autograd.Function):
             elif bn is None:
                 scale, shift = None, (bias.detach().float() if bias is not None else None)
             out3 = None
-            if x3_on and dt == torch.float32 and getattr(spec, "emit_x3", True) and k >= 32 and kpad == k:
+            if ((x3_on or (need_grad and getattr(spec, "x3_consumer", False))) and dt == torch.float32
+                    and getattr(spec, "emit_x3", True) and k >= 32 and kpad == k):
                 out3 = x3_alloc_for(m, k, dev)  # the consumer is (almost always) the next dense conv: hand it split rows
             if sums is not None:
                 state = BNState(k, dev)
@@ -1023,7 +1028,7 @@ def _dgrad_operand_uncached(wsrc, dtype):
 
 
 def conv_bn_act(x, conv, bn=None, act=ACT_NONE, residual=None, nc_scale=None, extra_pad=0, image_input=False,
-                in_scale=None, emit_x3=True, fork=False):
+                in_scale=None, emit_x3=True, fork=False, consumer=None):
     """in_scale: [N,C] f32 multipliers applied to the INPUT while it is staged (inference only): a
     Dropout2d mask of the producer folded into this conv's loader (MC-dropout tail, SURVEY 8a note iii).
     fork=True -> (out, x'): x' is x again, to be used for the OTHER consumer of x (the identity branch of a residual
@@ -1032,7 +1037,13 @@ def conv_bn_act(x, conv, bn=None, act=ACT_NONE, residual=None, nc_scale=None, ex
     spec.grad_enabled = torch.is_grad_enabled()
     spec.fork = bool(fork) and spec.grad_enabled and x.requires_grad
     if fork and not spec.fork:
-        return conv_bn_act(x, conv, bn, act, residual, nc_scale, extra_pad, image_input, in_scale, emit_x3), x
+        return conv_bn_act(x, conv, bn, act, residual, nc_scale, extra_pad, image_input, in_scale, emit_x3, consumer=consumer), x
+    # consumer: the nn.Conv2d that reads this output.  If the train step runs THAT conv on the pre-split kernels
+    # (DASS_X3=select: long 3x3 reductions), the BN-apply pass of this layer writes the split rows along with the f32
+    # ones (6 more bytes per element) instead of the consumer running a conversion pass (4 read + 6 written)
+    spec.x3_consumer = bool(consumer is not None and spec.grad_enabled and consumer.groups == 1
+                            and consumer.out_channels > 32
+                            and _x3_train_layer(consumer.kernel_size[0] * consumer.kernel_size[1], conv.out_channels))
     spec.emit_x3 = emit_x3  # False where the consumer is not a dense conv (concat / pool / upsample / classifier)
     if in_scale is not None:
         assert bn is None or not bn_use_batch_stats(bn), "in_scale needs eval-mode BN"

@@ -28,12 +28,12 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         if self.downsample:
-            out = ops.conv_bn_act(x, self.conv1, self.bn1, ops.ACT_RELU)
+            out = ops.conv_bn_act(x, self.conv1, self.bn1, ops.ACT_RELU, consumer=self.conv2)
             residual = ops.conv_bn_act(x, self.downsample[0], self.downsample[1], ops.ACT_NONE)
         else:
             # identity block: conv1 hands x back for the skip connection, so that the skip gradient is added inside
             # conv1's input-gradient launch (no separate accumulation pass over the block input)
-            out, residual = ops.conv_bn_act(x, self.conv1, self.bn1, ops.ACT_RELU, fork=True)
+            out, residual = ops.conv_bn_act(x, self.conv1, self.bn1, ops.ACT_RELU, fork=True, consumer=self.conv2)
         out = ops.conv_bn_act(out, self.conv2, self.bn2, ops.ACT_RELU)
         # bn3 -> += residual -> relu (resnet.py:36-43) in one epilogue
         return ops.conv_bn_act(out, self.conv3, self.bn3, ops.ACT_RELU, residual=residual)

@@ -46,7 +46,7 @@ class Decoder(nn.Module):
 
     def head(self, feats, dropout_mask=None, in_scale=None, mask_as_in_scale=None):
         lc = self.last_conv
-        h = ops.conv_bn_act(feats, lc[0], lc[1], ops.ACT_RELU, in_scale=in_scale)
+        h = ops.conv_bn_act(feats, lc[0], lc[1], ops.ACT_RELU, in_scale=in_scale, consumer=lc[3])
         if mask_as_in_scale is not None:  # inference: fold the Dropout2d mask into the classifier's loader
             h = ops.conv_bn_act(h, lc[3], lc[4], ops.ACT_RELU, emit_x3=False)
             return ops.conv_bn_act(h, lc[7], in_scale=mask_as_in_scale)
