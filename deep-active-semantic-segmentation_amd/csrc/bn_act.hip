@@ -27,7 +27,8 @@ __global__ __launch_bounds__(256) void colstat_kernel(const T *__restrict__ x, l
                                                       long rows_per_image, int act, float *__restrict__ partial,
                                                       const float *__restrict__ gate_scale = nullptr,
                                                       const float *__restrict__ gate_shift = nullptr,
-                                                      double *__restrict__ sums = nullptr) {
+                                                      double *__restrict__ sums = nullptr,
+                                                      const unsigned char *__restrict__ gates = nullptr) {
     __shared__ float red[2][16][64 + 1];
     const int tid = threadIdx.x;
     const int cx = tid & 15, ry = tid >> 4;
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256) void colstat_kernel(const T *__restrict__ x, l
         if (MODE == 1) {
             mu = *reinterpret_cast<const f32x4 *>(mean + k);
             is = *reinterpret_cast<const f32x4 *>(invstd + k);
-            if (!out) {
+            if (!out && !gates) {
                 gsc = *reinterpret_cast<const f32x4 *>(gate_scale + k);
                 gsh = *reinterpret_cast<const f32x4 *>(gate_shift + k);
             }
@@ -53,12 +54,20 @@ __global__ __launch_bounds__(256) void colstat_kernel(const T *__restrict__ x, l
                 s1 += xv * xv;
             } else {
                 f32x4 g = ld4<T>(dout + r * lddo + k);
+                if (gates) {
+                    // the forward stored the activation gate of every element (4 bits per 4-channel group): 1 byte read
+                    // instead of the 16 bytes of `out` (residual layers cannot re-derive the gate from the conv output alone)
+                    const unsigned gb = gates[r * (K >> 2) + (k >> 2)];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] = ((gb >> e) & 1u) ? g[e] : 0.f;
+                } else {
                 // activation gate from the stored output, or -- no residual, f32 -- re-derived from the conv output with
                 // the forward's own fma (bit-identical pre-activation), which saves reading `out`
                 const f32x4 o = out ? ld4<T>(out + r * ldo + k) : bn_affine(xv, gsc, gsh);
                 if (nc_scale) g *= *reinterpret_cast<const f32x4 *>(nc_scale + (r / rows_per_image) * K + k);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] *= act_grad_from_out(o[e], act);
+                }
                 s0 += g;
                 s1 += g * ((xv - mu) * is);
             }
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(256) void bn_apply_train_kernel(const T *__restrict
                                                              float momentum, float eps, float *mean, float *invstd, float *scale_o,
                                                              float *shift_o, const T *__restrict__ res, long ldr,
                                                              const float *__restrict__ nc_scale, long M, int K, long rows_per_image,
-                                                             int act, char *__restrict__ out3) {
+                                                             int act, char *__restrict__ out3, unsigned char *__restrict__ gates) {
     __shared__ __attribute__((aligned(16))) float s_scale[BN_KMAX];
     __shared__ __attribute__((aligned(16))) float s_shift[BN_KMAX];
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
@@ -251,6 +260,12 @@ __global__ __launch_bounds__(256) void bn_apply_train_kernel(const T *__restrict
         if (res) v += ld4<T>(res + m * ldr + k);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
+        if (gates) {  // the backward's activation gate of these four outputs (act_grad_from_out of the stored value)
+            unsigned gb = 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gb |= (act_grad_from_out(v[e], act) != 0.f ? 1u : 0u) << e;
+            gates[m * (K >> 2) + kq] = (unsigned char)gb;
+        }
         if (nc_scale) v *= *reinterpret_cast<const f32x4 *>(nc_scale + (m / rows_per_image) * K + k);
         if (out) st4<T>(out + m * ldo + k, v);
         if (out3) x3_store4(out3, m, cc3, k, v);
@@ -274,7 +289,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
                                                            char *__restrict__ dx3 = nullptr,
                                                            const double *__restrict__ sums = nullptr,
                                                            float *__restrict__ dbeta_out = nullptr,
-                                                           float *__restrict__ dgamma_out = nullptr) {
+                                                           float *__restrict__ dgamma_out = nullptr,
+                                                           const unsigned char *__restrict__ gates = nullptr) {
     if (dx3 && blockIdx.x == 0) x3_zero_row(dx3, M, (K + 31) >> 5);
     if (sums && blockIdx.x == 0)  // the f64 sums of dass_bn_bwd_reduce_sums, rounded once: the parameter gradients
         for (int k = threadIdx.x; k < K; k += blockDim.x) {
@@ -297,12 +313,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
         const int k = kq << 2;
         f32x4 g = ld4<T>(dout + m * lddo + k);
         f32x4 xin = {0.f, 0.f, 0.f, 0.f};
-        if (!out || (dx && train)) xin = ld4<T>(x + m * ldx + k);
+        if ((!out && !gates) || (dx && train)) xin = ld4<T>(x + m * ldx + k);
+        if (gates) {
+            const unsigned gb = gates[m * (K >> 2) + kq];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = ((gb >> e) & 1u) ? g[e] : 0.f;
+        } else {
         const f32x4 o = out ? ld4<T>(out + m * ldo + k)
                             : bn_affine(xin, *reinterpret_cast<const f32x4 *>(gate_scale + k), *reinterpret_cast<const f32x4 *>(gate_shift + k));
         if (nc_scale) g *= *reinterpret_cast<const f32x4 *>(nc_scale + (m / rows_per_image) * K + k);
 #pragma unroll
         for (int e = 0; e < 4; ++e) g[e] *= act_grad_from_out(o[e], act);
+        }
         if (dres) st4<T>(dres + m * lddr + k, g);
         if (dx) {
             const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + k);
@@ -607,7 +629,7 @@ extern "C" int dass_channel_sums(const void *x, int64_t ldx, int64_t M, int K, d
 extern "C" int dass_bn_apply_train(const void *x, int64_t ldx, void *out, int64_t ldo, const double *sums, double count, const float *gamma,
                                    const float *beta, float *running_mean, float *running_var, float momentum, float eps, float *mean,
                                    float *invstd, float *scale, float *shift, const void *residual, int64_t ldr, const float *nc_scale,
-                                   int64_t M, int K, int64_t rows_per_image, int act, int dtype, void *out3, void *stream) {
+                                   int64_t M, int K, int64_t rows_per_image, int act, int dtype, void *out3, void *gates, void *stream) {
     if (!x || (!out && !out3) || !sums || count <= 0 || !mean || !invstd || !scale || !shift || M <= 0 ||
         !ok4(K, ldx, out ? ldo : 4, residual ? ldr : 4) || rows_per_image <= 0)
         return DASS_ERR_ARG;
@@ -618,32 +640,36 @@ extern "C" int dass_bn_apply_train(const void *x, int64_t ldx, void *out, int64_
     if (dtype == DASS_F32)
         hipLaunchKernelGGL(bn_apply_train_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, ldx, (float *)out, ldo, sums, count,
                            gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, (const float *)residual, ldr,
-                           nc_scale, M, K, rows_per_image, act, (char *)out3);
+                           nc_scale, M, K, rows_per_image, act, (char *)out3, (unsigned char *)gates);
     else if (dtype == DASS_BF16)
         hipLaunchKernelGGL(bn_apply_train_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)x, ldx, (bf16_t *)out, ldo, sums, count,
                            gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, (const bf16_t *)residual, ldr,
-                           nc_scale, M, K, rows_per_image, act, (char *)nullptr);
+                           nc_scale, M, K, rows_per_image, act, (char *)nullptr, (unsigned char *)gates);
     else
         return DASS_ERR_UNSUPPORTED;
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
 
-// out == NULL: the activation gate is re-derived from x with gate_scale / gate_shift (f32 only), as dass_bn_bwd_reduce_gate
+// out == NULL: the activation gate is re-derived from x with gate_scale / gate_shift (f32 only), as dass_bn_bwd_reduce_gate;
+// gates != NULL: the gate bits dass_bn_apply_train stored (one byte per 4-channel group) replace both
 extern "C" int dass_bn_bwd_reduce_sums(const void *dout, int64_t lddo, const void *out, int64_t ldo, const void *x, int64_t ldx,
                                        const float *mean, const float *invstd, const float *gate_scale, const float *gate_shift,
-                                       const float *nc_scale, int64_t M, int K, int64_t rows_per_image, int act, double *sums, int dtype,
-                                       void *stream) {
+                                       const float *nc_scale, int64_t M, int K, int64_t rows_per_image, int act, double *sums,
+                                       const void *gates, int dtype, void *stream) {
     if (!dout || !x || !mean || !invstd || !sums || M <= 0 || !ok4(K, lddo, out ? ldo : 4, ldx) || rows_per_image <= 0) return DASS_ERR_ARG;
-    if (!out && (!gate_scale || !gate_shift || dtype != DASS_F32)) return DASS_ERR_ARG;
+    if (!out && !gates && (!gate_scale || !gate_shift || dtype != DASS_F32)) return DASS_ERR_ARG;
+    if (gates && nc_scale) return DASS_ERR_ARG;
     dim3 grid((unsigned)dass_stat_rows(M), (unsigned)((K + 63) / 64));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DASS_F32)
         hipLaunchKernelGGL((colstat_kernel<float, 1>), grid, dim3(256), 0, st, (const float *)x, ldx, (const float *)dout, lddo,
-                           (const float *)out, ldo, mean, invstd, nc_scale, M, K, rows_per_image, act, nullptr, gate_scale, gate_shift, sums);
+                           (const float *)out, ldo, mean, invstd, nc_scale, M, K, rows_per_image, act, nullptr, gate_scale, gate_shift, sums,
+                           (const unsigned char *)gates);
     else if (dtype == DASS_BF16)
         hipLaunchKernelGGL((colstat_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t *)x, ldx, (const bf16_t *)dout, lddo,
-                           (const bf16_t *)out, ldo, mean, invstd, nc_scale, M, K, rows_per_image, act, nullptr, nullptr, nullptr, sums);
+                           (const bf16_t *)out, ldo, mean, invstd, nc_scale, M, K, rows_per_image, act, nullptr, nullptr, nullptr, sums,
+                           (const unsigned char *)gates);
     else
         return DASS_ERR_UNSUPPORTED;
     DASS_LAUNCH_CHECK();
@@ -655,11 +681,12 @@ extern "C" int dass_bn_bwd_apply_sums(const void *dout, int64_t lddo, const void
                                       const float *mean, const float *invstd, const float *gamma, const double *sums, float *dbeta_out,
                                       float *dgamma_out, const float *gate_scale, const float *gate_shift, const float *nc_scale,
                                       void *dx, int64_t lddx, void *dres, int64_t lddr, int64_t M, int K, int64_t rows_per_image,
-                                      double count, int act, int dtype, void *dx3, void *stream) {
+                                      double count, int act, const void *gates, int dtype, void *dx3, void *stream) {
     if (!dout || !x || !dx || !mean || !invstd || !sums || count <= 0 || M <= 0 || !ok4(K, lddo, out ? ldo : 4, ldx, lddx) ||
         rows_per_image <= 0)
         return DASS_ERR_ARG;
-    if (!out && (!gate_scale || !gate_shift || dtype != DASS_F32)) return DASS_ERR_ARG;
+    if (!out && !gates && (!gate_scale || !gate_shift || dtype != DASS_F32)) return DASS_ERR_ARG;
+    if (gates && nc_scale) return DASS_ERR_ARG;
     if (dres && lddr % 4) return DASS_ERR_ARG;
     if (dx3 && (dtype != DASS_F32 || ((uintptr_t)dx3 & 15))) return DASS_ERR_ARG;
     const int grid = dass_grid_1d(M * (K / 4), 256);
@@ -669,12 +696,12 @@ extern "C" int dass_bn_bwd_apply_sums(const void *dout, int64_t lddo, const void
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)dout, lddo, (const float *)out, ldo,
                            (const float *)x, ldx, mean, invstd, gamma, (const float *)nullptr, (const float *)nullptr, nc_scale, (float *)dx,
                            lddx, (float *)dres, lddr, M, K, rows_per_image, inv_count, 1, act, gate_scale, gate_shift, (char *)dx3, sums,
-                           dbeta_out, dgamma_out);
+                           dbeta_out, dgamma_out, (const unsigned char *)gates);
     else if (dtype == DASS_BF16)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)dout, lddo, (const bf16_t *)out, ldo,
                            (const bf16_t *)x, ldx, mean, invstd, gamma, (const float *)nullptr, (const float *)nullptr, nc_scale,
                            (bf16_t *)dx, lddx, (bf16_t *)dres, lddr, M, K, rows_per_image, inv_count, 1, act, (const float *)nullptr,
-                           (const float *)nullptr, (char *)nullptr, sums, dbeta_out, dgamma_out);
+                           (const float *)nullptr, (char *)nullptr, sums, dbeta_out, dgamma_out, (const unsigned char *)gates);
     else
         return DASS_ERR_UNSUPPORTED;
     DASS_LAUNCH_CHECK();

@@ -328,6 +328,7 @@ def flush_bn_counters():
 
 
 _bn_sum_arena = {"buf": None, "off": 0, "on": os.environ.get("DASS_BN_SUMS", "1") == "1"}
+_BN_GATES = os.environ.get("DASS_BN_GATES", "1") == "1"  # residual layers keep their activation gates as bits for the backward
 
 
 def bn_sums_path(bn, k):
@@ -652,6 +653,7 @@ class _ConvBnAct(torch.autograd.Function):
         state = None
         y_raw = None
         x3_saved = None  # split rows of the input, kept for the weight gradient (dass_conv2d_wgrad_x3)
+        gates = None     # activation gate bits of a residual layer (train-mode BN through the sums path)
         batch_stats = bn is not None and bn_use_batch_stats(bn)
         fuse = (not spec.depthwise) and (not rowtap) and (bn is None or (not batch_stats and not need_grad))
         # pipelined pre-split engine: dense convs of the bf16x6 engine with enough output channels for its tiles
@@ -752,10 +754,14 @@ class _ConvBnAct(torch.autograd.Function):
             if sums is not None:
                 state = BNState(k, dev)
                 mom, rm, rv = _bn_running(bn)
+                if need_grad and res_t is not None and nc_scale is None and spec.act != ACT_NONE and _BN_GATES:
+                    # residual layers cannot re-derive the activation gate from the conv output alone: keep it as one byte
+                    # per 4-channel group, which the backward reads instead of the 16 bytes of `out`
+                    gates = torch.empty((m, k // 4), dtype=torch.uint8, device=dev)
                 check(lib.dass_bn_apply_train(_p(y_raw), k, _p(out), ldo, _p(sums), float(m), _p(bn.weight), _p(bn.bias), _p(rm), _p(rv),
                                               mom, float(bn.eps), _p(state.mean), _p(state.invstd), _p(state.scale), _p(state.shift),
-                                              _p(res_t), ldr or 0, _p(nc_scale), m, k, oh * ow, spec.act, _dt(out), _p(out3), _stream()),
-                      "dass_bn_apply_train")
+                                              _p(res_t), ldr or 0, _p(nc_scale), m, k, oh * ow, spec.act, _dt(out), _p(out3), _p(gates),
+                                              _stream()), "dass_bn_apply_train")
                 _running_stats_written(bn, rm, rv)
             else:
                 scale_shift_act(y_raw, k, out, ldo, m, k, scale, shift, residual=res_t, ldr=ldr or 0,
@@ -779,7 +785,7 @@ class _ConvBnAct(torch.autograd.Function):
                                   state.mean if state is not None else None,
                                   state.invstd if state is not None else None,
                                   state.scale if state is not None else None,
-                                  state.shift if state is not None else None, x3_saved)
+                                  state.shift if state is not None else None, x3_saved, gates)
         if getattr(spec, "fork", False):
             # the input is handed back as a second output: the gradients of both uses of x (this conv and the
             # identity branch of a residual block) then arrive in ONE backward call, where the input-gradient conv adds
@@ -789,7 +795,7 @@ class _ConvBnAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, d_fork=None):
-        xs, weight, gamma, y_raw, out, nc_scale, mean, invstd, bn_scale, bn_shift, x3_in = ctx.saved_tensors
+        xs, weight, gamma, y_raw, out, nc_scale, mean, invstd, bn_scale, bn_shift, x3_in, gates = ctx.saved_tensors
         spec = ctx.spec
         if dout is None:  # only the forked alias of the input was used downstream
             return d_fork, None, None, None, None, None, None, None, None
@@ -837,9 +843,10 @@ class _ConvBnAct(torch.autograd.Function):
             if need_red and ctx.has_bn and ctx.train_stats and getattr(ctx, "bn_sums", False) and ctx.sync_world == 1:
                 # (sum dz, sum dz * xhat) as f64 accumulators: the apply launch reads them, no finalize launch
                 bsums = _bn_sums(k, dev)
-                check(lib.dass_bn_bwd_reduce_sums(_p(dout_r), lddo, _p(None if gate else out), ldo, _p(y_raw), k, _p(mean_v), _p(invstd_v),
+                no_out = gate or gates is not None
+                check(lib.dass_bn_bwd_reduce_sums(_p(dout_r), lddo, _p(None if no_out else out), ldo, _p(y_raw), k, _p(mean_v), _p(invstd_v),
                                                   _p(bn_scale if gate else None), _p(bn_shift if gate else None), _p(nc_scale), m, k,
-                                                  oh * ow, spec.act, _p(bsums), _dt(out), _stream()), "dass_bn_bwd_reduce_sums")
+                                                  oh * ow, spec.act, _p(bsums), _p(gates), _dt(out), _stream()), "dass_bn_bwd_reduce_sums")
                 pg = torch.empty((2, k), dtype=torch.float32, device=dev)
                 dbeta, dgamma = pg[0], pg[1]
             elif need_red:
@@ -872,10 +879,11 @@ class _ConvBnAct(torch.autograd.Function):
                          or (ctx.x3_on and ctx.needs_input_grad[1] and x3_in is not None))):
                 dy3 = x3_alloc_for(m, k, dev)  # dy also as split rows: operand of the input- and weight-gradient launches
             if bsums is not None:
-                check(lib.dass_bn_bwd_apply_sums(_p(dout_r), lddo, _p(None if gate else out), ldo, _p(y_raw), k, _p(mean_v), _p(invstd_v),
-                                                 _p(gamma_v.detach()), _p(bsums), _p(dbeta), _p(dgamma), _p(bn_scale if gate else None),
-                                                 _p(bn_shift if gate else None), _p(nc_scale), _p(dy), lddy, _p(dres), k, m, k, oh * ow,
-                                                 float(m), spec.act, _dt(out), _p(dy3), _stream()), "dass_bn_bwd_apply_sums")
+                check(lib.dass_bn_bwd_apply_sums(_p(dout_r), lddo, _p(None if (gate or gates is not None) else out), ldo, _p(y_raw), k,
+                                                 _p(mean_v), _p(invstd_v), _p(gamma_v.detach()), _p(bsums), _p(dbeta), _p(dgamma),
+                                                 _p(bn_scale if gate else None), _p(bn_shift if gate else None), _p(nc_scale), _p(dy), lddy,
+                                                 _p(dres), k, m, k, oh * ow, float(m), spec.act, _p(gates), _dt(out), _p(dy3), _stream()),
+                      "dass_bn_bwd_apply_sums")
             elif gate:
                 check(lib.dass_bn_bwd_apply_gate(_p(dout_r), lddo, _p(y_raw), k, _p(mean_v), _p(invstd_v), _p(gamma_v.detach()), _p(db), _p(dg),
                                                  _p(bn_scale), _p(bn_shift), _p(nc_scale), _p(dy), lddy, m, k, oh * ow,

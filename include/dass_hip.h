@@ -168,6 +168,10 @@ int dass_bn_rows_bwd(const float *g, const float *x, const float *mean, const fl
  *   dass_bn_bwd_reduce_sums / dass_bn_bwd_apply_sums   the backward pair of dass_bn_bwd_reduce(_gate) / _apply(_gate)
  *                                                  with sums = (sum dz, sum dz * xhat); dbeta_out / dgamma_out get them
  *                                                  rounded to f32.  out == NULL selects the gate-from-x form (f32).
+ *   gates (nullable, uint8 [M][K/4])               dass_bn_apply_train stores the activation gate of every output (bit e of
+ *                                                  byte [m][k/4] = channel k+e passes gradient); the backward pair then
+ *                                                  reads that byte instead of the 16 bytes of `out` (layers with a
+ *                                                  residual cannot re-derive the gate from the conv output alone).
  * Arithmetic is that of the partial-row entry points (f32 inside a tile / slab, f64 across); only the order of the f64
  * additions is unspecified.  K <= 2048 for dass_bn_apply_train (DASS_ERR_UNSUPPORTED beyond). */
 int dass_conv2d_igemm_sums(const void *x, int64_t ldx, const void *w, void *y, int64_t ldy, int N, int H, int W, int C,
@@ -181,16 +185,17 @@ int dass_bn_apply_train(const void *x, int64_t ldx, void *out, int64_t ldo, cons
                         const float *gamma, const float *beta, float *running_mean, float *running_var, float momentum,
                         float eps, float *mean, float *invstd, float *scale, float *shift, const void *residual,
                         int64_t ldr, const float *nc_scale, int64_t M, int K, int64_t rows_per_image, int act, int dtype,
-                        void *out3, void *stream);
+                        void *out3, void *gates, void *stream);
 int dass_bn_bwd_reduce_sums(const void *dout, int64_t lddo, const void *out, int64_t ldo, const void *x, int64_t ldx,
                             const float *mean, const float *invstd, const float *gate_scale, const float *gate_shift,
                             const float *nc_scale, int64_t M, int K, int64_t rows_per_image, int act, double *sums,
-                            int dtype, void *stream);
+                            const void *gates, int dtype, void *stream);
 int dass_bn_bwd_apply_sums(const void *dout, int64_t lddo, const void *out, int64_t ldo, const void *x, int64_t ldx,
                            const float *mean, const float *invstd, const float *gamma, const double *sums,
                            float *dbeta_out, float *dgamma_out, const float *gate_scale, const float *gate_shift,
                            const float *nc_scale, void *dx, int64_t lddx, void *dres, int64_t lddr, int64_t M, int K,
-                           int64_t rows_per_image, double count, int act, int dtype, void *dx3, void *stream);
+                           int64_t rows_per_image, double count, int act, const void *gates, int dtype, void *dx3,
+                           void *stream);
 /* eval-mode BN folded to scale/shift from running stats */
 int dass_bn_eval_scale_shift(const float *gamma, const float *beta, const float *running_mean,
                              const float *running_var, float eps, int K,
