@@ -584,3 +584,26 @@ def test_scoring_kernels_random_sizes():
             r = torch.as_tensor(r).float()
             assert (smap.cpu() - r).abs().max().item() <= 3e-5, (case, mode, n, t, c, h, w)
             assert (smean.cpu() - r.mean(dim=(1, 2))).abs().max().item() <= 3e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 19, 33, 33, 129, 129), (1, 21, 25, 25, 97, 97), (3, 19, 10, 11, 37, 41), (1, 19, 129, 129, 513, 513),
+                                   (2, 5, 7, 9, 25, 30)])
+def test_upsample_argmax_vector_kernel_equals_scalar_kernel(shape):
+    """dass_upsample_argmax takes a four-pixels-per-thread path (16-byte class-vector loads) when the rows are 16-byte
+    aligned and the upsampling factor is >= 3; a 21-float row pitch forces the one-pixel-per-thread kernel.  Same
+    arithmetic per pixel, same first-maximum rule: the votes must be identical, ragged right edge included."""
+    ops = _ops()
+    n, c, ih, iw, oh, ow = shape
+    g = torch.Generator().manual_seed(c * ih + ow)
+    low = torch.randn(n, ih, iw, c, generator=g)
+    low[:, ::3, ::2, 1] = low[:, ::3, ::2, 0]  # exact ties between classes 0 and 1 on a lattice of corners
+    votes = []
+    for pitch in (24, 21):
+        buf = torch.zeros(n, ih, iw, pitch)
+        buf[..., :c] = low
+        x = buf.cuda().permute(0, 3, 1, 2)[:, :c]
+        vt = torch.full((n, 1, oh, ow), 255, dtype=torch.uint8).cuda()
+        ops.upsample_argmax(x, oh, ow, vt, 0)
+        votes.append(vt.cpu())
+    assert torch.equal(votes[0], votes[1])
+    assert int(votes[0].max()) < c
