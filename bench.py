@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--backbone", default="resnet101")
     ap.add_argument("--classes", type=int, default=19)
     ap.add_argument("--mc-steps", type=int, default=10, help="T of the MC-dropout scoring leg")
+    ap.add_argument("--mc-batch", type=int, default=0, help="images per scoring forward (0 = --batch, what the reference's driver passes to its selectors)")
     ap.add_argument("--mc-batches", type=int, default=47, help="timed scoring batches per rank (47 x 8 = 376 >= config D's 372 per GPU)")
     ap.add_argument("--no-coreset", action="store_true")
     ap.add_argument("--no-pool-reader", action="store_true")
@@ -258,7 +259,8 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
     res["coreset"] = None
     if not args.no_mc:
         model.eval()
-        pool_keys = [("pool_%06d" % i).encode("ascii") for i in range(world * args.mc_batches * b)]
+        b_train, b = b, (args.mc_batch or b)
+        pool_keys = [("pool_%06d" % i).encode("ascii") for i in range(world * args.mc_batches * b_train)]
         # this rank's shard, resident in HBM before timing (per-image seeds: content independent of sharding)
         s0, s1 = shard_bounds(len(pool_keys), rank, world)
         shard = {}
@@ -284,7 +286,7 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
         if rank == 0:
             log("[%s] mc-dropout T=%d: %.2f pool images/s (%d images)" % (dtype_name, args.mc_steps, pool_ips, len(pool_keys)))
         res["mc"] = {"metric": "mc_dropout_pool_images_per_s", "value": round(pool_ips, 3), "unit": "images/s",
-                     "T": args.mc_steps, "pool_images": len(pool_keys), "seconds": round(dts, 4), "selected": len(selected),
+                     "T": args.mc_steps, "pool_images": len(pool_keys), "scoring_batch": b, "seconds": round(dts, 4), "selected": len(selected),
                      "frac_of_mfma_peak": round(pool_ips * MC_GFLOP_PER_IMAGE / 1e3 / (MFMA_PEAK_TFLOPS[engine] * world), 4),
                      "sharding": "contiguous key shards per rank + RCCL all_gather of per-image scores" if world > 1 else "single rank"}
 
@@ -325,6 +327,7 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
                               "selection_2975_pool_seconds_at_this_gpu_count": round(2975.0 / feat_ips + dtk, 3),
                               "frac_of_mfma_peak": round(feat_ips * 142.5 / 1e3 / (MFMA_PEAK_TFLOPS[engine] * world), 4)}
 
+    b = args.batch  # (the scoring legs may have used --mc-batch)
     # ------------------------------------------------------------------ roofline of the dominant kernel
     res["roofline"] = None
     if rank == 0 and not args.no_roofline:
