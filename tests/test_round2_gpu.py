@@ -323,3 +323,44 @@ def test_bn_sums_path_equals_partial_row_path(shape, residual):
             continue
         b = runs[True][key]
         assert (a - b).abs().max().item() <= 2e-6 * max(a.abs().max().item(), 1e-3), key
+
+
+def test_train_score_train_score_loop_keeps_caches_coherent():
+    """the active-learning loop alternates training steps (HIP SGD writes weights and BN running statistics through raw
+    pointers) with eval-mode pool scoring (cached split-weight operands, eval-BN vectors, per-tensor split rows, the
+    decoder's hoisted first-conv operands).  After every phase change a deep copy of the model -- new parameter objects, no
+    cache entry can match -- must produce bit-identical MC-dropout votes and logits."""
+    import copy
+
+    ops, O, S = _setup()
+    from dass_hip.optim import SGD
+    from models.deeplab import DeepLab
+    from utils.loss import SegmentationLosses
+
+    ops.set_f32_mma("bf16x6")
+    ncls, n, hw, T = 19, 2, 65, 3
+    torch.manual_seed(3)
+    pm = DeepLab(backbone="resnet", output_stride=16, num_classes=ncls, sync_bn=False, pretrained=False).cuda()
+    opt = SGD([{"params": pm.get_1x_lr_params(), "lr": 0.01}, {"params": pm.get_10x_lr_params(), "lr": 0.1}], momentum=0.9, weight_decay=5e-4)
+    crit = SegmentationLosses(cuda=True).build_loss("ce")
+    x, lab = O.synthetic_batch(n, hw, hw, ncls, first_index=77)
+    x, lab = x.cuda(), lab.cuda()
+    g = torch.Generator().manual_seed(5)
+    m1 = (torch.rand(T, n, 256, generator=g) >= 0.5).float() * 2.0
+    m2 = (torch.rand(T, n, 256, generator=g) >= 0.1).float() / 0.9
+    seen = []
+    for phase in range(3):
+        pm.train()
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            crit(pm(x), lab).backward()
+            opt.step()
+        pm.eval()
+        fresh = copy.deepcopy(pm)
+        with torch.no_grad():
+            v = pm.mc_dropout_votes(x, T, masks=(m1, m2))
+            assert torch.equal(v, fresh.mc_dropout_votes(x, T, masks=(m1, m2))), phase
+            lg = pm(x).float()
+            assert torch.equal(lg, fresh(x).float()), phase
+        seen.append(lg.cpu())
+    assert not torch.equal(seen[0], seen[2]), "the training steps must move the model for this test to mean anything"
