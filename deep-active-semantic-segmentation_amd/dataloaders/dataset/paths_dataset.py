@@ -138,7 +138,9 @@ def pool_loader(env, paths, crop_size, include_labels, batch_size, workers=4, ah
                 made[0] += 1
                 slot = (torch.empty(rec.shape, dtype=torch.uint8, pin_memory=True), torch.cuda.Event())
             else:
-                slot = free.get()
+                # cannot happen while at most (ahead + 1) batches are staged or in flight; never block a fetch thread on the
+                # consumer (an abandoned generator would leave the pool's shutdown waiting): stage this frame unpinned
+                return torch.from_numpy(rec), None
         buf, ev = slot
         if tuple(buf.shape) != tuple(rec.shape):  # a frame of another size: stage it unpinned
             free.put(slot)
