@@ -86,8 +86,21 @@ class Decoder(nn.Module):
             ops.conv_launch(xb, ldb, wb, yb, 256, (n, h, w, 48, h, w, 256, 3, 3, 1, 1, 1), scale=st.scale)
         return wa, st, yb
 
-    def head_mc_pass(self, feats, prep, m1, m2):
-        """one stochastic pass of last_conv: masks m1 (ASPP Dropout2d, [N,256]) and m2 (last_conv[6]) folded into loaders"""
+    def head_mc_pack(self, prep, masks1):
+        """the Dropout2d-sparse operands of ALL T passes in two launches: masks1 [T, N, 256] -> per pass (order, limit,
+        per-image weight copies); None when the sparse pre-split path is off"""
+        if not (ops.x3_pipeline() and ops.mc_sparse()):
+            return None
+        wa = prep[0]
+        t, n, c = masks1.shape
+        order, lim = ops.dropout_pack(masks1.reshape(t * n, c))
+        wan = ops.w3_pack_per_image(wa, 256 * 9, 256, order, lim)
+        per = wan.numel() // t
+        return [(order[i * n:(i + 1) * n], lim[i * n:(i + 1) * n], wan[i * per:(i + 1) * per]) for i in range(t)]
+
+    def head_mc_pass(self, feats, prep, m1, m2, packed=None):
+        """one stochastic pass of last_conv: masks m1 (ASPP Dropout2d, [N,256]) and m2 (last_conv[6]) folded into loaders;
+        packed: this pass's entry of head_mc_pack (else the operands are packed here)"""
         import torch
 
         wa, st, yb = prep
@@ -105,9 +118,12 @@ class Decoder(nn.Module):
             m1 = m1.contiguous()
             h1_3 = ops.x3_alloc(m, 256, feats.device)
             if ops.mc_sparse():
-                order, lim = ops.dropout_pack(m1)
+                if packed is not None:
+                    order, lim, wan = packed
+                else:
+                    order, lim = ops.dropout_pack(m1)
+                    wan = ops.w3_pack_per_image(wa, 256 * 9, 256, order, lim)
                 xa3 = ops.split3_rows_packed(xa, lda, m, 256, m1, order, lim, h * w)
-                wan = ops.w3_pack_per_image(wa, 256 * 9, 256, order, lim)
                 ops.conv_x3_per_image_launch(xa3, wan, lim, None, 0, dims, y3=h1_3, scale=st.scale, shift=st.shift, residual=yb,
                                              ldr=256, act=ops.ACT_RELU)
             else:

@@ -114,10 +114,12 @@ class DeepLab(nn.Module):
             # all T x 2 Bernoulli draws in one launch sequence (8 tiny kernels per pass otherwise: ~40 us of a 1.4 ms pass)
             draws = torch.rand((2, steps, n, 256), device=dev, generator=generator)
             masks = ((draws[0] >= p1).to(torch.float32) * (1.0 / (1.0 - p1)), (draws[1] >= p2).to(torch.float32) * (1.0 / (1.0 - p2)))
+        masks = (masks[0].to(dev).float().contiguous(), masks[1].to(dev).float().contiguous())
+        packs = self.decoder.head_mc_pack(prep, masks[0][:steps]) if prep is not None else None
         for t in range(steps):
-            m1, m2 = masks[0][t].to(dev).float(), masks[1][t].to(dev).float()
+            m1, m2 = masks[0][t], masks[1][t]
             if prep is not None:
-                low_res = self.decoder.head_mc_pass(feats, prep, m1, m2)
+                low_res = self.decoder.head_mc_pass(feats, prep, m1, m2, packs[t] if packs is not None else None)
             else:
                 low_res = self.decoder.head(feats, in_scale=torch.cat((m1, ones48), dim=1), mask_as_in_scale=m2)
             ops.upsample_argmax(low_res, hh, ww, votes, t)
