@@ -26,7 +26,9 @@ only by summation order, and the roofline peak is priced accordingly (2500 / 6 T
                 actually holds under an all-CU MFMA load (profiles/r02_clock_probe.json),
   cpu_baseline: the CPU oracle (stock PyTorch fp32 restatement, oracle/) timed on this box's host cores on bounded
                 samples (rank 0, N=1 only): (i) train steps, (ii) 10-pass MC-dropout the reference way (T full forwards)
-                and with the deterministic prefix hoisted, (iii) core-set features + sklearn fp64 k-center,
+                and with the deterministic prefix hoisted, (iii) core-set features + sklearn fp64 k-center on the SAME
+                [2975, 2736] matrix as the GPU leg (`core_set.kcenter.picks_equal_sklearn_on_same_matrix`), (iv) BASELINE
+                config 0 (U-Net 128x128 batch 2, 3 SGD steps, CPU only),
   f32_mfma_mode: the same legs with the convs on v_mfma_f32_32x32x2_f32 (the plain f32 fma chain), for comparison,
   bf16_perf_mode: the same legs with bf16 storage / f32 accumulate (NOT parity-grade: deviation from the
                 f32 reference is measured in tests/test_bf16_gpu.py), reported for information only.
@@ -286,7 +288,10 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
         if rank == 0:
             log("[%s] mc-dropout T=%d: %.2f pool images/s (%d images)" % (dtype_name, args.mc_steps, pool_ips, len(pool_keys)))
         res["mc"] = {"metric": "mc_dropout_pool_images_per_s", "value": round(pool_ips, 3), "unit": "images/s",
-                     "T": args.mc_steps, "pool_images": len(pool_keys), "scoring_batch": b, "seconds": round(dts, 4), "selected": len(selected),
+                     "T": args.mc_steps, "pool_images": len(pool_keys),
+                     "pool_note": "per-rank pool = config D's 8-GPU share (2975 / 8 = 372, rounded up to whole batches); throughput is per image, "
+                                  "so one GPU scores the whole 2975-image pool in 2975 / value seconds",
+                     "scoring_batch": b, "seconds": round(dts, 4), "selected": len(selected),
                      "frac_of_mfma_peak": round(pool_ips * MC_GFLOP_PER_IMAGE / 1e3 / (MFMA_PEAK_TFLOPS[engine] * world), 4),
                      "sharding": "contiguous key shards per rank + RCCL all_gather of per-image scores" if world > 1 else "single rank"}
 
@@ -308,9 +313,8 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
             barrier()
             dtf = tmax(time.perf_counter() - t0)
             # the greedy selection at the full pool size (2975 x 2736, 50 already selected, k = 125: the authors' setting)
-            gk = torch.Generator().manual_seed(5)
-            full = torch.randn(2975, 2736, generator=gk).to(dev)
-            full[: feats.shape[0]] = feats[: min(2975, feats.shape[0])]
+            # -- on the SAME matrix the CPU leg hands to sklearn (kcenter_matrix), so the two pick lists can be compared
+            full = torch.from_numpy(kcenter_matrix()).to(dev)
             ops.kcenter_greedy(full, list(range(50)), 4)      # warm-up
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -323,6 +327,7 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
             res["coreset"] = {"metric": "core_set_feature_images_per_s", "value": round(feat_ips, 2), "unit": "images/s",
                               "pool_images": len(pool_keys), "feature_seconds": round(dtf, 4),
                               "kcenter": {"n": 2975, "d": 2736, "preselected": 50, "k": 125, "seconds": round(dtk, 4),
+                                          "picks": [int(i) for i in picks.tolist()],
                                           "hbm_gb_per_s": round(175 * 2975 * 2736 * 4 / dtk / 1e9, 1)},
                               "selection_2975_pool_seconds_at_this_gpu_count": round(2975.0 / feat_ips + dtk, 3),
                               "frac_of_mfma_peak": round(feat_ips * 142.5 / 1e3 / (MFMA_PEAK_TFLOPS[engine] * world), 4)}
@@ -400,6 +405,14 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
     return res
 
 
+def kcenter_matrix():
+    """config E's selection input at full size: [2975, 2736] f32, non-negative like the pooled post-ReLU decoder features
+    (the same array for the GPU loop and for sklearn, so that their pick lists are comparable)"""
+    import numpy as np
+
+    return np.abs(np.random.RandomState(5).randn(2975, 2736)).astype(np.float32)
+
+
 def pool_reader_leg(args, dev):
     """1024 x 2048 Cityscapes-shaped records (pickled uint8 [H, W, 4], the LMDB wire format) -> normalised
     513 x 513 crops + labels on the GPU through dataloaders.dataset.paths_dataset.pool_loader (unpickle, 8 MB host->device
@@ -465,8 +478,10 @@ def cpu_baseline(args):
     except AttributeError:
         cores = os.cpu_count() or 1
     cores_box = cores
-    cores = max(1, min(cores, 16))
-    log("cpu baseline on %d of the box's %d usable cores (host reports %s) ..." % (cores, cores_box, os.cpu_count()))
+    # stock PyTorch's intra-op pool stops scaling long before 256 threads on these layer sizes: the train leg is timed with 16
+    # threads and with min(available, 64), the better figure is `value` (with its thread count in `cores`), both are kept
+    cores_small, cores = max(1, min(cores, 16)), max(1, min(cores, 64))
+    log("cpu baseline on %d / %d of the box's %d usable cores (host reports %s) ..." % (cores_small, cores, cores_box, os.cpu_count()))
     torch.set_num_threads(cores)
     s = args.size
     om = O.ODeepLab(args.backbone, 16, args.classes)
@@ -483,13 +498,23 @@ def cpu_baseline(args):
         oopt.step()
 
     cpu_step()  # untimed: oneDNN primitive creation
-    nsteps, t0 = 0, time.perf_counter()
-    while nsteps < 12 and time.perf_counter() - t0 < 12.0:  # ~10-20 s of CPU work
+    by_threads = {}
+    for nthreads in sorted({cores_small, cores}):
+        torch.set_num_threads(nthreads)
         cpu_step()
-        nsteps += 1
-    dtc = time.perf_counter() - t0
+        nsteps, t0 = 0, time.perf_counter()
+        while nsteps < 8 and time.perf_counter() - t0 < 8.0:  # ~8 s of CPU work per thread count
+            cpu_step()
+            nsteps += 1
+        dtc = time.perf_counter() - t0
+        by_threads[nthreads] = (2 * nsteps / dtc, nsteps, dtc)
+        log("cpu train leg, %d threads: %.3f images/s" % (nthreads, 2 * nsteps / dtc))
+    cores = max(by_threads, key=lambda t: by_threads[t][0])
+    _, nsteps, dtc = by_threads[cores]
+    torch.set_num_threads(cores)
     out = {"value": round(2 * nsteps / dtc, 4), "unit": "images/s", "cores": cores, "cores_available": cores_box,
            "cores_host": os.cpu_count(), "kind": "port",
+           "by_threads": {str(t): round(v[0], 4) for t, v in by_threads.items()},
            "sample": "%d train steps (fwd+CE+bwd+SGD) of batch 2 = %d images, %s %dx%d, stock PyTorch CPU fp32 "
                      "(oracle/deeplab_cpu.py), %.1f s" % (nsteps, 2 * nsteps, args.backbone, s, s, dtc)}
     del oopt
@@ -527,12 +552,25 @@ def cpu_baseline(args):
         om.return_features = False
     import numpy as np
 
-    full = np.random.RandomState(5).randn(2975, 2736)
+    full = kcenter_matrix().astype(np.float64)
     t0 = time.perf_counter()
-    S.kcenter_greedy(full, list(range(50)), 125)
+    cpu_picks, _ = S.kcenter_greedy(full, list(range(50)), 125)
     dtk = time.perf_counter() - t0
-    out["core_set"] = {"feature_images_per_s": round(nimg / dtf, 4), "kcenter_seconds": round(dtk, 3),
+    out["core_set"] = {"feature_images_per_s": round(nimg / dtf, 4), "kcenter_seconds": round(dtk, 3), "kcenter_picks": [int(i) for i in cpu_picks],
                        "sample": "%d images of feature extraction in %.1f s; sklearn pairwise_distances fp64 k-center, k=125 on 2975x2736" % (nimg, dtf)}
+    # ---- (iv) BASELINE config 0: U-Net(3,4) 128x128 batch 2, 3 SGD steps, stock PyTorch on the CPU (the reference's train.py
+    # plumbing case; oracle/unet_cpu.py pinned against models/unet.py by tests/golden/unet_config0.npz) -- loss must decrease
+    from oracle import unet_cpu as U
+
+    torch.manual_seed(1234)
+    net = U.OUNet(3, 4)
+    U.config0_steps(U.OUNet(3, 4), steps=1)  # warm-up on a throw-away copy
+    t0 = time.perf_counter()
+    losses = U.config0_steps(net, steps=3, lr=0.01)
+    dtu = time.perf_counter() - t0
+    out["config0_unet"] = {"value": round(6 / dtu, 3), "unit": "images/s", "losses": [round(v, 6) for v in losses],
+                           "loss_decreases": bool(losses[2] < losses[0]), "cores": cores,
+                           "sample": "3 SGD steps of batch 2, U-Net(3,4) 128x128, %.2f s" % dtu}
     return out
 
 
@@ -574,6 +612,15 @@ def main():
     if env.rank == 0 and env.world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
 
+    if cpu is not None and head["coreset"] is not None:
+        # config E parity at full size: the device k-center loop and sklearn's saw the same matrix
+        gpu_picks = head["coreset"]["kcenter"].pop("picks")
+        head["coreset"]["kcenter"]["picks_equal_sklearn_on_same_matrix"] = gpu_picks == cpu["core_set"].pop("kcenter_picks")
+    elif head["coreset"] is not None:
+        head["coreset"]["kcenter"].pop("picks", None)
+    for other in others.values():
+        if other["coreset"] is not None:
+            other["coreset"]["kcenter"].pop("picks", None)
     if env.rank == 0:
         b, s, world = args.batch, args.size, env.world
         line = {"metric": "train_images_per_s (DeepLab-v3+ R101 513x513; + mc_dropout pool-images/s in 'mc_dropout')",

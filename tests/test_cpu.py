@@ -508,3 +508,58 @@ def test_global_batch_loss_world2_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "rank 0 loss ok" in outs[0] and "rank 1 loss ok" in outs[1]
+
+
+# ----------------------------------------------------------------------------- round 3: reference-EXECUTED selector fixtures, config 0
+def test_oracle_selectors_match_reference_execution():
+    """tests/golden/selectors_ref.npz holds what ceal.py:19-166, mc_dropout.py:173-196 and core_set.py:40-69 RETURNED when
+    run as written (oracle/make_goldens_r3.py); the oracle's restatement must give the same selections"""
+    g = np.load(os.path.join(GOLD, "selectors_ref.npz"))
+    ncls, n, hw = 19, 10, 65
+    om = O.ODeepLab("mobilenet", 16, ncls)
+    O.fill_state_dict(om, seed=51)
+    om.eval()
+    x, lab = O.synthetic_batch(n, hw, hw, ncls, first_index=300)
+    with torch.no_grad():
+        logits = om(x)
+    conf, margin, ent = (m.mean(dim=(1, 2)).tolist() for m in S.softmax_score_maps(logits, lab, ncls))
+    idx = list(range(n))
+    assert S.select_top(conf, idx, n, reverse=False) == list(g["ceal_conf_order"])
+    assert S.select_top(margin, idx, n, reverse=False) == list(g["ceal_margin_order"])
+    assert S.select_top(ent, idx, n, reverse=True) == list(g["ceal_entropy_order"])
+    assert np.abs(np.asarray(ent) - g["ceal_entropies"]).max() <= 1e-5
+    weak_idx = [i for i in idx if g["ceal_entropies"][i] < float(g["ceal_threshold"])]
+    assert weak_idx == list(g["ceal_weak_index"])
+    wl = S.weak_label_maps(logits, lab, ncls)
+    for j, i in enumerate(weak_idx):
+        assert (wl[i] != g["ceal_weak_labels"][j]).mean() <= 1e-4
+    # MC-dropout, T = 4, the masks of the reference run
+    n, T = 6, 4
+    om = O.ODeepLab("mobilenet", 16, ncls)
+    O.fill_state_dict(om, seed=52)
+    om.eval()
+    x, lab = O.synthetic_batch(n, hw, hw, ncls, first_index=340)
+    votes = S.mc_votes(om, x, O.dropout_masks(n, T, seed=77))
+    assert (votes.numpy() != g["mc_votes"]).mean() <= 1e-4
+    scores = [float(e.mean()) for e in S.vote_entropy_maps(torch.from_numpy(g["mc_votes"]).long(), lab, ncls)]
+    assert S.select_top(scores, list(range(n)), n, reverse=True) == list(g["mc_order"])
+    assert np.abs(np.asarray(scores) - g["mc_scores"]).max() <= 1e-6
+
+
+def test_config0_unet_oracle_matches_reference_fixture():
+    """BASELINE config 0 (U-Net(3,4), 128 x 128, batch 2, CPU): the oracle module, initialised from the same seed as the
+    reference's, reproduces the reference's eval logits and its 3-step SGD loss trajectory; the loss decreases"""
+    from oracle import unet_cpu as U
+
+    g = np.load(os.path.join(GOLD, "unet_config0.npz"))
+    torch.manual_seed(int(g["init_seed"]))
+    net = U.OUNet(3, 4)
+    assert sum(p.numel() for p in net.parameters()) == int(g["n_params"])
+    x, _ = U.config0_batch()
+    net.eval()
+    with torch.no_grad():
+        rows = net(x)[:, :, ::16, ::16].numpy()
+    assert np.abs(rows - g["logit_rows"]).max() <= 1e-5 * max(1.0, np.abs(g["logit_rows"]).max())
+    losses = U.config0_steps(net, steps=3, lr=0.01)
+    assert np.abs(np.asarray(losses) - g["losses"]).max() <= 1e-5
+    assert losses[2] < losses[0]
