@@ -47,9 +47,10 @@ import torch  # noqa: E402
 
 # MI355X_MICROARCH.md dense peaks, per ALGORITHMIC flop of each conv engine: the split engines execute 6 (3) bf16
 # MFMA products per f32 product, so their ceiling in algorithmic TFLOP/s is the bf16 peak / 6 (/ 3)
-MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16x6": 2500.0 / 6, "bf16x3": 2500.0 / 3, "bf16": 2500.0}
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16x6": 2500.0 / 6, "bf16x3": 2500.0 / 3, "f16x3": 2500.0 / 3, "bf16": 2500.0}
 PEAK_NOTE = {"f32": "f32 MFMA dense", "bf16x6": "bf16 MFMA dense 2500 / 6 products per f32 product",
-             "bf16x3": "bf16 MFMA dense 2500 / 3 products per f32 product", "bf16": "bf16 MFMA dense"}
+             "bf16x3": "bf16 MFMA dense 2500 / 3 products per f32 product",
+             "f16x3": "f16 MFMA dense 2500 / 3 products per f32 product (two scaled f16 parts per operand)", "bf16": "bf16 MFMA dense"}
 TRAIN_GFLOP_PER_IMAGE = 556.9  # 3 x 92.81 GMAC x 2 (R101 os16 513^2)
 MC_GFLOP_PER_IMAGE = 573.6     # 2 x (71.26 + 10 x 21.55) GMAC, T=10
 
@@ -69,8 +70,9 @@ def parse():
     ap.add_argument("--no-coreset", action="store_true")
     ap.add_argument("--no-pool-reader", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="headline mode (f32 = parity mode)")
-    ap.add_argument("--f32-mma", default="bf16x6", choices=["bf16x6", "f32", "bf16x3"],
-                    help="conv engine of the f32 headline (bf16x6 = exact three-way split, the default parity engine)")
+    ap.add_argument("--f32-mma", default=os.environ.get("DASS_F32_MMA", "f16x3"), choices=["f16x3", "bf16x6", "f32", "bf16x3"],
+                    help="conv engine of the f32 headline (f16x3 = two scaled f16 parts per operand, three products: the default parity "
+                         "engine; bf16x6 = three bf16 parts, six products)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mc", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -153,16 +155,21 @@ def conv_aggregate(args, ops, tdt):
         dy = torch.randn((n, oh, ow, k), device=dev).to(tdt)
         dx = torch.empty((n, h, w, c), device=dev, dtype=tdt)
         dw = torch.empty((k, ks, ks, c), device=dev)
-        wop = ops.prepare_conv_weight(wt.to(tdt) if tdt != torch.float32 else wt)
-        wop_t = ops.prepare_conv_weight((wt.permute(3, 1, 2, 0).flip(1, 2).contiguous()).to(tdt) if tdt != torch.float32
-                                        else wt.permute(3, 1, 2, 0).flip(1, 2).contiguous())
         stream = ops._stream()
         pad_t = dil * (ks - 1) - pad
-        # the engine the train step uses for this layer (DASS_X3=select: pre-split kernels on the long 3x3 reductions; the
-        # forward then pays the conversion pass of its input, the input gradient gets dy's split rows from the BN backward)
+        # the engine the train step uses for this layer (bf16x6, DASS_X3=select: pre-split kernels on the long 3x3 reductions, the
+        # forward pays the conversion pass of its input, dy's split rows come out of the BN backward; f16x3: pre-split kernels on
+        # every dense layer, both operands of all three launches written by the BN passes -- no conversion pass in the step)
         x3_fwd = tdt == torch.float32 and ops._x3_train_layer(ks * ks, c) and k > 32
         x3_dg = tdt == torch.float32 and ops._x3_train_layer(ks * ks, k) and c > 32
-        if x3_fwd:
+        x3_wg = x3_fwd and ops.x3_pipeline(training=True)
+        wop = ops.prepare_conv_weight(wt.to(tdt) if tdt != torch.float32 else wt, x3=x3_fwd)
+        wop_t = ops.prepare_conv_weight((wt.permute(3, 1, 2, 0).flip(1, 2).contiguous()).to(tdt) if tdt != torch.float32
+                                        else wt.permute(3, 1, 2, 0).flip(1, 2).contiguous(), x3=x3_dg)
+        if x3_fwd and ops.x3_parts() == 2:
+            x3_ = ops.split3_rows(x, c, n * h * w, c)      # (written by the producer's BN-apply pass in the step)
+            tot["fwd"] += cnt * timeit(lambda: ops.conv_x3_launch(x3_, wop, y, k, (n, h, w, c, oh, ow, k, ks, ks, st, pad, dil)))
+        elif x3_fwd:
             tot["fwd"] += cnt * timeit(lambda: ops.conv_x3_launch(ops.split3_rows(x, c, n * h * w, c), wop, y, k,
                                                                    (n, h, w, c, oh, ow, k, ks, ks, st, pad, dil)))
         else:
@@ -174,8 +181,14 @@ def conv_aggregate(args, ops, tdt):
         else:
             tot["dgrad"] += cnt * timeit(lambda: check(lib.dass_conv2d_igemm(ops._p(dy), k, ops._p(wop_t), ops._p(dx), c, None, None, None, 0, None,
                                                                             n, oh, ow, k, h, w, c, ks, ks, 1, pad_t, dil, st, 0, ops._cdt(dx), stream), "dgrad"))
-        tot["wgrad"] += cnt * timeit(lambda: check(lib.dass_conv2d_wgrad(ops._p(x), c, ops._p(dy), k, ops._p(dw), n, h, w, c, oh, ow, k, ks, ks,
-                                                                        st, pad, dil, ops._cdt(dy), stream), "wgrad"))
+        if x3_wg:
+            x3w, dy3w = ops.split3_rows(x, c, n * h * w, c), ops.split3_rows(dy, k, n * oh * ow, k)
+            tot["wgrad"] += cnt * timeit(lambda: check(lib.dass_conv2d_wgrad_x3(ops._p(x3w), ops._p(dy3w), ops._p(dw), n, h, w, c, oh, ow, k, ks, ks,
+                                                                               st, pad, dil, 1, stream), "wgrad_x3"))
+            del x3w, dy3w
+        else:
+            tot["wgrad"] += cnt * timeit(lambda: check(lib.dass_conv2d_wgrad(ops._p(x), c, ops._p(dy), k, ops._p(dw), n, h, w, c, oh, ow, k, ks, ks,
+                                                                            st, pad, dil, ops._cdt(dy), stream), "wgrad"))
         gflop += cnt * 2.0 * n * oh * ow * k * ks * ks * c / 1e9
     ms = tot["fwd"] + tot["dgrad"] + tot["wgrad"]
     return {"ms_per_step": round(ms, 3), "fwd_ms": round(tot["fwd"], 3), "dgrad_ms": round(tot["dgrad"], 3), "wgrad_ms": round(tot["wgrad"], 3),
@@ -342,8 +355,8 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
         w = (torch.randn((k_, 3, 3, c_), device=dev) * 0.02).to(tdt)
         y = torch.empty((n_, h_, h_, k_), device=dev, dtype=tdt)
         dims = (n_, h_, h_, c_, h_, h_, k_, 3, 3, 1, 1, 1)
-        w = ops.prepare_conv_weight(w)  # bf16x6 multiplies pre-split weights (once per optimizer step in training)
         x3_best = tdt == torch.float32 and ops._x3_train_layer(9, c_)  # this layer runs on the pre-split kernel in the train step
+        w = ops.prepare_conv_weight(w, x3=x3_best)  # the split engines multiply pre-split weights (once per optimizer step in training)
         if x3_best:
             x3_ = ops.split3_rows(x, c_, n_ * h_ * h_, c_)
             launch = lambda: ops.conv_x3_launch(x3_, w, y, k_, dims)  # noqa: E731
@@ -369,7 +382,7 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
         if os.path.exists(tfile):  # HBM bytes per launch from the rocprofv3 --pmc passes (collected offline, see profiles/)
             traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
         kname = {"f32": "float,128,128,2,2", "bf16": "bf16,128,128,2,2", "bf16x6": "float,128,128,4,1,split=3",
-                 "bf16x3": "float,128,128,2,2,split=2"}[engine]
+                 "bf16x3": "float,128,128,2,2,split=2", "f16x3": "float,128,128,4,1,split=3"}[engine]
         if x3_best:
             kname_full = "conv_x3_kernel<256,128,4,2,2> + fix-up, pre-split operands (3x3 304->256 @%dx%d, batch %d)" % (h_, h_, n_)
         else:
@@ -385,7 +398,7 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
         cfile = os.path.join(ROOT, "profiles", "r02_clock_probe.json")
         if os.path.exists(cfile) and engine != "f32":
             cp = json.load(open(cfile))
-            div = {"bf16x6": 6.0, "bf16x3": 3.0, "bf16": 1.0}[engine]
+            div = {"bf16x6": 6.0, "bf16x3": 3.0, "f16x3": 3.0, "bf16": 1.0}[engine]
             speak = cp["sustained_bf16_mfma_peak_tflops"] / div
             sustained = {"clock_ghz": cp["sustained_clock_ghz_all_cus_lds_fed"], "peak": round(speak, 1),
                          "frac": round(agg["achieved"] / speak, 4), "best_launch_frac": round(achieved / speak, 4),

@@ -29,7 +29,8 @@ __global__ __launch_bounds__(256) void colstat_kernel(const T *__restrict__ x, l
                                                       const float *__restrict__ gate_shift = nullptr,
                                                       double *__restrict__ sums = nullptr,
                                                       const unsigned char *__restrict__ gates = nullptr) {
-    __shared__ float red[2][16][64 + 1];
+    __shared__ float red[3][16][64 + 1];
+    f32x4 gm4 = {0.f, 0.f, 0.f, 0.f};  // per-channel max |dz| of this thread's rows (MODE 1 with sums)
     const int tid = threadIdx.x;
     const int cx = tid & 15, ry = tid >> 4;
     const int k = blockIdx.y * 64 + cx * 4;
@@ -70,6 +71,8 @@ __global__ __launch_bounds__(256) void colstat_kernel(const T *__restrict__ x, l
                 }
                 s0 += g;
                 s1 += g * ((xv - mu) * is);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gm4[e] = fmaxf(gm4[e], fabsf(g[e]));
             }
         }
     }
@@ -78,7 +81,24 @@ __global__ __launch_bounds__(256) void colstat_kernel(const T *__restrict__ x, l
         red[0][ry][cx * 4 + e] = s0[e];
         red[1][ry][cx * 4 + e] = s1[e];
     }
+    if (MODE == 1 && sums) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[2][ry][cx * 4 + e] = gm4[e];
+    }
     __syncthreads();
+    if (MODE == 1 && sums && tid >= 128 && tid < 192) {
+        // per-channel max |dz| -> the K floats behind the 2K f64 sums (an atomic max on the bit patterns of non-negative
+        // floats): dass_bn_bwd_apply_sums derives the bound of dx from them when it emits dx in the two-part x3 format
+        const int c = tid - 128, kk = blockIdx.y * 64 + c;
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a = fmaxf(a, red[2][i][c]);
+        if (kk < K) {
+            if (!(a >= 0.f)) a = __uint_as_float(0x7f800000u);  // NaN: an infinite bound
+            unsigned *slot = reinterpret_cast<unsigned *>(sums + 2 * (long)K) + kk;
+            if (__float_as_uint(a) > *reinterpret_cast<volatile unsigned *>(slot)) atomicMax(slot, __float_as_uint(a));  // (a max only grows)
+        }
+    }
     if (tid < 128) {
         const int which = tid >> 6, c = tid & 63;
         float a = 0.f;
@@ -216,9 +236,13 @@ __global__ __launch_bounds__(256) void bn_apply_train_kernel(const T *__restrict
                                                              float momentum, float eps, float *mean, float *invstd, float *scale_o,
                                                              float *shift_o, const T *__restrict__ res, long ldr,
                                                              const float *__restrict__ nc_scale, long M, int K, long rows_per_image,
-                                                             int act, char *__restrict__ out3, unsigned char *__restrict__ gates) {
+                                                             int act, char *__restrict__ out3, unsigned char *__restrict__ gates,
+                                                             int parts, const float *__restrict__ res_bound) {
     __shared__ __attribute__((aligned(16))) float s_scale[BN_KMAX];
     __shared__ __attribute__((aligned(16))) float s_shift[BN_KMAX];
+    __shared__ float s_bnd[2][4];
+    float gmax = 0.f;  // max over channels of |gamma| sqrt(M - 1) + |beta|: bounds |gamma xhat + beta| (two-part x3 output)
+    const float sqm = sqrtf(count > 2.0 ? (float)(count - 1.0) : 1.f);
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
         const double mu = sums[k] / count;
         double var = sums[K + k] / count - mu * mu;
@@ -228,6 +252,7 @@ __global__ __launch_bounds__(256) void bn_apply_train_kernel(const T *__restrict
         const float sc = (float)((double)g * is), sh = (float)((double)b - mu * (double)g * is);
         s_scale[k] = sc;
         s_shift[k] = sh;
+        gmax = fmaxf(gmax, fabsf(g) * sqm + fabsf(b));
         if (blockIdx.x == 0) {
             mean[k] = (float)mu;
             invstd[k] = (float)is;
@@ -240,8 +265,27 @@ __global__ __launch_bounds__(256) void bn_apply_train_kernel(const T *__restrict
             }
         }
     }
+    float x3s = 1.f;
+    if (out3 && parts == 2) {
+        // Two-part x3 output: the per-tensor scale needs a bound of |out| BEFORE any element is written.  Batch statistics give
+        // one for free (Samuelson): |x - mean| <= std * sqrt(M - 1) for every sample, so per channel |gamma * xhat + beta| <=
+        // |gamma| * sqrt(M - 1) + |beta|; a residual adds its own bound, ReLU6 caps at 6, a Dropout2d multiplier is <= 4.
+        // Loose by ~sqrt(M) / (the batch's true max |xhat|, ~5): 2^4 .. 2^6 -- harmless (dass_common.h), and the same in every block.
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o, 64));
+        if ((threadIdx.x & 63) == 0) s_bnd[0][threadIdx.x >> 6] = gmax;
+    }
     __syncthreads();
-    if (out3 && blockIdx.x == 0) x3_zero_row(out3, M, (K + 31) >> 5);
+    if (out3 && parts == 2) {
+        const float gm = fmaxf(fmaxf(s_bnd[0][0], s_bnd[0][1]), fmaxf(s_bnd[0][2], s_bnd[0][3]));
+        float bound = 1.25f * gm + (res_bound ? *res_bound : 0.f);
+        if (act == DASS_ACT_RELU6) bound = fminf(bound, 6.f);
+        if (nc_scale) bound *= 4.f;
+        x3s = x3_scale_of(bound);
+        if (blockIdx.x == 0) x3_zero_row(out3, M, (K + 31) >> 5, 2, x3_inv_of(x3s), bound);
+    } else if (out3 && blockIdx.x == 0) {
+        x3_zero_row(out3, M, (K + 31) >> 5);
+    }
     const int cc3 = (K + 31) >> 5;
     const int kv = K >> 2;
     const long stride = (long)gridDim.x * blockDim.x;
@@ -268,7 +312,7 @@ __global__ __launch_bounds__(256) void bn_apply_train_kernel(const T *__restrict
         }
         if (nc_scale) v *= *reinterpret_cast<const f32x4 *>(nc_scale + (m / rows_per_image) * K + k);
         if (out) st4<T>(out + m * ldo + k, v);
-        if (out3) x3_store4(out3, m, cc3, k, v);
+        if (out3) x3_store4r(out3, m, cc3, k, v, parts, x3s);
     }
 }
 
@@ -290,8 +334,33 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
                                                            const double *__restrict__ sums = nullptr,
                                                            float *__restrict__ dbeta_out = nullptr,
                                                            float *__restrict__ dgamma_out = nullptr,
-                                                           const unsigned char *__restrict__ gates = nullptr) {
-    if (dx3 && blockIdx.x == 0) x3_zero_row(dx3, M, (K + 31) >> 5);
+                                                           const unsigned char *__restrict__ gates = nullptr, int parts = 3) {
+    float x3s = 1.f;
+    if (dx3 && parts == 2) {
+        // Two-part x3 form of dx: per channel |dx| = |gamma invstd| |dz - mean(dz) - xhat mean(dz xhat)|
+        //   <= |gamma invstd| (max|dz| + |mean(dz)| + sqrt(M - 1) |mean(dz xhat)|)      (Samuelson: |xhat| <= sqrt(M - 1)),
+        // with the two means from the f64 sums and the channel's max |dz| left behind them by dass_bn_bwd_reduce_sums; the
+        // tensor's bound is the max over the channels.  Channel-wise on purpose: a near-constant channel has a huge invstd and
+        // a tiny dz, a product of the two global maxima would be loose by many binades (seen: 4x the gradient error).
+        __shared__ float s_g[4];
+        const float *dzmax = reinterpret_cast<const float *>(sums + 2 * (long)K);
+        const float sqm = sqrtf(M > 1 ? (float)(M - 1) : 1.f);
+        float gi = 0.f;
+        for (int k = threadIdx.x; k < K; k += blockDim.x) {
+            float b = dzmax[k];
+            if (train) b += fabsf((float)sums[k]) * inv_count + sqm * fabsf((float)sums[K + k]) * inv_count;
+            gi = fmaxf(gi, fabsf((gamma ? gamma[k] : 1.f) * invstd[k]) * b);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gi = fmaxf(gi, __shfl_xor(gi, o, 64));
+        if ((threadIdx.x & 63) == 0) s_g[threadIdx.x >> 6] = gi;
+        __syncthreads();
+        const float bound = 1.25f * fmaxf(fmaxf(s_g[0], s_g[1]), fmaxf(s_g[2], s_g[3]));
+        x3s = x3_scale_of(bound);
+        if (blockIdx.x == 0) x3_zero_row(dx3, M, (K + 31) >> 5, 2, x3_inv_of(x3s), bound);
+    } else if (dx3 && blockIdx.x == 0) {
+        x3_zero_row(dx3, M, (K + 31) >> 5);
+    }
     if (sums && blockIdx.x == 0)  // the f64 sums of dass_bn_bwd_reduce_sums, rounded once: the parameter gradients
         for (int k = threadIdx.x; k < K; k += blockDim.x) {
             if (dbeta_out) dbeta_out[k] = (float)sums[k];
@@ -349,7 +418,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
             }
             const f32x4 dxv = r * (ga * is);
             st4<T>(dx + m * lddx + k, dxv);
-            if (dx3) x3_store4(dx3, m, cc3, k, dxv);  // operand of the producing conv's input-gradient launch
+            if (dx3) x3_store4r(dx3, m, cc3, k, dxv, parts, x3s);  // operand of the producing conv's input- and weight-gradient launches
         }
     }
 }
@@ -486,6 +555,7 @@ extern "C" int dass_scale_shift_act(const void *x, int64_t ldx, void *out, int64
                                     int64_t M, int K, int64_t rows_per_image, int act, int dtype, void *out3, void *stream) {
     if (!x || (!out && !out3) || M <= 0 || !ok4(K, ldx, out ? ldo : 4, residual ? ldr : 4) || rows_per_image <= 0) return DASS_ERR_ARG;
     if (out3 && (dtype != DASS_F32 || ((uintptr_t)out3 & 15))) return DASS_ERR_ARG;
+    if (out3 && dass_get_x3_parts() != 3) return DASS_ERR_UNSUPPORTED;  // no bound of x here: the consumer converts (dass_split3_rows)
     const int grid = dass_grid_1d(M * (K / 4), 256);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DASS_F32)
@@ -544,6 +614,7 @@ extern "C" int dass_bn_bwd_apply_gate(const void *dout, int64_t lddo, const void
                                       const float *gate_shift, const float *nc_scale, void *dx, int64_t lddx, int64_t M, int K,
                                       int64_t rows_per_image, double count, int train, int act, int dtype, void *dx3, void *stream) {
     if (dx3 && ((uintptr_t)dx3 & 15)) return DASS_ERR_ARG;
+    if (dx3 && dass_get_x3_parts() != 3) return DASS_ERR_UNSUPPORTED;  // the two-part form needs max|dz| (the sums path supplies it)
     if (!dout || !x || !dx || !invstd || !gate_scale || !gate_shift || M <= 0 || !ok4(K, lddo, ldx, lddx) || rows_per_image <= 0)
         return DASS_ERR_ARG;
     if (train && (!mean || !dbeta || !dgamma || count <= 0)) return DASS_ERR_ARG;
@@ -573,6 +644,7 @@ extern "C" int dass_bn_bwd_apply(const void *dout, int64_t lddo, const void *out
                                  double count, int train, int act, int dtype, void *dx3, void *stream) {
     if (!dout || !out || M <= 0 || !ok4(K, lddo, ldo) || rows_per_image <= 0) return DASS_ERR_ARG;
     if (dx3 && (!dx || dtype != DASS_F32 || ((uintptr_t)dx3 & 15))) return DASS_ERR_ARG;
+    if (dx3 && dass_get_x3_parts() != 3) return DASS_ERR_UNSUPPORTED;
     if (dx && (!invstd || lddx % 4)) return DASS_ERR_ARG;
     if (dx && train && (!x || !mean || !dbeta || !dgamma || ldx % 4 || count <= 0)) return DASS_ERR_ARG;
     if (dres && lddr % 4) return DASS_ERR_ARG;
@@ -629,22 +701,26 @@ extern "C" int dass_channel_sums(const void *x, int64_t ldx, int64_t M, int K, d
 extern "C" int dass_bn_apply_train(const void *x, int64_t ldx, void *out, int64_t ldo, const double *sums, double count, const float *gamma,
                                    const float *beta, float *running_mean, float *running_var, float momentum, float eps, float *mean,
                                    float *invstd, float *scale, float *shift, const void *residual, int64_t ldr, const float *nc_scale,
-                                   int64_t M, int K, int64_t rows_per_image, int act, int dtype, void *out3, void *gates, void *stream) {
+                                   int64_t M, int K, int64_t rows_per_image, int act, int dtype, void *out3, void *gates, int64_t gates_bytes,
+                                   const float *residual_bound, void *stream) {
     if (!x || (!out && !out3) || !sums || count <= 0 || !mean || !invstd || !scale || !shift || M <= 0 ||
         !ok4(K, ldx, out ? ldo : 4, residual ? ldr : 4) || rows_per_image <= 0)
         return DASS_ERR_ARG;
     if (K > BN_KMAX) return DASS_ERR_UNSUPPORTED;
     if (out3 && (dtype != DASS_F32 || ((uintptr_t)out3 & 15))) return DASS_ERR_ARG;
+    if (gates && gates_bytes < M * (K / 4)) return DASS_ERR_ARG;  // one byte per 4-channel group of every row
+    const int parts = dass_get_x3_parts();
+    if (out3 && parts == 2 && residual && !residual_bound) return DASS_ERR_ARG;  // the output's bound needs the residual's
     const int grid = dass_grid_1d(M * (K / 4), 256);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DASS_F32)
         hipLaunchKernelGGL(bn_apply_train_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, ldx, (float *)out, ldo, sums, count,
                            gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, (const float *)residual, ldr,
-                           nc_scale, M, K, rows_per_image, act, (char *)out3, (unsigned char *)gates);
+                           nc_scale, M, K, rows_per_image, act, (char *)out3, (unsigned char *)gates, parts, residual_bound);
     else if (dtype == DASS_BF16)
         hipLaunchKernelGGL(bn_apply_train_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)x, ldx, (bf16_t *)out, ldo, sums, count,
                            gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, (const bf16_t *)residual, ldr,
-                           nc_scale, M, K, rows_per_image, act, (char *)nullptr, (unsigned char *)gates);
+                           nc_scale, M, K, rows_per_image, act, (char *)nullptr, (unsigned char *)gates, 3, (const float *)nullptr);
     else
         return DASS_ERR_UNSUPPORTED;
     DASS_LAUNCH_CHECK();
@@ -656,10 +732,10 @@ extern "C" int dass_bn_apply_train(const void *x, int64_t ldx, void *out, int64_
 extern "C" int dass_bn_bwd_reduce_sums(const void *dout, int64_t lddo, const void *out, int64_t ldo, const void *x, int64_t ldx,
                                        const float *mean, const float *invstd, const float *gate_scale, const float *gate_shift,
                                        const float *nc_scale, int64_t M, int K, int64_t rows_per_image, int act, double *sums,
-                                       const void *gates, int dtype, void *stream) {
+                                       const void *gates, int64_t gates_bytes, int dtype, void *stream) {
     if (!dout || !x || !mean || !invstd || !sums || M <= 0 || !ok4(K, lddo, out ? ldo : 4, ldx) || rows_per_image <= 0) return DASS_ERR_ARG;
     if (!out && !gates && (!gate_scale || !gate_shift || dtype != DASS_F32)) return DASS_ERR_ARG;
-    if (gates && nc_scale) return DASS_ERR_ARG;
+    if (gates && (nc_scale || gates_bytes < M * (K / 4))) return DASS_ERR_ARG;
     dim3 grid((unsigned)dass_stat_rows(M), (unsigned)((K + 63) / 64));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DASS_F32)
@@ -681,12 +757,12 @@ extern "C" int dass_bn_bwd_apply_sums(const void *dout, int64_t lddo, const void
                                       const float *mean, const float *invstd, const float *gamma, const double *sums, float *dbeta_out,
                                       float *dgamma_out, const float *gate_scale, const float *gate_shift, const float *nc_scale,
                                       void *dx, int64_t lddx, void *dres, int64_t lddr, int64_t M, int K, int64_t rows_per_image,
-                                      double count, int act, const void *gates, int dtype, void *dx3, void *stream) {
+                                      double count, int act, const void *gates, int64_t gates_bytes, int dtype, void *dx3, void *stream) {
     if (!dout || !x || !dx || !mean || !invstd || !sums || count <= 0 || M <= 0 || !ok4(K, lddo, out ? ldo : 4, ldx, lddx) ||
         rows_per_image <= 0)
         return DASS_ERR_ARG;
     if (!out && !gates && (!gate_scale || !gate_shift || dtype != DASS_F32)) return DASS_ERR_ARG;
-    if (gates && nc_scale) return DASS_ERR_ARG;
+    if (gates && (nc_scale || gates_bytes < M * (K / 4))) return DASS_ERR_ARG;
     if (dres && lddr % 4) return DASS_ERR_ARG;
     if (dx3 && (dtype != DASS_F32 || ((uintptr_t)dx3 & 15))) return DASS_ERR_ARG;
     const int grid = dass_grid_1d(M * (K / 4), 256);
@@ -696,7 +772,7 @@ extern "C" int dass_bn_bwd_apply_sums(const void *dout, int64_t lddo, const void
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)dout, lddo, (const float *)out, ldo,
                            (const float *)x, ldx, mean, invstd, gamma, (const float *)nullptr, (const float *)nullptr, nc_scale, (float *)dx,
                            lddx, (float *)dres, lddr, M, K, rows_per_image, inv_count, 1, act, gate_scale, gate_shift, (char *)dx3, sums,
-                           dbeta_out, dgamma_out, (const unsigned char *)gates);
+                           dbeta_out, dgamma_out, (const unsigned char *)gates, dass_get_x3_parts());
     else if (dtype == DASS_BF16)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)dout, lddo, (const bf16_t *)out, ldo,
                            (const bf16_t *)x, ldx, mean, invstd, gamma, (const float *)nullptr, (const float *)nullptr, nc_scale,

@@ -1122,6 +1122,88 @@ __global__ __launch_bounds__(256) void weight_split3_batch_kernel(const long *__
     }
 }
 
+// ---- DASS_F16X3 weight operand (dass_common.h "x3 operand formats", NP = 2): rows x taps x ceil(red/32) slabs of [2 parts][32 k]
+// f16 (128 B) of w * s, s = the power-of-two scale of the tensor's max |w| (kept, with its inverse, in the 16-B trailer).
+// Pass 1 (amax_only): every tile's max |w| -> atomic max into the trailer's bound slot; pass 2: the split.  Same tiling and
+// descriptor table as weight_split3_batch_kernel.
+__global__ __launch_bounds__(256) void weight_split2_batch_kernel(const long *__restrict__ desc, const long *__restrict__ start, int n,
+                                                                  long total_tiles, int amax_only) {
+    __shared__ float tile[32][33];
+    __shared__ float red[4];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (long tl = blockIdx.x; tl < total_tiles; tl += gridDim.x) {
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (start[mid] <= tl) lo = mid; else hi = mid - 1;
+        }
+        const long *d = desc + 8 * lo;
+        const float *src = reinterpret_cast<const float *>(d[0]);
+        char *dst = reinterpret_cast<char *>(d[1]);
+        const int K = (int)d[2], R = (int)d[3], S = (int)d[4], Csrc = (int)d[5], Cdst = (int)d[6], mode = (int)d[7];
+        const int rows = mode == 0 ? K : Csrc, red_n = mode == 0 ? Cdst : K, taps = R * S, cch = (red_n + 31) / 32;
+        unsigned *tr = reinterpret_cast<unsigned *>(dst + (long)rows * taps * cch * 128);
+        long q = tl - start[lo];
+        const int cc = (int)(q % cch);
+        q /= cch;
+        const int t = (int)(q % taps);
+        const int rb = (int)(q / taps);  // row block
+        const int r = t / S, s2 = t - r * S;
+        __syncthreads();  // previous tile fully consumed
+        float mx = 0.f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int y = ty + 8 * p;
+            float v = 0.f;
+            if (mode == 0) {
+                const int row = rb * 32 + y, e = cc * 32 + tx;
+                if (row < rows && e < Csrc) v = src[(((long)row * R + r) * S + s2) * Csrc + e];
+                tile[y][tx] = v;
+            } else {
+                const int e = cc * 32 + y, row = rb * 32 + tx;
+                if (e < K && row < rows) v = src[(((long)e * R + (R - 1 - r)) * S + (S - 1 - s2)) * Csrc + row];
+                tile[tx][y] = v;
+            }
+            mx = fmaxf(mx, fabsf(v));
+        }
+        if (amax_only) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+                if (!(mx >= 0.f)) mx = __uint_as_float(0x7f800000u);
+                atomicMax(tr + 1, __float_as_uint(mx));
+            }
+            continue;
+        }
+        const float scale = x3_scale_of(__uint_as_float(tr[1]));
+        if (tl == start[lo] && threadIdx.x == 0) tr[0] = __float_as_uint(x3_inv_of(scale));
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int y = ty + 8 * p, row = rb * 32 + y;
+            if (row >= rows) continue;
+            const float v = tile[y][tx] * scale;
+            const _Float16 h = (_Float16)v;
+            const _Float16 l = (_Float16)(v - (float)h);
+            _Float16 *o = reinterpret_cast<_Float16 *>(dst) + (((long)row * taps + t) * cch + cc) * 64 + tx;
+            o[0] = h;
+            o[32] = l;
+        }
+    }
+}
+// trailers of n operands zeroed (bound slot is an atomic max)
+__global__ void weight_trailer_zero_kernel(const long *__restrict__ desc, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long *d = desc + 8 * i;
+    const int K = (int)d[2], R = (int)d[3], S = (int)d[4], Csrc = (int)d[5], Cdst = (int)d[6], mode = (int)d[7];
+    const int rows = mode == 0 ? K : Csrc, red_n = mode == 0 ? Cdst : K;
+    *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(d[1]) + (long)rows * R * S * ((red_n + 31) / 32) * 128) = make_uint4(0u, 0u, 0u, 0u);
+}
+
 template <typename T, int BM, int BN, int WM, int WN, bool WIDE = false, int SPLIT = 0, int PF = 1> int launch_conv(ConvP &p, hipStream_t st) {
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = (p.K + BN - 1) / BN;
@@ -1451,7 +1533,24 @@ extern "C" int dass_weight_split_batch(const void *desc, const int64_t *start, i
 }
 
 extern "C" int64_t dass_weight_split_bytes(int rows, int R, int S, int red) {
-    return (int64_t)rows * R * S * ((red + 31) / 32) * 192;
+    return (int64_t)rows * R * S * ((red + 31) / 32) * 192 + 16;  // (+ the trailer every pre-split operand carries)
+}
+/* bytes of the pre-split operand of `dtype` (DASS_F32X6: three bf16 parts; DASS_F16X3: two scaled f16 parts + scale trailer) */
+extern "C" int64_t dass_weight_operand_bytes(int rows, int R, int S, int red, int dtype) {
+    if (dtype == DASS_F16X3) return (int64_t)rows * R * S * ((red + 31) / 32) * 128 + 16;
+    return dass_weight_split_bytes(rows, R, S, red);
+}
+
+/* the DASS_F16X3 form of dass_weight_split_batch: same table; three launches (zero the trailers, max |w| per tensor, split) */
+extern "C" int dass_weight_split_batch_f16(const void *desc, const int64_t *start, int n, int64_t total, void *stream) {
+    if (!desc || !start || n <= 0 || total <= 0) return DASS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const long grid = total < 256 * 32 ? total : 256 * 32;
+    hipLaunchKernelGGL(weight_trailer_zero_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const long *)desc, n);
+    hipLaunchKernelGGL(weight_split2_batch_kernel, dim3((unsigned)grid), dim3(256), 0, st, (const long *)desc, (const long *)start, n, (long)total, 1);
+    hipLaunchKernelGGL(weight_split2_batch_kernel, dim3((unsigned)grid), dim3(256), 0, st, (const long *)desc, (const long *)start, n, (long)total, 0);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
 }
 
 extern "C" int dass_conv2d_rowtap(const void *x, const void *w, void *y, int64_t ldy, int N, int H, int W, int Cin, int OH,

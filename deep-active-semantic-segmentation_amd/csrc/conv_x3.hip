@@ -38,7 +38,8 @@ struct X3P {
     double *stat_sums;  // alternative to stat_partial: [2][K] f64 accumulators (hardware atomics), see dass_bn_apply_train
     float *ws;  // stream-K workspace: 2 slabs of BM x BN f32 per workgroup of the main launch
     long ldy, ldr;
-    unsigned x3_bytes, w3_bytes, zero_off, row_pitch;  // row_pitch = CC * 192
+    unsigned x3_bytes, w3_bytes, zero_off, row_pitch;  // row_pitch = CC * (parts * 64)
+    unsigned x3_tr, w3_tr;  // byte offsets of the operands' trailers {inv_scale, bound} (two-part format)
     int cc_out;
     int N, H, W, CC, OH, OW, K, R, S, stride, pad, dil, act;
     int M, mtiles, ntiles, sk_wgs;
@@ -77,9 +78,19 @@ __device__ __forceinline__ v4i make_srd(const void *base, unsigned bytes) {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-__device__ __forceinline__ f32x16 mfma16(const uint4 &a, const uint4 &b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&a), *reinterpret_cast<const bf16x8 *>(&b), c, 0, 0, 0);
+// NP = 3: bf16 parts, NP = 2: f16 parts (dass_common.h "x3 operand formats")
+template <int NP> __device__ __forceinline__ f32x16 mfma16(const uint4 &a, const uint4 &b, f32x16 c) {
+    if constexpr (NP == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8 *>(&a), *reinterpret_cast<const f16x8 *>(&b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&a), *reinterpret_cast<const bf16x8 *>(&b), c, 0, 0, 0);
 }
+template <int NP> __device__ __forceinline__ f32x4 mfma32(const uint4 &a, const uint4 &b, f32x4 c) {
+    if constexpr (NP == 2) return __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8 *>(&a), *reinterpret_cast<const f16x8 *>(&b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&a), *reinterpret_cast<const bf16x8 *>(&b), c, 0, 0, 0);
+}
+// the products of one operand pair, smallest first.  NP = 3: (a0,b2) (a2,b0) (a1,b1) (a0,b1) (a1,b0) (a0,b0); NP = 2: (a0,b1) (a1,b0) (a0,b0)
+template <int NP> struct Terms;
+template <> struct Terms<3> { static constexpr int N = 6; static constexpr int PA[6] = {0, 2, 1, 0, 1, 0}; static constexpr int PB[6] = {2, 0, 1, 1, 0, 0}; };
+template <> struct Terms<2> { static constexpr int N = 3; static constexpr int PA[3] = {0, 1, 0}; static constexpr int PB[3] = {1, 0, 0}; };
 
 // fused epilogue of ONE 4-channel group of output pixel m (tile-independent: used by the main kernel and the fix-up pass)
 __device__ __forceinline__ void x3_store_out(const X3P &p, f32x4 v, int m, int k, int ohw, bool vec_ok) {
@@ -123,21 +134,25 @@ __device__ __forceinline__ void x3_store_out(const X3P &p, f32x4 v, int m, int k
 // M16: the products run on v_mfma_f32_16x16x32_bf16 (one 32-k slab per instruction) instead of v_mfma_f32_32x32x16_bf16: the
 // same FLOPs per cycle, but the chip holds a ~10 % higher clock under that shape (tools/mfma_shape_probe.py: 2.17 vs 1.97 GHz
 // with two LDS-fed waves per SIMD on all CUs; MI355X_MICROARCH.md measures 1.12-1.14 x).
-template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE, bool M16>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE, bool M16, int NP = 3>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(const X3P p) {
     constexpr int NW = WARPS_M * WARPS_N;
+    constexpr int SB = NP * 64, PG = NP * 1024;  // bytes of one row-slab / of the NP 1-KiB pieces of one 16-row rowgroup
+    using TT = Terms<NP>;
     constexpr int TMW = BM / WARPS_M, TNW = BN / WARPS_N, MT = TMW / 32, NT = TNW / 32;
     constexpr int MT16 = TMW / 16, NT16 = TNW / 16, MH = MT16 / 2, NH = NT16 / 2;  // M16: 16 x 16 blocks, handled in halves
     constexpr int AG = BM / 16, BG = BN / 16, RG = (AG + BG) / NW;
     static_assert((AG + BG) % NW == 0, "rowgroups must divide over the waves");
     static_assert(MT >= 1 && NT >= 1 && NSTAGE >= 2 && NSTAGE <= 4, "tile");
-    constexpr int A_BYTES = AG * 3072, B_BYTES = BG * 3072, STAGE = A_BYTES + B_BYTES;
-    constexpr int G = RG * 3;  // DMA instructions per wave and slab
+    constexpr int A_BYTES = AG * PG, B_BYTES = BG * PG, STAGE = A_BYTES + B_BYTES;
+    constexpr int G = RG * NP;  // DMA instructions per wave and slab
     static_assert(G * (NSTAGE - 2) <= 63, "vmcnt range");
     constexpr int RING = NSTAGE * STAGE;
+    constexpr int EPI = NW * 32 * ((NT >= 2 ? 64 : 32) + 4) * 4;  // the epilogue's accumulator patches reuse the ring (two-part 64 x 64 ring is smaller)
+    constexpr int SMEM = RING > EPI ? RING : EPI;
     // ONE shared object (a second one beside a DMA-filled array makes hipcc drain vmcnt before every ds_read)
-    __shared__ __attribute__((aligned(16))) char smem[RING + 64 * 4];
-    unsigned *tap_delta = reinterpret_cast<unsigned *>(smem + RING);
+    __shared__ __attribute__((aligned(16))) char smem[SMEM + 64 * 4];
+    unsigned *tap_delta = reinterpret_cast<unsigned *>(smem + SMEM);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -166,15 +181,15 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     // ---- fragment addresses: lane (r = lane & 31, h = lane >> 5) reads row r, chunk 2 ks + h of each part
     const int fr = lane & 31, fh = lane >> 5;
     const int fsw = ((fr & 15) >> 2) & 3;
-    const int f_row = (fr >> 4) * 3072 + (fr & 15) * 64;
-    const int a_lane0 = (wm * (TMW / 16)) * 3072 + f_row + (((0 + fh) ^ fsw) * 16);
-    const int a_lane1 = (wm * (TMW / 16)) * 3072 + f_row + (((2 + fh) ^ fsw) * 16);
-    const int b_lane0 = A_BYTES + (wn * (TNW / 16)) * 3072 + f_row + (((0 + fh) ^ fsw) * 16);
-    const int b_lane1 = A_BYTES + (wn * (TNW / 16)) * 3072 + f_row + (((2 + fh) ^ fsw) * 16);
+    const int f_row = (fr >> 4) * PG + (fr & 15) * 64;
+    const int a_lane0 = (wm * (TMW / 16)) * PG + f_row + (((0 + fh) ^ fsw) * 16);
+    const int a_lane1 = (wm * (TMW / 16)) * PG + f_row + (((2 + fh) ^ fsw) * 16);
+    const int b_lane0 = A_BYTES + (wn * (TNW / 16)) * PG + f_row + (((0 + fh) ^ fsw) * 16);
+    const int b_lane1 = A_BYTES + (wn * (TNW / 16)) * PG + f_row + (((2 + fh) ^ fsw) * 16);
     // M16: lane (r = lane & 15, g = lane >> 4) reads row r, chunk g (k = 8 g .. 8 g + 7) of a 16-row piece: the 64 lanes cover
     // the 1 KiB piece exactly once (conflict-free under the same XOR swizzle)
     const int l16 = (lane & 15) * 64 + (((lane >> 4) ^ ((0 - ((lane & 15) >> 2)) & 3)) * 16);
-    const int a16 = (wm * MT16) * 3072 + l16, b16 = A_BYTES + (wn * NT16) * 3072 + l16;
+    const int a16 = (wm * MT16) * PG + l16, b16 = A_BYTES + (wn * NT16) * PG + l16;
 
     // ---- this workgroup's range of (tile, slab) units
     const int wgid = xcd_remap(blockIdx.x, gridDim.x);
@@ -234,7 +249,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
         } else {
             int k = n0 + (q - AG) * 16 + r16;
             if (k >= p.K) k = p.K - 1;  // columns >= K are never stored: any finite row will do
-            rb_off[j] = (unsigned)grp * p.w3_group_stride + (unsigned)k * (unsigned)(ntaps * p.CC * 192) + chunk_off;
+            rb_off[j] = (unsigned)grp * p.w3_group_stride + (unsigned)k * (unsigned)(ntaps * p.CC * SB) + chunk_off;
         }
     }
 
@@ -289,8 +304,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
         }
         nx_t = __builtin_ctzll(it_mask);
         it_mask &= it_mask - 1;
-        nx_a_uni = tap_delta[nx_t] + (unsigned)(it_cc * 192);
-        nx_b_uni = (unsigned)((nx_t * p.CC + it_cc) * 192);
+        nx_a_uni = tap_delta[nx_t] + (unsigned)(it_cc * SB);
+        nx_b_uni = (unsigned)((nx_t * p.CC + it_cc) * SB);
     };
     auto issue_rowgroup = [&](auto jc, int stage) __attribute__((always_inline)) {  // the three parts of rowgroup wave + j * NW of the next slab (j: int or integral_constant)
         const int j = jc;
@@ -299,16 +314,14 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
         if (q < AG) {
             const bool valid = (vmask[j] >> nx_t) & 1ull;
             const unsigned voff = valid ? rb_off[j] + nx_a_uni : p.zero_off + chunk_off;
-            const unsigned dst = __builtin_amdgcn_readfirstlane(st + q * 3072);
-            dma16(rsa, dst, voff);
-            dma16(rsa, dst + 1024, voff + 64);
-            dma16(rsa, dst + 2048, voff + 128);
+            const unsigned dst = __builtin_amdgcn_readfirstlane(st + q * PG);
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) dma16(rsa, dst + pl * 1024, voff + pl * 64);
         } else {
             const unsigned voff = rb_off[j] + nx_b_uni;
-            const unsigned dst = __builtin_amdgcn_readfirstlane(st + A_BYTES + (q - AG) * 3072);
-            dma16(rsb, dst, voff);
-            dma16(rsb, dst + 1024, voff + 64);
-            dma16(rsb, dst + 2048, voff + 128);
+            const unsigned dst = __builtin_amdgcn_readfirstlane(st + A_BYTES + (q - AG) * PG);
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) dma16(rsb, dst + pl * 1024, voff + pl * 64);
         }
     };
 
@@ -328,28 +341,25 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     // latency is covered; the DMA issue of the slab NSTAGE-1 ahead is cut into its rowgroups and placed BETWEEN the
     // MFMA groups of the first half (an in-order wave issues them in the shadow of the running MFMAs).
     if constexpr (!M16) {
-    uint4 a0[3][MT], b0[3][NT], a1[3][MT], b1[3][NT];
-    auto load_frags = [&](const char *ap, const char *bp, uint4(&a)[3][MT], uint4(&b)[3][NT]) {
+    uint4 a0[NP][MT], b0[NP][NT], a1[NP][MT], b1[NP][NT];
+    auto load_frags = [&](const char *ap, const char *bp, uint4(&a)[NP][MT], uint4(&b)[NP][NT]) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[pl][nt] = *reinterpret_cast<const uint4 *>(bp + nt * 6144 + pl * 1024);
+            for (int nt = 0; nt < NT; ++nt) b[pl][nt] = *reinterpret_cast<const uint4 *>(bp + nt * 2 * PG + pl * 1024);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[pl][mt] = *reinterpret_cast<const uint4 *>(ap + mt * 6144 + pl * 1024);
+            for (int mt = 0; mt < MT; ++mt) a[pl][mt] = *reinterpret_cast<const uint4 *>(ap + mt * 2 * PG + pl * 1024);
         }
     };
     // six products, smallest first: (a0,b2) (a2,b0) (a1,b1) (a0,b1) (a1,b0) (a0,b0); `between(term)` runs after each group
-    auto multiply = [&](const uint4(&a)[3][MT], const uint4(&b)[3][NT], auto between) {
+    auto multiply = [&](const uint4(&a)[NP][MT], const uint4(&b)[NP][NT], auto between) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int term = 0; term < 6; ++term) {
+        for (int term = 0; term < TT::N; ++term) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    constexpr int PA_OF[6] = {0, 2, 1, 0, 1, 0}, PB_OF[6] = {2, 0, 1, 1, 0, 0};
-                    acc[mt][nt] = mfma16(a[PA_OF[term]][mt], b[PB_OF[term]][nt], acc[mt][nt]);
-                }
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16<NP>(a[TT::PA[term]][mt], b[TT::PB[term]][nt], acc[mt][nt]);
             between(term);
         }
         __builtin_amdgcn_s_setprio(0);
@@ -369,9 +379,11 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
         const bool more = issued < total;  // block-uniform
         if (s > 0) {
             multiply(a1, b1, [&](int term) {  // slab s-1, k-step 1
-                if (more && term < RG) {
+                if (more) {
                     __builtin_amdgcn_sched_barrier(0);
-                    issue_rowgroup(term, nxt);  // into the stage slab s-1 occupied
+#pragma unroll
+                    for (int j = 0; j < RG; ++j)
+                        if (j % TT::N == term) issue_rowgroup(j, nxt);  // into the stage slab s-1 occupied
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
@@ -393,7 +405,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     // registers: four fragment sets (a_lo, a_hi, b_lo, b_hi; 96 VGPRs for a 64 x 64 wave tile) are enough to have every
     // ds_read issued one full step (24 MFMAs) ahead of its use.  Steps 3 and 4 of slab s-1 run after the barrier of slab s
     // (the skew of the 32x32 loop), with the DMA issue of the slab NSTAGE-1 ahead between their MFMA groups.
-    uint4 a_lo[3][MH], a_hi[3][MH], b_lo[3][NH], b_hi[3][NH];
+    uint4 a_lo[NP][MH], a_hi[NP][MH], b_lo[NP][NH], b_hi[NP][NH];
     // the loader's per-rowgroup state as plain values (the optimizer left rb_off[] / vmask[] in scratch memory when they were
     // reached through the nested closures of this loop: a scratch load in front of every DMA issue, with a vmcnt(0) behind it)
     static_assert(RG <= 4, "rowgroups per wave");
@@ -408,53 +420,53 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
         if (q < AG) {
             const bool valid = (vm >> nx_t) & 1ull;
             const unsigned voff = valid ? rbo + nx_a_uni : p.zero_off + chunk_off;
-            const unsigned dst = __builtin_amdgcn_readfirstlane(st + q * 3072);
+            const unsigned dst = __builtin_amdgcn_readfirstlane(st + q * PG);
             dma16(rsa, dst, voff);
             dma16(rsa, dst + 1024, voff + 64);
-            dma16(rsa, dst + 2048, voff + 128);
+            if constexpr (NP == 3) dma16(rsa, dst + 2048, voff + 128);
         } else {
             const unsigned voff = rbo + nx_b_uni;
-            const unsigned dst = __builtin_amdgcn_readfirstlane(st + A_BYTES + (q - AG) * 3072);
+            const unsigned dst = __builtin_amdgcn_readfirstlane(st + A_BYTES + (q - AG) * PG);
             dma16(rsb, dst, voff);
             dma16(rsb, dst + 1024, voff + 64);
-            dma16(rsb, dst + 2048, voff + 128);
+            if constexpr (NP == 3) dma16(rsb, dst + 2048, voff + 128);
         }
     };
-    auto rd_a = [&](const char *st, uint4(&a)[3][MH], int half) __attribute__((always_inline)) {
+    auto rd_a = [&](const char *st, uint4(&a)[NP][MH], int half) __attribute__((always_inline)) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-            for (int i2 = 0; i2 < MH; ++i2) a[pl][i2] = *reinterpret_cast<const uint4 *>(st + a16 + (half * MH + i2) * 3072 + pl * 1024);
+            for (int i2 = 0; i2 < MH; ++i2) a[pl][i2] = *reinterpret_cast<const uint4 *>(st + a16 + (half * MH + i2) * PG + pl * 1024);
     };
-    auto rd_b = [&](const char *st, uint4(&b)[3][NH], int half) __attribute__((always_inline)) {
+    auto rd_b = [&](const char *st, uint4(&b)[NP][NH], int half) __attribute__((always_inline)) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-            for (int j2 = 0; j2 < NH; ++j2) b[pl][j2] = *reinterpret_cast<const uint4 *>(st + b16 + (half * NH + j2) * 3072 + pl * 1024);
+            for (int j2 = 0; j2 < NH; ++j2) b[pl][j2] = *reinterpret_cast<const uint4 *>(st + b16 + (half * NH + j2) * PG + pl * 1024);
     };
     // one quadrant: blocks (I0 + i, J0 + j); six products, smallest first; `between(term)` runs after each term's MFMAs
     // (the term index travels as a TYPE: an index the optimizer only sees as a loop variable made it keep rb_off[] / vmask[]
     // in scratch memory, and scratch traffic shares the vmcnt counter the DMA waits are counted on)
-    auto quad = [&](const uint4(&a)[3][MH], const uint4(&b)[3][NH], auto I0, auto J0, auto between) __attribute__((always_inline)) {
+    auto quad = [&](const uint4(&a)[NP][MH], const uint4(&b)[NP][NH], auto I0, auto J0, auto between) __attribute__((always_inline)) {
         __builtin_amdgcn_s_setprio(1);
         auto one = [&](auto T) __attribute__((always_inline)) {
             constexpr int term = decltype(T)::value;
-            constexpr int PA_OF[6] = {0, 2, 1, 0, 1, 0}, PB_OF[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
             for (int i2 = 0; i2 < MH; ++i2)
 #pragma unroll
                 for (int j2 = 0; j2 < NH; ++j2)
-                    acc16[decltype(I0)::value + i2][decltype(J0)::value + j2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        *reinterpret_cast<const bf16x8 *>(&a[PA_OF[term]][i2]), *reinterpret_cast<const bf16x8 *>(&b[PB_OF[term]][j2]),
-                        acc16[decltype(I0)::value + i2][decltype(J0)::value + j2], 0, 0, 0);
+                    acc16[decltype(I0)::value + i2][decltype(J0)::value + j2] =
+                        mfma32<NP>(a[TT::PA[term]][i2], b[TT::PB[term]][j2], acc16[decltype(I0)::value + i2][decltype(J0)::value + j2]);
             between(T);
         };
         one(std::integral_constant<int, 0>{});
         one(std::integral_constant<int, 1>{});
         one(std::integral_constant<int, 2>{});
-        one(std::integral_constant<int, 3>{});
-        one(std::integral_constant<int, 4>{});
-        one(std::integral_constant<int, 5>{});
+        if constexpr (NP == 3) {
+            one(std::integral_constant<int, 3>{});
+            one(std::integral_constant<int, 4>{});
+            one(std::integral_constant<int, 5>{});
+        }
         __builtin_amdgcn_s_setprio(0);
     };
     using C0 = std::integral_constant<int, 0>;
@@ -463,7 +475,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     auto nothing = [](auto) {};
     int cur = 0, nxt = NSTAGE - 1;
     // slab s with FIRST = the column half its steps 1 and 4 use (bf), SECOND = the other (bs); the previous slab had them swapped
-    auto slab = [&](int s, uint4(&bf)[3][NH], uint4(&bs)[3][NH], auto JF, auto JS, int hf, int hs) __attribute__((always_inline)) {
+    auto slab = [&](int s, uint4(&bf)[NP][NH], uint4(&bs)[NP][NH], auto JF, auto JS, int hf, int hs) __attribute__((always_inline)) {
         const int later = issued - s - 1;
         if (NSTAGE >= 4 && later >= 2) wait_vmcnt<(NSTAGE >= 4 ? 2 * G : 0)>();
         else if (NSTAGE >= 3 && later >= 1) wait_vmcnt<(NSTAGE >= 3 ? G : 0)>();
@@ -479,10 +491,13 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
         __builtin_amdgcn_sched_barrier(0);
         if (s > 0) {
             quad(a_hi, bf, CMH{}, JF, [&](auto T) __attribute__((always_inline)) {  // step 3 of slab s-1: (hi rows, ITS second half = this slab's first)
-                if constexpr (decltype(T)::value < RG) {
+                // rowgroup j of the next slab is issued after term j (two-part form: three terms, so rowgroup 3 rides with term 2)
+                constexpr int tv = decltype(T)::value;
+                if constexpr (tv < RG) {
                     if (more) {
                         __builtin_amdgcn_sched_barrier(0);
                         issue16(T, nxt);
+                        if constexpr (tv == TT::N - 1 && RG > TT::N) issue16(std::integral_constant<int, (RG > TT::N ? TT::N : 0)>{}, nxt);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -528,6 +543,22 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     }
     }
     wait_vmcnt<0>();
+    if constexpr (NP == 2) {
+        // two-part operands carry per-tensor power-of-two scales: sums of (x sa)(w sb) -> multiply by 1 / (sa sb), exact.
+        // Done on the raw accumulators, so partial stream-K slabs, BN statistics and the epilogue all see true values.
+        const float inv = *reinterpret_cast<const float *>(p.x3 + p.x3_tr) * *reinterpret_cast<const float *>(p.w3 + p.w3_tr);
+        if constexpr (M16) {
+#pragma unroll
+            for (int i = 0; i < MT16; ++i)
+#pragma unroll
+                for (int j = 0; j < NT16; ++j) acc16[i][j] *= inv;
+        } else {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] *= inv;
+        }
+    }
     __syncthreads();  // all waves out of the main loop: the ring is free for the epilogue
 
     if ((p.stat_partial || p.stat_sums) && complete) {
@@ -594,14 +625,14 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     const float *res = reinterpret_cast<const float *>(p.res);
     constexpr int PBLK = (NT >= 2) ? 2 : 1;
     constexpr int PW = PBLK * 32, PITCH = PW + 4, C4 = PW / 4;
-    static_assert(NW * 32 * PITCH * 4 <= RING, "epilogue patches must fit the ring");
+    static_assert(NW * 32 * PITCH * 4 <= SMEM, "epilogue patches must fit the ring");
     static_assert(NT % PBLK == 0, "column blocks per pass");
     float *patch = reinterpret_cast<float *>(smem) + wave * 32 * PITCH;
     const bool vec_ok = (!y || (p.ldy & 3) == 0) && ((p.K & 3) == 0) && (!res || (p.ldr & 3) == 0);
     float *slab = complete ? nullptr : p.ws + ((long)wgid * 2 + (sk_seg > 0 ? 1 : 0)) * (BM * BN);
-    if (p.y3 && tile == 0 && s_lo == 0)  // the zero row consumers point padded taps at
-        for (int i = tid; i < p.cc_out * 12; i += 64 * NW)
-            *reinterpret_cast<uint4 *>(p.y3 + (long)p.M * p.cc_out * 192 + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+    if (p.y3 && tile == 0 && s_lo == 0)  // the zero row consumers point padded taps at (+ the trailer; y3 is a three-part tensor)
+        for (int i = tid; i < p.cc_out * 12 + 1; i += 64 * NW)
+            *reinterpret_cast<uint4 *>(p.y3 + (long)p.M * p.cc_out * 192 + i * 16) = i < p.cc_out * 12 ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(0x3f800000u, 0u, 0u, 0u);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -721,8 +752,17 @@ template <int BM, int BN> __global__ __launch_bounds__(256) void conv_x3_fixup_k
 
 // f32 rows [M][ld] (C real channels) -> x3 rows [M + 1][CC][192]; channels >= C and row M are zero.
 // One thread per 8 channels: two 16-B loads, three 16-B stores.  HBM-bound: 4 B read + 6 B written per element.
+// NP = 2: the tensor's bound sits in the trailer (dass_absmax_rows_kernel ran before); block 0 completes the trailer.
+template <int NP>
 __global__ __launch_bounds__(256) void split3_rows_kernel(const float *__restrict__ x, long ld, char *__restrict__ out, long M, int C, int CC,
                                                           const float *__restrict__ nc_scale, long rows_per_image) {
+    constexpr int SB = NP * 64;
+    float scale = 1.f;
+    if constexpr (NP == 2) {
+        unsigned *tr = reinterpret_cast<unsigned *>(out + (M + 1) * CC * SB);
+        scale = x3_scale_of(__uint_as_float(tr[1]));
+        if (blockIdx.x == 0 && threadIdx.x == 0) tr[0] = __float_as_uint(x3_inv_of(scale));
+    }
     const long units = (M + 1) * CC * 4;  // 8-channel units
     for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (long)gridDim.x * blockDim.x) {
         const int oct = (int)(u & 3);
@@ -749,20 +789,62 @@ __global__ __launch_bounds__(256) void split3_rows_kernel(const float *__restric
                 }
             }
         }
-        uint2 a0, a1, a2, b0, b1, b2;
-        split3_4(v0, a0, a1, a2);
-        split3_4(v1, b0, b1, b2);
-        char *d = out + (m * CC + cc) * 192 + oct * 16;
-        *reinterpret_cast<uint4 *>(d) = make_uint4(a0.x, a0.y, b0.x, b0.y);
-        *reinterpret_cast<uint4 *>(d + 64) = make_uint4(a1.x, a1.y, b1.x, b1.y);
-        *reinterpret_cast<uint4 *>(d + 128) = make_uint4(a2.x, a2.y, b2.x, b2.y);
+        char *d = out + (m * CC + cc) * SB + oct * 16;
+        if constexpr (NP == 3) {
+            uint2 a0, a1, a2, b0, b1, b2;
+            split3_4(v0, a0, a1, a2);
+            split3_4(v1, b0, b1, b2);
+            *reinterpret_cast<uint4 *>(d) = make_uint4(a0.x, a0.y, b0.x, b0.y);
+            *reinterpret_cast<uint4 *>(d + 64) = make_uint4(a1.x, a1.y, b1.x, b1.y);
+            *reinterpret_cast<uint4 *>(d + 128) = make_uint4(a2.x, a2.y, b2.x, b2.y);
+        } else {
+            uint2 a0, a1, b0, b1;
+            split2_4(v0 * scale, a0, a1);
+            split2_4(v1 * scale, b0, b1);
+            *reinterpret_cast<uint4 *>(d) = make_uint4(a0.x, a0.y, b0.x, b0.y);
+            *reinterpret_cast<uint4 *>(d + 64) = make_uint4(a1.x, a1.y, b1.x, b1.y);
+        }
     }
 }
 
-static int g_cus = 0;  // compute units of the current device (stream-K launches one workgroup per resident slot)
+// max |x * nc_scale| over f32 rows [M][ld] (C channels) -> atomic max into *bound_bits (zeroed by the caller; non-negative floats
+// order like their bit patterns).  The bound of the two-part format's per-tensor scale when no producer supplied one.
+__global__ __launch_bounds__(256) void absmax_rows_kernel(const float *__restrict__ x, long ld, long M, int C, const float *__restrict__ nc_scale,
+                                                          long rows_per_image, unsigned *__restrict__ bound_bits) {
+    const int c4 = (C + 3) >> 2;
+    const long units = M * c4;
+    float mx = 0.f;
+    for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (long)gridDim.x * blockDim.x) {
+        const long m = u / c4;
+        const int c = (int)(u - m * c4) * 4;
+        const float *src = x + m * ld + c;
+        const float *sc = nc_scale ? nc_scale + (m / rows_per_image) * C + c : nullptr;
+        if (c + 4 <= C) {
+            f32x4 v = *reinterpret_cast<const f32x4 *>(src);
+            if (sc) v *= *reinterpret_cast<const f32x4 *>(sc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fabsf(v[e]));
+        } else {
+            for (int e = 0; c + e < C; ++e) mx = fmaxf(mx, fabsf(src[e] * (sc ? sc[e] : 1.f)));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (!(mx >= 0.f)) mx = __uint_as_float(0x7f800000u);  // a NaN in the tensor: propagate as an infinite bound
+        atomicMax(bound_bits, __float_as_uint(mx));
+    }
+}
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE> int launch_x3(X3P &p, hipStream_t st, int mode, long ws_bytes, bool m16) {
-    constexpr int LDS = NSTAGE * (BM + BN) * 192 + 256;
+static int g_cus = 0;
+static int g_x3_parts = 3;  // operand format of the pre-split kernels: 3 = bf16 triple (bf16x6 engine), 2 = scaled f16 pair (f16x3 engine)  // compute units of the current device (stream-K launches one workgroup per resident slot)
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE, int NP = 3> int launch_x3(X3P &p, hipStream_t st, int mode, long ws_bytes, bool m16) {
+    constexpr int LDS = NSTAGE * (BM + BN) * (NP * 64) + 256;
     constexpr int RES = (160 * 1024) / LDS >= 4 ? 4 : (160 * 1024) / LDS;  // resident workgroups per CU (LDS-limited)
     p.mt_per_group = (p.group_rows + BM - 1) / BM;
     p.mtiles = p.mt_per_group * ((p.M + p.group_rows - 1) / p.group_rows);
@@ -788,10 +870,10 @@ template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE> int launch_x3(X3
         if (p.dp_tiles == tiles) stream = false;  // the tile count is a whole number of rounds
         else if (s_tile / (ur / p.sk_part > 0 ? ur / p.sk_part : 1) + 2 > 256) return DASS_ERR_UNSUPPORTED;  // cannot happen for S_tile <= 1016
     }
-    if (m16)
-        hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE, true>), dim3(p.sk_wgs), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
-    else
-        hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE, false>), dim3(p.sk_wgs), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
+    if (m16 || NP == 2)  // (the two-part format is built for the 16x16x32 shape only)
+        hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE, true, NP>), dim3(p.sk_wgs), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
+    else if constexpr (NP == 3)
+        hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE, false, 3>), dim3(p.sk_wgs), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
     DASS_LAUNCH_CHECK();
     if (stream) {
         constexpr int RPP = 256 / (BN / 4);
@@ -835,6 +917,18 @@ static int dispatch_x3(X3P &p, hipStream_t st, long ws_bytes) {
         else if (s_tile >= 100) { pick = 1; if (!mode) mode = 2; }
         else { pick = 4; if (!mode) mode = 1; }  // short reductions: segments would be too short to amortise the fix-up
     }
+    if (g_x3_parts == 2) {
+        switch (pick) {
+        case 1: return launch_x3<256, 128, 4, 2, 2, 2>(p, st, mode, ws_bytes, true);
+        case 2: return launch_x3<128, 128, 4, 2, 3, 2>(p, st, mode, ws_bytes, true);
+        case 3: return launch_x3<128, 64, 4, 1, 2, 2>(p, st, mode, ws_bytes, true);
+        case 5: return launch_x3<128, 128, 2, 2, 3, 2>(p, st, mode, ws_bytes, true);
+        case 6: return launch_x3<64, 64, 2, 2, 3, 2>(p, st, mode, ws_bytes, true);
+        case 7: return launch_x3<128, 128, 4, 2, 2, 2>(p, st, mode, ws_bytes, true);
+        case 8: return launch_x3<256, 128, 4, 2, 3, 2>(p, st, mode, ws_bytes, true);  // three stages of 48 KB fit only in the two-part format
+        default: return launch_x3<64, 64, 2, 2, 2, 2>(p, st, mode, ws_bytes, true);
+        }
+    }
     switch (pick) {
     case 1: return launch_x3<256, 128, 4, 2, 2>(p, st, mode, ws_bytes, m16);
     case 2: return launch_x3<128, 128, 4, 2, 3>(p, st, mode, ws_bytes, m16);
@@ -856,7 +950,26 @@ extern "C" int dass_x3_force_tile(int tile) {
 // two BM x BN f32 slabs per workgroup of the largest stream-K launch (256 CUs x 256 x 128 tiles; every other variant needs less)
 extern "C" int64_t dass_conv2d_x3_workspace_bytes(void) { return (int64_t)2 * 256 * (256 * 128) * 4; }
 
-extern "C" int64_t dass_x3_bytes(int64_t rows, int C) { return (rows + 1) * ((C + 31) / 32) * 192; }
+/* operand format of the pre-split kernels and of every x3 buffer allocated from now on: 3 (default) or 2, see dass_common.h */
+extern "C" int dass_set_x3_parts(int parts) {
+    if (parts != 2 && parts != 3) return DASS_ERR_ARG;
+    g_x3_parts = parts;
+    return DASS_OK;
+}
+extern "C" int dass_get_x3_parts(void) { return g_x3_parts; }
+
+extern "C" int64_t dass_x3_bytes(int64_t rows, int C) { return x3_trailer_off(rows, (C + 31) / 32, g_x3_parts) + 16; }
+
+/* bound[0] = max |x| over f32 rows (atomic max: the caller zeroes it), optionally of x * nc_scale[image][channel] */
+extern "C" int dass_absmax_rows(const float *x, int64_t ld, int64_t M, int C, const float *nc_scale, int64_t rows_per_image, float *bound,
+                                void *stream) {
+    if (!x || !bound || M <= 0 || C <= 0 || ld < C || (ld & 3) || ((uintptr_t)x & 15)) return DASS_ERR_ARG;
+    if (nc_scale && (rows_per_image <= 0 || (C & 3))) return DASS_ERR_ARG;
+    hipLaunchKernelGGL(absmax_rows_kernel, dim3(dass_grid_1d(M * ((C + 3) / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, (long)ld, (long)M, C,
+                       nc_scale, (long)(rows_per_image > 0 ? rows_per_image : 1), (unsigned *)bound);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
 
 extern "C" int dass_split3_rows(const float *x, int64_t ld, void *out, int64_t M, int C, const float *nc_scale, int64_t rows_per_image,
                                 void *stream) {
@@ -864,8 +977,19 @@ extern "C" int dass_split3_rows(const float *x, int64_t ld, void *out, int64_t M
     if ((ld & 3) || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return DASS_ERR_ARG;
     if (nc_scale && (rows_per_image <= 0 || (C & 3))) return DASS_ERR_ARG;
     const int CC = (C + 31) / 32;
-    hipLaunchKernelGGL(split3_rows_kernel, dim3(dass_grid_1d((M + 1) * CC * 4, 256)), dim3(256), 0, (hipStream_t)stream, x, (long)ld,
-                       (char *)out, (long)M, C, CC, nc_scale, (long)rows_per_image);
+    hipStream_t st = (hipStream_t)stream;
+    if (g_x3_parts == 2) {
+        // two-part format: the per-tensor scale comes from max |x| (one extra read of the tensor, mostly from L2 / MALL)
+        char *tr = (char *)out + x3_trailer_off(M, CC, 2);
+        if (hipMemsetAsync(tr, 0, 16, st) != hipSuccess) return DASS_ERR_LAUNCH;
+        const int rc = dass_absmax_rows(x, ld, M, C, nc_scale, rows_per_image, (float *)(tr + 4), stream);
+        if (rc != DASS_OK) return rc;
+        hipLaunchKernelGGL(split3_rows_kernel<2>, dim3(dass_grid_1d((M + 1) * CC * 4, 256)), dim3(256), 0, st, x, (long)ld, (char *)out, (long)M, C,
+                           CC, nc_scale, (long)rows_per_image);
+    } else {
+        hipLaunchKernelGGL(split3_rows_kernel<3>, dim3(dass_grid_1d((M + 1) * CC * 4, 256)), dim3(256), 0, st, x, (long)ld, (char *)out, (long)M, C,
+                           CC, nc_scale, (long)rows_per_image);
+    }
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
@@ -881,7 +1005,10 @@ static int conv_x3_impl(const void *x3, const void *w3, void *y, int64_t ldy, vo
     if (((uintptr_t)x3 & 15) || ((uintptr_t)w3 & 15) || ((uintptr_t)y3 & 15)) return DASS_ERR_ARG;
     if ((long)N * OH * OW >= (1l << 31)) return DASS_ERR_ARG;
     const int CC = (C + 31) / 32;
-    const long xbytes = ((long)N * H * W + 1) * CC * 192, wbytes = (long)K * R * S * CC * 192 * (per_image ? N : 1);
+    const int parts = g_x3_parts, SB = parts * 64;
+    if (parts == 2 && y3) return DASS_ERR_UNSUPPORTED;  // the fused x3 output needs the OUTPUT's bound before the kernel runs (not built)
+    const long xtr = x3_trailer_off((long)N * H * W, CC, parts), wtr = (long)K * R * S * CC * SB * (per_image ? N : 1);
+    const long xbytes = xtr + 16, wbytes = wtr + 16;
     if (per_image && ustride != 1) return DASS_ERR_UNSUPPORTED;
     if (xbytes >= (1l << 32) || wbytes >= (1l << 32)) return DASS_ERR_UNSUPPORTED;  // 32-bit buffer offsets
     if (y3 && (K & 3)) return DASS_ERR_ARG;
@@ -901,14 +1028,16 @@ static int conv_x3_impl(const void *x3, const void *w3, void *y, int64_t ldy, vo
     p.ldr = ldr;
     p.x3_bytes = (unsigned)xbytes;
     p.w3_bytes = (unsigned)wbytes;
-    p.zero_off = (unsigned)((long)N * H * W * CC * 192);
-    p.row_pitch = (unsigned)(CC * 192);
+    p.x3_tr = (unsigned)xtr;
+    p.w3_tr = (unsigned)wtr;
+    p.zero_off = (unsigned)((long)N * H * W * CC * SB);
+    p.row_pitch = (unsigned)(CC * SB);
     p.cc_out = (K + 31) / 32;
     p.N = N; p.H = H; p.W = W; p.CC = CC; p.OH = OH; p.OW = OW; p.K = K; p.R = R; p.S = S;
     p.stride = stride; p.pad = pad; p.dil = dil; p.act = act; p.ustride = ustride;
     p.M = N * OH * OW;
     p.group_rows = per_image ? OH * OW : p.M;
-    p.w3_group_stride = per_image ? (unsigned)((long)K * R * S * CC * 192) : 0u;
+    p.w3_group_stride = per_image ? (unsigned)((long)K * R * S * CC * SB) : 0u;
     p.cc_limit = per_image ? cc_limit : nullptr;
     p.OHs = OH; p.OWs = OW; p.o_mul = 1; p.oy_add = 0; p.ox_add = 0;
     p.tap_allow = ~0ull;
@@ -1006,14 +1135,19 @@ __global__ __launch_bounds__(64) void dropout_compact_kernel(const float *__rest
 // not written (the conv never reads them); the zero row M is (by the last block).  A block works inside ONE image: thread t
 // owns 8 packed channels (unit t % (CC * 4)) -- their source indices and multipliers are fetched once -- and walks the rows
 // t / (CC * 4), + 256 / (CC * 4), ... of the block's row range.
+template <int NP>
 __global__ __launch_bounds__(256) void split3_rows_packed_kernel(const float *__restrict__ x, long ld, char *__restrict__ out, long M, int C,
                                                                  int CC, const float *__restrict__ mask, const int *__restrict__ order,
                                                                  const int *__restrict__ cc_limit, long rows_per_image, int chunks) {
+    constexpr int SB = NP * 64;
     const int n = blockIdx.x / chunks, chunk = blockIdx.x - n * chunks;
     const int upr = CC * 4, unit = threadIdx.x % upr, rstep = blockDim.x / upr;
     const int cc = unit >> 2, oct = unit & 3;
-    if ((long)n * rows_per_image >= M) {  // the extra block: the zero row
-        for (int i = threadIdx.x; i < CC * 12; i += blockDim.x) *reinterpret_cast<uint4 *>(out + M * CC * 192 + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+    float scale = 1.f;  // NP = 2: from the bound dass_absmax_rows left in the trailer
+    if constexpr (NP == 2) scale = x3_scale_of(__uint_as_float(*reinterpret_cast<const unsigned *>(out + (M + 1) * CC * SB + 4)));
+    if ((long)n * rows_per_image >= M) {  // the extra block: the zero row (+ the trailer's inverse scale)
+        for (int i = threadIdx.x; i < CC * NP * 4; i += blockDim.x) *reinterpret_cast<uint4 *>(out + M * CC * SB + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+        if (threadIdx.x == 0) *reinterpret_cast<float *>(out + (M + 1) * CC * SB) = x3_inv_of(scale);
         return;
     }
     if (threadIdx.x >= upr * rstep || cc >= cc_limit[n]) return;
@@ -1037,21 +1171,33 @@ __global__ __launch_bounds__(256) void split3_rows_packed_kernel(const float *__
             v0[e] = src[ci[e]] * sc[e];
             v1[e] = src[ci[4 + e]] * sc[4 + e];
         }
-        uint2 a0, a1, a2, b0, b1, b2;
-        split3_4(v0, a0, a1, a2);
-        split3_4(v1, b0, b1, b2);
-        char *d = out + (m * CC + cc) * 192 + oct * 16;
-        *reinterpret_cast<uint4 *>(d) = make_uint4(a0.x, a0.y, b0.x, b0.y);
-        *reinterpret_cast<uint4 *>(d + 64) = make_uint4(a1.x, a1.y, b1.x, b1.y);
-        *reinterpret_cast<uint4 *>(d + 128) = make_uint4(a2.x, a2.y, b2.x, b2.y);
+        char *d = out + (m * CC + cc) * SB + oct * 16;
+        if constexpr (NP == 3) {
+            uint2 a0, a1, a2, b0, b1, b2;
+            split3_4(v0, a0, a1, a2);
+            split3_4(v1, b0, b1, b2);
+            *reinterpret_cast<uint4 *>(d) = make_uint4(a0.x, a0.y, b0.x, b0.y);
+            *reinterpret_cast<uint4 *>(d + 64) = make_uint4(a1.x, a1.y, b1.x, b1.y);
+            *reinterpret_cast<uint4 *>(d + 128) = make_uint4(a2.x, a2.y, b2.x, b2.y);
+        } else {
+            uint2 a0, a1, b0, b1;
+            split2_4(v0 * scale, a0, a1);
+            split2_4(v1 * scale, b0, b1);
+            *reinterpret_cast<uint4 *>(d) = make_uint4(a0.x, a0.y, b0.x, b0.y);
+            *reinterpret_cast<uint4 *>(d + 64) = make_uint4(a1.x, a1.y, b1.x, b1.y);
+        }
     }
 }
 
-// pre-split weights [rows = K * taps][CC][3][32] -> per image [N][rows][CC][3][32] with the channel order of that image
+// pre-split weights [rows = K * taps][CC][NP][32] -> per image [N][rows][CC][NP][32] with the channel order of that image
+// (the trailer -- the weights' scale -- is copied behind the last image)
+template <int NP>
 __global__ __launch_bounds__(256) void w3_pack_per_image_kernel(const unsigned short *__restrict__ w3, unsigned short *__restrict__ out,
                                                                 long rows, int CC, int N, const int *__restrict__ order,
                                                                 const int *__restrict__ cc_limit) {
-    const long units = (long)N * rows * CC * 4;  // 8 packed channels x 3 parts
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        *reinterpret_cast<uint4 *>(out + (long)N * rows * CC * (NP * 32)) = *reinterpret_cast<const uint4 *>(w3 + rows * CC * (NP * 32));
+    const long units = (long)N * rows * CC * 4;  // 8 packed channels x NP parts
     for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (long)gridDim.x * blockDim.x) {
         const int oct = (int)(u & 3);
         long rc = u >> 2;
@@ -1061,17 +1207,17 @@ __global__ __launch_bounds__(256) void w3_pack_per_image_kernel(const unsigned s
         const int n = (int)(rc / rows);
         if (cc >= cc_limit[n]) continue;
         const int *o = order + ((long)n * CC + cc) * 32 + oct * 8;
-        const unsigned short *src = w3 + row * CC * 96;
-        unsigned short v[3][8];
+        const unsigned short *src = w3 + row * CC * (NP * 32);
+        unsigned short v[NP][8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = o[e];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) v[pl][e] = c >= 0 ? src[(c >> 5) * 96 + pl * 32 + (c & 31)] : (unsigned short)0;
+            for (int pl = 0; pl < NP; ++pl) v[pl][e] = c >= 0 ? src[(c >> 5) * (NP * 32) + pl * 32 + (c & 31)] : (unsigned short)0;
         }
-        unsigned short *d = out + (((long)n * rows + row) * CC + cc) * 96 + oct * 8;
+        unsigned short *d = out + (((long)n * rows + row) * CC + cc) * (NP * 32) + oct * 8;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NP; ++pl)
             *reinterpret_cast<uint4 *>(d + pl * 32) = make_uint4(v[pl][0] | ((unsigned)v[pl][1] << 16), v[pl][2] | ((unsigned)v[pl][3] << 16),
                                                                  v[pl][4] | ((unsigned)v[pl][5] << 16), v[pl][6] | ((unsigned)v[pl][7] << 16));
     }
@@ -1096,8 +1242,19 @@ extern "C" int dass_split3_rows_packed(const float *x, int64_t ld, void *out, in
     long chunks = (4096 + images - 1) / images;  // ~4096 blocks; at least 8 rows each
     const long max_chunks = (rows_per_image + 7) / 8;
     if (chunks > max_chunks) chunks = max_chunks;
-    hipLaunchKernelGGL(split3_rows_packed_kernel, dim3((unsigned)(images * chunks + 1)), dim3(256), 0, (hipStream_t)stream, x, (long)ld,
-                       (char *)out, (long)M, C, CC, mask, order, cc_limit, (long)rows_per_image, (int)chunks);
+    hipStream_t st = (hipStream_t)stream;
+    if (g_x3_parts == 2) {
+        if ((ld & 3) || (C & 3) || ((uintptr_t)x & 15)) return DASS_ERR_ARG;
+        char *tr = (char *)out + x3_trailer_off(M, CC, 2);
+        if (hipMemsetAsync(tr, 0, 16, st) != hipSuccess) return DASS_ERR_LAUNCH;
+        const int rc = dass_absmax_rows(x, ld, M, C, mask, rows_per_image, (float *)(tr + 4), stream);
+        if (rc != DASS_OK) return rc;
+        hipLaunchKernelGGL(split3_rows_packed_kernel<2>, dim3((unsigned)(images * chunks + 1)), dim3(256), 0, st, x, (long)ld, (char *)out, (long)M,
+                           C, CC, mask, order, cc_limit, (long)rows_per_image, (int)chunks);
+    } else {
+        hipLaunchKernelGGL(split3_rows_packed_kernel<3>, dim3((unsigned)(images * chunks + 1)), dim3(256), 0, st, x, (long)ld, (char *)out, (long)M,
+                           C, CC, mask, order, cc_limit, (long)rows_per_image, (int)chunks);
+    }
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
@@ -1107,8 +1264,15 @@ extern "C" int dass_w3_pack_per_image(const void *w3, void *out, int64_t rows, i
     if (!w3 || !out || !order || !cc_limit || rows <= 0 || C <= 0 || N <= 0) return DASS_ERR_ARG;
     if (((uintptr_t)out & 15) || ((uintptr_t)w3 & 1)) return DASS_ERR_ARG;
     const int CC = (C + 31) / 32;
-    hipLaunchKernelGGL(w3_pack_per_image_kernel, dim3(dass_grid_1d((long)N * rows * CC * 4, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned short *)w3, (unsigned short *)out, (long)rows, CC, N, order, cc_limit);
+    if (g_x3_parts == 2)
+        hipLaunchKernelGGL(w3_pack_per_image_kernel<2>, dim3(dass_grid_1d((long)N * rows * CC * 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned short *)w3, (unsigned short *)out, (long)rows, CC, N, order, cc_limit);
+    else
+        hipLaunchKernelGGL(w3_pack_per_image_kernel<3>, dim3(dass_grid_1d((long)N * rows * CC * 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned short *)w3, (unsigned short *)out, (long)rows, CC, N, order, cc_limit);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
+
+/* bytes of dass_w3_pack_per_image's output (N copies + the trailer) */
+extern "C" int64_t dass_w3_pack_bytes(int64_t rows, int C, int N) { return (int64_t)N * rows * ((C + 31) / 32) * (g_x3_parts * 64) + 16; }

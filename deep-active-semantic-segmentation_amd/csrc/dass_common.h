@@ -72,20 +72,72 @@ __device__ __forceinline__ void split3_4(f32x4 v, uint2 &p0, uint2 &p1, uint2 &p
     p1 = make_uint2(m0, m1);
     p2 = make_uint2(pk_bf16(sa), pk_bf16(sb));
 }
-// x3 rows (csrc/conv_x3.hip): element (row m, channel k..k+3) of a [rows][cc][3][32] bf16 tensor
-__device__ __forceinline__ void x3_store4(char *base, long m, int cc, int k, f32x4 v) {
-    uint2 q0, q1, q2;
-    split3_4(v, q0, q1, q2);
-    char *d = base + (m * cc + (k >> 5)) * 192 + (k & 31) * 2;
-    *reinterpret_cast<uint2 *>(d) = q0;
-    *reinterpret_cast<uint2 *>(d + 64) = q1;
-    *reinterpret_cast<uint2 *>(d + 128) = q2;
+// ---- x3 operand formats (csrc/conv_x3.hip).  An activation [rows][C] f32 is kept as rows x ceil(C/32) slabs of
+//   [NP parts][32 ch] 2-byte elements (NP * 64 B), then ONE all-zero row (padded taps point at it), then a 16-B trailer
+//   {float inv_scale, uint bound_bits, 0, 0}.
+//   NP = 3 ("bf16x6" engine): x = x0 + x1 + x2, three bf16 parts, exact to 2^-26 |x|; six products per pair; trailer unused (1.0).
+//   NP = 2 ("f16x3" engine): x * s = h0 + h1, two f16 parts (h0 = f16(x s), h1 = f16(x s - h0): 11 + 1 + 11 significant bits,
+//            |x s - h0 - h1| <= 2^-23 |x s|); s = a power of two chosen per TENSOR from a guaranteed bound B >= max |x| so that
+//            B s lies in [2^14, 2^15) (f16 overflows at 65504); three products per pair (h0 g1, h1 g0, h0 g0 -- the dropped
+//            h1 g1 is <= 2^-22 of the product) on the f16 MFMA pipe, f32 accumulation, result multiplied by
+//            inv_scale(a) * inv_scale(b) (exact: powers of two).  gfx950's MFMA honours f16 subnormal inputs
+//            (tools/probes/f16_denorm_probe.hip), so elements far below the bound keep an ABSOLUTE accuracy of 2^-25 / s.
+typedef _Float16 dass_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pk_f16(dass_f32x2 v) {
+    dass_f16x2 h = __builtin_convertvector(v, dass_f16x2);  // RNE
+    return *reinterpret_cast<unsigned *>(&h);
 }
-// the all-zero row (index rows) and nothing else; call from ONE block of a producer kernel
-__device__ __forceinline__ void x3_zero_row(char *base, long rows, int cc) {
-    for (int i = threadIdx.x; i < cc * 12; i += blockDim.x)
-        *reinterpret_cast<uint4 *>(base + rows * cc * 192 + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+__device__ __forceinline__ dass_f32x2 unpk_f16(unsigned u) {
+    const dass_f16x2 h = *reinterpret_cast<const dass_f16x2 *>(&u);
+    return dass_f32x2{(float)h[0], (float)h[1]};
 }
+// power-of-two scale for a tensor whose elements are bounded by `bound`: bound * scale in [2^14, 2^15)
+__device__ __forceinline__ float x3_scale_of(float bound) {
+    const int e = (int)((__float_as_uint(bound) >> 23) & 0xffu);
+    if (e == 0 || e == 255) return 1.f;  // zero / denormal bound (an all-zero tensor), or inf / nan: nothing sensible to scale
+    int se = 268 - e;                    // exponent field of 2^(14 - (e - 127))
+    se = se < 2 ? 2 : (se > 252 ? 252 : se);
+    return __uint_as_float((unsigned)se << 23);
+}
+__device__ __forceinline__ float x3_inv_of(float scale) { return __uint_as_float((254u << 23) - __float_as_uint(scale)); }  // 1 / 2^n
+// four f32 (already multiplied by the tensor's scale) -> the two f16 parts, 8 B each
+__device__ __forceinline__ void split2_4(f32x4 v, uint2 &p0, uint2 &p1) {
+    const dass_f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    const unsigned h0 = pk_f16(a), h1 = pk_f16(b);
+    p0 = make_uint2(h0, h1);
+    p1 = make_uint2(pk_f16(a - unpk_f16(h0)), pk_f16(b - unpk_f16(h1)));
+}
+// element (row m, channels k..k+3) of an x3 tensor with cc channel slabs; NP = 2: v is multiplied by `scale` first
+template <int NP> __device__ __forceinline__ void x3_store4p(char *base, long m, int cc, int k, f32x4 v, float scale) {
+    char *d = base + (m * cc + (k >> 5)) * (NP * 64) + (k & 31) * 2;
+    if constexpr (NP == 3) {
+        uint2 q0, q1, q2;
+        split3_4(v, q0, q1, q2);
+        *reinterpret_cast<uint2 *>(d) = q0;
+        *reinterpret_cast<uint2 *>(d + 64) = q1;
+        *reinterpret_cast<uint2 *>(d + 128) = q2;
+    } else {
+        uint2 q0, q1;
+        split2_4(v * scale, q0, q1);
+        *reinterpret_cast<uint2 *>(d) = q0;
+        *reinterpret_cast<uint2 *>(d + 64) = q1;
+    }
+}
+__device__ __forceinline__ void x3_store4(char *base, long m, int cc, int k, f32x4 v) { x3_store4p<3>(base, m, cc, k, v, 1.f); }
+// runtime-parts form for the streaming producers (BN apply / backward): parts in {2, 3}
+__device__ __forceinline__ void x3_store4r(char *base, long m, int cc, int k, f32x4 v, int parts, float scale) {
+    if (parts == 2) x3_store4p<2>(base, m, cc, k, v, scale);
+    else x3_store4p<3>(base, m, cc, k, v, 1.f);
+}
+// the all-zero row (index rows) + the trailer {inv_scale, bound}; call from ONE block of a producer kernel
+__device__ __forceinline__ void x3_zero_row(char *base, long rows, int cc, int parts = 3, float inv_scale = 1.f, float bound = 0.f) {
+    char *z = base + rows * cc * (parts * 64);
+    for (int i = threadIdx.x; i < cc * parts * 4; i += blockDim.x) *reinterpret_cast<uint4 *>(z + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+    if (threadIdx.x == 0) *reinterpret_cast<uint4 *>(z + cc * parts * 64) = make_uint4(__float_as_uint(inv_scale), __float_as_uint(bound), 0u, 0u);
+}
+// host + device: bytes of an x3 tensor (rows + zero row + trailer) and the trailer's offset
+static inline __host__ __device__ long x3_trailer_off(long rows, int cc, int parts) { return (rows + 1) * cc * (long)(parts * 64); }
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == DASS_ACT_RELU) return v > 0.f ? v : 0.f;

@@ -22,6 +22,7 @@ struct WX3P {
     const char *x3;    // [rows_in + 1][CC][192], row rows_in zero
     float *dw;         // [K][R*S][C] f32, accumulated atomically
     unsigned dy3_bytes, x3_bytes, dy_zero, x_zero, dy_pitch, x_pitch;
+    unsigned dy_tr, x_tr;  // trailers {inv_scale, bound} of the two-part format
     int N, H, W, C, OH, OW, K, R, S, stride, pad, dil;
     int M, KC, CC, ktiles, ctiles, psplit, pix_per_split;
 };
@@ -57,20 +58,20 @@ __device__ __forceinline__ v2u tr16(unsigned addr) {
 // Tile BMK (out channels) x BNC (in channels); NW waves as WARPS_M x WARPS_N.  LDS stage = 32 pixels:
 // operand A (dy): BMK/32 chunks x 3 parts x 2 pixel halves, piece (chunk ch, part pl, half hf) at ((ch*3 + pl)*2 + hf) * 1024;
 // operand B (x) behind it with BNC/32 chunks.
-template <int BMK, int BNC, int WARPS_M, int WARPS_N, int NSTAGE>
-__global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void wgrad_x3_kernel(const WX3P p) {
+// NP: parts per element (dass_common.h "x3 operand formats"): 3 = bf16 triple / six products, 2 = scaled f16 pair / three products
+template <int BMK, int BNC, int WARPS_M, int WARPS_N, int NSTAGE, int NP>
+__device__ __forceinline__ void wgrad_x3_body(const WX3P &p, int wg, char *smem) {
     constexpr int NW = WARPS_M * WARPS_N;
+    constexpr int SB = NP * 64, CHB = NP * 2048;  // bytes of a row-slab in memory / of one 32-channel chunk of a 32-pixel LDS stage
+    constexpr int NTERM = NP == 3 ? 6 : 3;
     constexpr int TMW = BMK / WARPS_M, TNW = BNC / WARPS_N, MT = TMW / 32, NT = TNW / 32;
     constexpr int ACH = BMK / 32, BCH = BNC / 32;           // 32-channel chunks per operand
-    constexpr int A_BYTES = ACH * 6144, B_BYTES = BCH * 6144, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_BYTES = ACH * CHB, B_BYTES = BCH * CHB, STAGE = A_BYTES + B_BYTES;
     constexpr int CHW = (ACH + BCH) / NW;                   // chunks a wave loads (all three parts, both pixel halves)
     static_assert((ACH + BCH) % NW == 0 && CHW >= 1, "chunks must divide over the waves");
     static_assert(ACH % CHW == 0, "a wave loads chunks of ONE operand");
-    constexpr int G = CHW * 6;                              // DMA instructions per wave and slab
+    constexpr int G = CHW * NP * 2;                         // DMA instructions per wave and slab
     static_assert(MT >= 1 && NT >= 1 && NSTAGE >= 2 && NSTAGE <= 3 && G * (NSTAGE - 2) <= 63, "tile");
-    __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE];
-
-    int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int tap = wg % (p.R * p.S);
     wg /= (p.R * p.S);
     const int ct = wg % p.ctiles;
@@ -134,11 +135,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void wgrad_x3_kernel(con
                 const int ch = first_ch + j;
                 const int gch = (loads_a ? k0 : c0) / 32 + ch;                 // chunk index in the tensor
                 const bool ch_ok = gch < (loads_a ? p.KC : p.CC);            // beyond the tensor: zeros
-                const unsigned base = (zero || !ch_ok) ? (loads_a ? p.dy_zero : p.x_zero) : src + (unsigned)(gch * 192);
-                const unsigned dst = __builtin_amdgcn_readfirstlane(st + (loads_a ? 0 : A_BYTES) + ((ch * 3) * 2 + hf) * 1024);
-                wdma16(loads_a ? rsa : rsb, dst, base + chunk16);
-                wdma16(loads_a ? rsa : rsb, dst + 2048, base + 64 + chunk16);
-                wdma16(loads_a ? rsa : rsb, dst + 4096, base + 128 + chunk16);
+                const unsigned base = (zero || !ch_ok) ? (loads_a ? p.dy_zero : p.x_zero) : src + (unsigned)(gch * SB);
+                const unsigned dst = __builtin_amdgcn_readfirstlane(st + (loads_a ? 0 : A_BYTES) + ((ch * NP) * 2 + hf) * 1024);
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) wdma16(loads_a ? rsa : rsb, dst + pl * 2048, base + pl * 64 + chunk16);
             }
             // advance this cursor by 32 pixels
             cur_pix[hf] += 32;
@@ -169,8 +169,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void wgrad_x3_kernel(con
     // (g >> 1); inside the group lane 4 q + pp supplies the address of pixel row q, 4-channel column chunk pp
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
     const unsigned lane_off = (unsigned)((8 * (g >> 1) + q) * 64 + (16 * (g & 1) + 4 * pp) * 2);
-    const unsigned a_rd = smem_base + (unsigned)((wm * (TMW / 32)) * 6144) + lane_off;
-    const unsigned b_rd = smem_base + (unsigned)(A_BYTES + (wn * (TNW / 32)) * 6144) + lane_off;
+    const unsigned a_rd = smem_base + (unsigned)((wm * (TMW / 32)) * CHB) + lane_off;
+    const unsigned b_rd = smem_base + (unsigned)(A_BYTES + (wn * (TNW / 32)) * CHB) + lane_off;
 
     int issued = 0;
 #pragma unroll
@@ -183,35 +183,40 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void wgrad_x3_kernel(con
     // fragments of one 16-pixel k-step: [part][block][pixels 0-3 / 4-7 of this lane's half].  They stay in the registers
     // the asm reads wrote until the explicit lgkmcnt wait (the compiler does not know these loads: cdna_hip_programming.md
     // 5.7 form (iii)); the 16-B operands are assembled inside multiply(), after the wait.
-    v2u a0[3][MT][2], b0[3][NT][2], a1[3][MT][2], b1[3][NT][2];
-    auto load_frags = [&](unsigned abase, unsigned bbase, v2u(&a)[3][MT][2], v2u(&b)[3][NT][2]) {
+    v2u a0[NP][MT][2], b0[NP][NT][2], a1[NP][MT][2], b1[NP][NT][2];
+    auto load_frags = [&](unsigned abase, unsigned bbase, v2u(&a)[NP][MT][2], v2u(&b)[NP][NT][2]) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                b[pl][nt][0] = tr16(bbase + nt * 6144 + pl * 2048);
-                b[pl][nt][1] = tr16(bbase + nt * 6144 + pl * 2048 + 256);
+                b[pl][nt][0] = tr16(bbase + nt * CHB + pl * 2048);
+                b[pl][nt][1] = tr16(bbase + nt * CHB + pl * 2048 + 256);
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                a[pl][mt][0] = tr16(abase + mt * 6144 + pl * 2048);
-                a[pl][mt][1] = tr16(abase + mt * 6144 + pl * 2048 + 256);
+                a[pl][mt][0] = tr16(abase + mt * CHB + pl * 2048);
+                a[pl][mt][1] = tr16(abase + mt * CHB + pl * 2048 + 256);
             }
         }
     };
-    auto multiply = [&](const v2u(&a)[3][MT][2], const v2u(&b)[3][NT][2]) {
+    auto multiply = [&](const v2u(&a)[NP][MT][2], const v2u(&b)[NP][NT][2]) {
         auto frag = [](const v2u(&f)[2]) { return make_uint4(f[0][0], f[0][1], f[1][0], f[1][1]); };
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int term = 0; term < 6; ++term)
+        for (int term = 0; term < NTERM; ++term)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    constexpr int PA_OF[6] = {0, 2, 1, 0, 1, 0}, PB_OF[6] = {2, 0, 1, 1, 0, 0};
-                    const uint4 av = frag(a[PA_OF[term]][mt]), bv = frag(b[PB_OF[term]][nt]);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&av),
-                                                                          *reinterpret_cast<const bf16x8 *>(&bv), acc[mt][nt], 0, 0, 0);
+                    // smallest products first.  NP = 3: (0,2) (2,0) (1,1) (0,1) (1,0) (0,0); NP = 2: (0,1) (1,0) (0,0)
+                    constexpr int PA3[6] = {0, 2, 1, 0, 1, 0}, PB3[6] = {2, 0, 1, 1, 0, 0}, PA2[3] = {0, 1, 0}, PB2[3] = {1, 0, 0};
+                    const uint4 av = frag(a[NP == 3 ? PA3[term] : PA2[term % 3]][mt]), bv = frag(b[NP == 3 ? PB3[term] : PB2[term % 3]][nt]);
+                    if constexpr (NP == 3)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&av),
+                                                                              *reinterpret_cast<const bf16x8 *>(&bv), acc[mt][nt], 0, 0, 0);
+                    else
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8 *>(&av),
+                                                                             *reinterpret_cast<const f16x8 *>(&bv), acc[mt][nt], 0, 0, 0);
                 }
         __builtin_amdgcn_s_setprio(0);
     };
@@ -253,6 +258,13 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void wgrad_x3_kernel(con
     }
     if (total > 0) multiply(a1, b1);
     wwait_vmcnt<0>();
+    if constexpr (NP == 2) {  // undo the operands' per-tensor power-of-two scales (exact)
+        const float inv = *reinterpret_cast<const float *>(p.dy3 + p.dy_tr) * *reinterpret_cast<const float *>(p.x3 + p.x_tr);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] *= inv;
+    }
 
     const long rs = (long)p.R * p.S;
 #pragma unroll
@@ -271,6 +283,37 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void wgrad_x3_kernel(con
     }
 }
 
+template <int BMK, int BNC, int WARPS_M, int WARPS_N, int NSTAGE, int NP> constexpr int wgrad_x3_smem() {
+    return NSTAGE * ((BMK / 32) + (BNC / 32)) * (NP * 2048);
+}
+
+template <int BMK, int BNC, int WARPS_M, int WARPS_N, int NSTAGE, int NP = 3>
+__global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void wgrad_x3_kernel(const WX3P p) {
+    __shared__ __attribute__((aligned(16))) char smem[wgrad_x3_smem<BMK, BNC, WARPS_M, WARPS_N, NSTAGE, NP>()];
+    wgrad_x3_body<BMK, BNC, WARPS_M, WARPS_N, NSTAGE, NP>(p, xcd_remap(blockIdx.x, gridDim.x), smem);
+}
+
+// GROUPED form: one launch computes the weight gradients of MANY conv layers (all deferred layers of a backward pass that
+// share a tile class).  items[i] describes problem i, wg_begin[i] its first workgroup in the grid (wg_begin[n] = grid size);
+// a workgroup finds its problem by binary search over the block-uniform table and runs the same body.  With hundreds of
+// problems in one grid there are enough output tiles to fill the chip WITHOUT cutting the pixel reduction of the 8712-row
+// layers into a dozen atomically-added splits: every workgroup runs the whole reduction of its tile (272 slabs instead of
+// ~20), the per-launch fill / drain / atomic tails of 100 separate launches are paid once, and the problems are ordered
+// longest-first so the long reductions of the early layers start at once.
+template <int BMK, int BNC, int WARPS_M, int WARPS_N, int NSTAGE, int NP>
+__global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void wgrad_x3_group_kernel(const WX3P *__restrict__ items, const int *__restrict__ wg_begin, int n) {
+    __shared__ __attribute__((aligned(16))) char smem[wgrad_x3_smem<BMK, BNC, WARPS_M, WARPS_N, NSTAGE, NP>()];
+    const int wgid = xcd_remap(blockIdx.x, gridDim.x);
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (wg_begin[mid] <= wgid) lo = mid; else hi = mid - 1;
+    }
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    const WX3P p = items[lo];
+    wgrad_x3_body<BMK, BNC, WARPS_M, WARPS_N, NSTAGE, NP>(p, wgid - wg_begin[lo], smem);
+}
+
 static long wx3_split(long base, long M, long target_wgs, long min_slabs) {
     if (dass_get_deterministic()) return 1;  // one pixel split: no cross-workgroup atomics (conv_igemm.hip)
     long want = (target_wgs + base - 1) / base;
@@ -280,7 +323,7 @@ static long wx3_split(long base, long M, long target_wgs, long min_slabs) {
     return want < 1 ? 1 : want;
 }
 
-template <int BMK, int BNC, int WARPS_M, int WARPS_N, int NSTAGE> int launch_wx3(WX3P &p, hipStream_t st, long target, long min_slabs) {
+template <int BMK, int BNC, int WARPS_M, int WARPS_N, int NSTAGE, int NP = 3> int launch_wx3(WX3P &p, hipStream_t st, long target, long min_slabs) {
     p.ktiles = (p.K + BMK - 1) / BMK;
     p.ctiles = (p.C + BNC - 1) / BNC;
     const long base = (long)p.ktiles * p.ctiles * p.R * p.S;
@@ -289,7 +332,7 @@ template <int BMK, int BNC, int WARPS_M, int WARPS_N, int NSTAGE> int launch_wx3
     pps = (pps + 31) / 32 * 32;
     p.pix_per_split = (int)pps;
     p.psplit = (int)((p.M + pps - 1) / pps);
-    hipLaunchKernelGGL((wgrad_x3_kernel<BMK, BNC, WARPS_M, WARPS_N, NSTAGE>), dim3((unsigned)(base * p.psplit)), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
+    hipLaunchKernelGGL((wgrad_x3_kernel<BMK, BNC, WARPS_M, WARPS_N, NSTAGE, NP>), dim3((unsigned)(base * p.psplit)), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
@@ -303,7 +346,9 @@ extern "C" int dass_conv2d_wgrad_x3(const void *x3, const void *dy3, float *dw, 
     if (((uintptr_t)x3 & 15) || ((uintptr_t)dy3 & 15)) return DASS_ERR_ARG;
     if ((long)N * OH * OW >= (1l << 31)) return DASS_ERR_ARG;
     const int CC = (C + 31) / 32, KC = (K + 31) / 32;
-    const long xbytes = ((long)N * H * W + 1) * CC * 192, dbytes = ((long)N * OH * OW + 1) * KC * 192;
+    const int parts = dass_get_x3_parts(), SB = parts * 64;
+    const long xtr = x3_trailer_off((long)N * H * W, CC, parts), dtr = x3_trailer_off((long)N * OH * OW, KC, parts);
+    const long xbytes = xtr + 16, dbytes = dtr + 16;
     if (xbytes >= (1l << 32) || dbytes >= (1l << 32)) return DASS_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (zero_first && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * R * S * C, st) != hipSuccess) return DASS_ERR_LAUNCH;
@@ -313,10 +358,12 @@ extern "C" int dass_conv2d_wgrad_x3(const void *x3, const void *dy3, float *dw, 
     p.dw = dw;
     p.dy3_bytes = (unsigned)dbytes;
     p.x3_bytes = (unsigned)xbytes;
-    p.dy_pitch = (unsigned)(KC * 192);
-    p.x_pitch = (unsigned)(CC * 192);
-    p.dy_zero = (unsigned)((long)N * OH * OW * KC * 192);
-    p.x_zero = (unsigned)((long)N * H * W * CC * 192);
+    p.dy_pitch = (unsigned)(KC * SB);
+    p.x_pitch = (unsigned)(CC * SB);
+    p.dy_zero = (unsigned)((long)N * OH * OW * KC * SB);
+    p.x_zero = (unsigned)((long)N * H * W * CC * SB);
+    p.dy_tr = (unsigned)dtr;
+    p.x_tr = (unsigned)xtr;
     p.N = N; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K; p.R = R; p.S = S;
     p.stride = stride; p.pad = pad; p.dil = dil;
     p.M = N * OH * OW;
@@ -325,6 +372,148 @@ extern "C" int dass_conv2d_wgrad_x3(const void *x3, const void *dy3, float *dw, 
     static const long min_slabs = getenv("DASS_WX3_MINSLABS") ? atol(getenv("DASS_WX3_MINSLABS")) : 16;
     static const int force = getenv("DASS_WX3_TILE") ? atoi(getenv("DASS_WX3_TILE")) : 0;
     const bool big = (K > 64 && C > 64 && force != 2) || force == 1;
+    if (parts == 2) {
+        if (big) return launch_wx3<128, 128, 4, 2, 3, 2>(p, st, target, min_slabs);
+        return launch_wx3<64, 64, 2, 2, 3, 2>(p, st, target, min_slabs);
+    }
     if (big) return launch_wx3<128, 128, 4, 2, 3>(p, st, target, min_slabs);
     return launch_wx3<64, 64, 2, 2, 3>(p, st, target, min_slabs);
+}
+
+// ---- grouped launch (see wgrad_x3_group_kernel).  items: n x 16 int64 on the HOST
+//   {x3, dy3, dw, N, H, W, C, OH, OW, K, R, S, stride, pad, dil, 0};  dw must be zeroed (tiles are ADDED: big-M problems are still cut
+// into pixel ranges of at most DASS_WX3_GROUP_SLABS 32-pixel slabs, default 512, so no workgroup runs much longer than the
+// rest).  scratch: device buffer of dass_conv2d_wgrad_x3_group_scratch_bytes(n) for the problem table (written by an
+// asynchronous copy on `stream`: keep it alive until the launches have run, do not reuse it for another call before that).
+extern "C" int64_t dass_conv2d_wgrad_x3_group_scratch_bytes(int n) { return (int64_t)(n > 0 ? n : 1) * (sizeof(WX3P) + 8) + 64; }
+
+namespace {
+struct GroupItem {
+    WX3P p;
+    long wgs;
+    int slabs;
+};
+
+template <int BMK, int BNC, int WARPS_M, int WARPS_N, int NSTAGE, int NP>
+int launch_group(GroupItem *it, int n, char *scratch, hipStream_t st) {
+    if (n == 0) return DASS_OK;
+    // longest reductions first: the hardware hands out workgroups in grid order
+    for (int i = 1; i < n; ++i) {  // insertion sort (n is a few hundred)
+        GroupItem key = it[i];
+        int j = i - 1;
+        while (j >= 0 && it[j].slabs < key.slabs) {
+            it[j + 1] = it[j];
+            --j;
+        }
+        it[j + 1] = key;
+    }
+    // pinned staging tables (truly asynchronous copies), a ring of 8: a slot is rewritten only after the copy out of it, issued
+    // eight grouped launches earlier, has completed -- the host never waits for the stream in steady state
+    struct Slot {
+        WX3P *p = nullptr;
+        int *b = nullptr;
+        int cap = 0;
+        hipEvent_t done = nullptr;
+        bool used = false;
+    };
+    static thread_local Slot ring[8];
+    static thread_local int next_slot = 0;
+    Slot &sl = ring[next_slot];
+    next_slot = (next_slot + 1) & 7;
+    if (sl.used && hipEventSynchronize(sl.done) != hipSuccess) return DASS_ERR_LAUNCH;
+    if (sl.cap < n) {
+        if (sl.p) { (void)hipHostFree(sl.p); (void)hipHostFree(sl.b); }
+        sl.cap = n + 64;
+        if (hipHostMalloc((void **)&sl.p, sizeof(WX3P) * sl.cap) != hipSuccess || hipHostMalloc((void **)&sl.b, sizeof(int) * (sl.cap + 1)) != hipSuccess) {
+            sl.cap = 0;
+            sl.p = nullptr;
+            return DASS_ERR_LAUNCH;
+        }
+    }
+    if (!sl.done && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) return DASS_ERR_LAUNCH;
+    WX3P *host_p = sl.p;
+    int *host_b = sl.b;
+    long total = 0;
+    for (int i = 0; i < n; ++i) {
+        host_p[i] = it[i].p;
+        host_b[i] = (int)total;
+        total += it[i].wgs;
+    }
+    host_b[n] = (int)total;
+    if (total >= (1l << 31)) return DASS_ERR_UNSUPPORTED;
+    WX3P *dev_p = reinterpret_cast<WX3P *>(scratch);
+    int *dev_b = reinterpret_cast<int *>(scratch + sizeof(WX3P) * n);
+    if (hipMemcpyAsync(dev_p, host_p, sizeof(WX3P) * n, hipMemcpyHostToDevice, st) != hipSuccess) return DASS_ERR_LAUNCH;
+    if (hipMemcpyAsync(dev_b, host_b, sizeof(int) * (n + 1), hipMemcpyHostToDevice, st) != hipSuccess) return DASS_ERR_LAUNCH;
+    if (hipEventRecord(sl.done, st) != hipSuccess) return DASS_ERR_LAUNCH;
+    sl.used = true;
+    hipLaunchKernelGGL((wgrad_x3_group_kernel<BMK, BNC, WARPS_M, WARPS_N, NSTAGE, NP>), dim3((unsigned)total), dim3(64 * WARPS_M * WARPS_N), 0, st, dev_p, dev_b, n);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+}  // namespace
+
+extern "C" int dass_conv2d_wgrad_x3_group(const int64_t *items, int n, void *scratch, int64_t scratch_bytes, void *stream) {
+    if (!items || n <= 0 || !scratch || ((uintptr_t)scratch & 15)) return DASS_ERR_ARG;
+    if (scratch_bytes < dass_conv2d_wgrad_x3_group_scratch_bytes(n)) return DASS_ERR_ARG;
+    const int parts = dass_get_x3_parts(), SB = parts * 64;
+    static const long cap_slabs = getenv("DASS_WX3_GROUP_SLABS") ? atol(getenv("DASS_WX3_GROUP_SLABS")) : 512;
+    GroupItem *big = new GroupItem[n], *small = new GroupItem[n];
+    int nb = 0, ns = 0, rc = DASS_OK;
+    for (int i = 0; i < n && rc == DASS_OK; ++i) {
+        const int64_t *d = items + 16 * i;
+        const void *x3 = (const void *)d[0], *dy3 = (const void *)d[1];
+        float *dw = (float *)d[2];
+        const int N = (int)d[3], H = (int)d[4], W = (int)d[5], C = (int)d[6], OH = (int)d[7], OW = (int)d[8], K = (int)d[9], R = (int)d[10],
+                  S = (int)d[11], stride = (int)d[12], pad = (int)d[13], dil = (int)d[14];
+        if (!x3 || !dy3 || !dw || ((uintptr_t)x3 & 15) || ((uintptr_t)dy3 & 15)) rc = DASS_ERR_ARG;
+        if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || K <= 0 || R <= 0 || S <= 0 || stride < 1 || dil < 1) rc = DASS_ERR_ARG;
+        if (rc != DASS_OK) break;
+        if ((long)N * OH * OW >= (1l << 31)) { rc = DASS_ERR_ARG; break; }
+        const int CC = (C + 31) / 32, KC = (K + 31) / 32;
+        const long xtr = x3_trailer_off((long)N * H * W, CC, parts), dtr = x3_trailer_off((long)N * OH * OW, KC, parts);
+        if (xtr + 16 >= (1l << 32) || dtr + 16 >= (1l << 32)) { rc = DASS_ERR_UNSUPPORTED; break; }
+        const bool is_big = K > 64 && C > 64;
+        GroupItem &g = is_big ? big[nb++] : small[ns++];
+        WX3P &p = g.p;
+        p.dy3 = (const char *)dy3; p.x3 = (const char *)x3; p.dw = dw;
+        p.dy3_bytes = (unsigned)(dtr + 16); p.x3_bytes = (unsigned)(xtr + 16);
+        p.dy_pitch = (unsigned)(KC * SB); p.x_pitch = (unsigned)(CC * SB);
+        p.dy_zero = (unsigned)((long)N * OH * OW * KC * SB); p.x_zero = (unsigned)((long)N * H * W * CC * SB);
+        p.dy_tr = (unsigned)dtr; p.x_tr = (unsigned)xtr;
+        p.N = N; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K; p.R = R; p.S = S;
+        p.stride = stride; p.pad = pad; p.dil = dil;
+        p.M = N * OH * OW; p.KC = KC; p.CC = CC;
+        const int tile = is_big ? 128 : 64;
+        p.ktiles = (K + tile - 1) / tile;
+        p.ctiles = (C + tile - 1) / tile;
+        long split = dass_get_deterministic() ? 1 : ((long)p.M + 32 * cap_slabs - 1) / (32 * cap_slabs);
+        long pps = (p.M + split - 1) / split;
+        pps = (pps + 31) / 32 * 32;
+        p.pix_per_split = (int)pps;
+        p.psplit = (int)((p.M + pps - 1) / pps);
+        g.wgs = (long)p.ktiles * p.ctiles * R * S * p.psplit;
+        g.slabs = (int)(pps / 32);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char *sc = (char *)scratch;
+    static const int gtile = getenv("DASS_WX3_GROUP_TILE") ? atoi(getenv("DASS_WX3_GROUP_TILE")) : 1;  // tuning knob (measured: 6.9 / 10.7 / 9.3 / 10.1 ms per R101 step for 1 / 2 / 3 / 0)
+    if (rc == DASS_OK) {
+        if (parts == 2) {
+            if (gtile == 1) rc = launch_group<128, 128, 2, 2, 2, 2>(big, nb, sc, st);       // 4 waves of 64 x 64, two 32 KB stages: two workgroups per CU
+            else if (gtile == 2) rc = launch_group<128, 128, 2, 2, 3, 2>(big, nb, sc, st);  // the same with three stages (one workgroup per CU)
+            else if (gtile == 3) rc = launch_group<128, 128, 4, 2, 2, 2>(big, nb, sc, st);  // 8 waves of 32 x 64, two stages
+            else rc = launch_group<128, 128, 4, 2, 3, 2>(big, nb, sc, st);
+        } else {
+            rc = launch_group<128, 128, 4, 2, 3, 3>(big, nb, sc, st);
+        }
+    }
+    if (rc == DASS_OK) {
+        char *sc2 = sc + ((sizeof(WX3P) * nb + sizeof(int) * (nb + 1) + 63) / 64) * 64;
+        if (parts == 2) rc = launch_group<64, 64, 2, 2, 3, 2>(small, ns, sc2, st);
+        else rc = launch_group<64, 64, 2, 2, 3, 3>(small, ns, sc2, st);
+    }
+    delete[] big;
+    delete[] small;
+    return rc;
 }

@@ -16,13 +16,15 @@ import torch
 
 from ._lib import check, lib
 
-F32, BF16, F32X3, F32X6 = 0, 1, 2, 3
+F32, BF16, F32X3, F32X6, F16X3 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 
 _state = {"dtype": torch.float32, "f32_mma": os.environ.get("DASS_F32_MMA", "bf16x6"),
           "x3": os.environ.get("DASS_X3", "select"), "mc_sparse": os.environ.get("DASS_MC_SPARSE", "1") != "0"}
 assert _state["x3"] in ("off", "infer", "select", "all"), "DASS_X3 must be off, infer, select or all"
-assert _state["f32_mma"] in ("f32", "bf16x3", "bf16x6"), "DASS_F32_MMA must be f32, bf16x3 or bf16x6"
+assert _state["f32_mma"] in ("f32", "bf16x3", "bf16x6", "f16x3"), "DASS_F32_MMA must be f32, bf16x3, bf16x6 or f16x3"
+_state["x3_f16"] = os.environ.get("DASS_X3_F16", "all")  # where the pre-split kernels run under the f16x3 engine
+assert _state["x3_f16"] in ("off", "infer", "select", "all")
 
 
 def set_compute_dtype(dtype):
@@ -42,10 +44,27 @@ def set_f32_mma(mode):
                product to below f32 rounding at 3/8 of the matrix-pipe time -- same parity bars as "f32";
       "f32"    v_mfma_f32_32x32x2_f32, the plain f32 fma chain;
       "bf16x3" two parts, three products (DASS_F32X3): 17-bit products (~4.5e-6 per conv), 3/16 of the pipe time;
-               does NOT meet the 1e-3 logit bar on MobileNet -- a fast training mode, not a parity mode.
+               does NOT meet the 1e-3 logit bar on MobileNet -- a fast training mode, not a parity mode;
+      "f16x3"  the pre-split kernels in their two-part mode (dass_set_x3_parts(2)): every operand tensor is scaled by a power of
+               two (from a guaranteed bound of its max |x|) and split into TWO f16 parts -- 23 significant bits -- and three
+               products per pair run on the f16 MFMA pipe: the f32 product to 2^-22, half the matrix work of "bf16x6"; same
+               parity bars (include/dass_hip.h "dass_set_x3_parts").  Layers the pre-split kernels do not take (<= 32 output
+               channels, stems, depthwise) run the classic kernels exactly as under "bf16x6".
     Initial value from the environment variable DASS_F32_MMA."""
-    assert mode in ("f32", "bf16x3", "bf16x6")
+    assert mode in ("f32", "bf16x3", "bf16x6", "f16x3")
     _state["f32_mma"] = mode
+    check(lib.dass_set_x3_parts(2 if mode == "f16x3" else 3), "dass_set_x3_parts")
+
+
+def x3_parts():
+    """parts per element of the x3 operand format in force (3 = bf16 triple, 2 = scaled f16 pair)"""
+    return 2 if _state["f32_mma"] == "f16x3" else 3
+
+
+def _x3_mode():
+    """effective placement of the pre-split kernels: DASS_X3 under "bf16x6", DASS_X3_F16 (default "all") under "f16x3" -- with
+    4 B instead of 6 B per split element and half the products, the all-layers form pays in training as well"""
+    return _state["x3_f16"] if _state["f32_mma"] == "f16x3" else _state["x3"]
 
 
 def f32_mma():
@@ -67,7 +86,12 @@ def set_x3_pipeline(mode):
     Same six products in the same order either way: results agree to the last bit or two."""
     mode = {True: "all", False: "off"}.get(mode, mode)
     assert mode in ("off", "infer", "select", "all")
-    _state["x3"] = mode
+    _state["x3_f16" if _state["f32_mma"] == "f16x3" else "x3"] = mode
+
+
+def x3_mode():
+    """the placement set_x3_pipeline() would have to be given to restore the current state"""
+    return _x3_mode()
 
 
 def set_mc_sparse(on):
@@ -89,30 +113,35 @@ def set_deterministic(on):
 
 if os.environ.get("DASS_DETERMINISTIC", "0") == "1":
     lib.dass_set_deterministic(1)
+if _state["f32_mma"] == "f16x3":
+    lib.dass_set_x3_parts(2)
 
 
 def x3_pipeline(training=False):
     """is the pre-split engine on for an inference call site (training=False) / for a call that records autograd"""
-    if _state["f32_mma"] != "bf16x6":
+    if _state["f32_mma"] not in ("bf16x6", "f16x3"):
         return False
-    return _state["x3"] == "all" or (_state["x3"] in ("infer", "select") and not training)
+    mode = _x3_mode()
+    return mode == "all" or (mode in ("infer", "select") and not training)
 
 
 def _x3_train_layer(taps, red_channels):
     """training launches that go to the pre-split engine: all of them ("all") or the long 3x3 reductions ("select")"""
-    if _state["f32_mma"] != "bf16x6":
+    if _state["f32_mma"] not in ("bf16x6", "f16x3"):
         return False
-    return _state["x3"] == "all" or (_state["x3"] == "select" and taps >= _SELECT[0] and red_channels >= _SELECT[1])
+    mode = _x3_mode()
+    return mode == "all" or (mode == "select" and taps >= _SELECT[0] and red_channels >= _SELECT[1])
 
 
 _SELECT = (int(os.environ.get("DASS_X3_SELECT_TAPS", "9")), int(os.environ.get("DASS_X3_SELECT_C", "256")))  # measured optimum
+_X3_MIN_ROWS = 256  # output rows below which a conv stays on the classic kernel
 
 
 def _cdt(t):
     """dtype code for the MFMA conv entry points"""
     d = _dt(t)
     if d == F32:
-        return {"f32": F32, "bf16x3": F32X3, "bf16x6": F32X6}[_state["f32_mma"]]
+        return {"f32": F32, "bf16x3": F32X3, "bf16x6": F32X6, "f16x3": F32X6}[_state["f32_mma"]]
     return d
 
 
@@ -228,7 +257,7 @@ def split3_rows_packed(x, ld, m, c, mask, order, lim, rows_per_image):
 def w3_pack_per_image(w3, rows, c, order, lim):
     """pre-split weight operand -> one copy per image in that image's channel order"""
     n = order.shape[0]
-    out = torch.empty((n * rows * ((c + 31) // 32) * 192,), dtype=torch.uint8, device=order.device)
+    out = torch.empty((lib.dass_w3_pack_bytes(rows, c, n),), dtype=torch.uint8, device=order.device)
     check(lib.dass_w3_pack_per_image(_p(w3), _p(out), rows, c, n, _p(order), _p(lim), _stream()), "dass_w3_pack_per_image")
     return out
 
@@ -259,7 +288,7 @@ def x3_operand(t, xs, ld, m, c, nc_scale=None, rows_per_image=1):
     tensor (`t._dass_x3`, valid while the tensor is unmodified) or converted now by dass_split3_rows"""
     if nc_scale is None:
         hit = t.__dict__.get("_dass_x3") if hasattr(t, "__dict__") else None
-        if hit is not None and hit[0] == (t.data_ptr(), t._version, m, c):
+        if hit is not None and hit[0] == (t.data_ptr(), t._version, m, c, x3_parts()):
             return hit[1]
         buf = split3_rows(xs, ld, m, c)
         if hasattr(t, "__dict__"):
@@ -269,7 +298,29 @@ def x3_operand(t, xs, ld, m, c, nc_scale=None, rows_per_image=1):
 
 
 def attach_x3(t, buf, m, c):
-    t.__dict__["_dass_x3"] = ((t.data_ptr(), t._version, m, c), buf)
+    t.__dict__["_dass_x3"] = ((t.data_ptr(), t._version, m, c, x3_parts()), buf)
+
+
+def attached_x3(t, m, c):
+    """the split rows a producer attached to `t` (None when absent or stale)"""
+    hit = t.__dict__.get("_dass_x3") if hasattr(t, "__dict__") else None
+    return hit[1] if hit is not None and hit[0] == (t.data_ptr(), t._version, m, c, x3_parts()) else None
+
+
+def x3_bound_ptr(buf):
+    """device float: the bound of max |x| kept in the trailer of a two-part x3 buffer (behind its inverse scale)"""
+    return ctypes.c_void_p(buf.data_ptr() + buf.numel() - 12)
+
+
+def bound_of(t, xs, ld, m, c):
+    """-> (keepalive, pointer) of a device float >= max |t|: from the trailer of t's attached two-part rows, else by one
+    dass_absmax_rows pass (rows xs / ld)"""
+    buf = attached_x3(t, m, c) if x3_parts() == 2 else None
+    if buf is not None:
+        return buf, x3_bound_ptr(buf)
+    b = torch.zeros((1,), dtype=torch.float32, device=xs.device)
+    check(lib.dass_absmax_rows(_p(xs), ld, m, c, None, 1, _p(b), _stream()), "dass_absmax_rows")
+    return b, _p(b)
 
 
 def channel_stats(x, ld, m, k):
@@ -342,7 +393,7 @@ def bn_sums_path(bn, k):
 def _bn_sums(k, dev):
     """a zeroed [2][k] f64 slice: cut from an arena cleared by one memset per ~20 train steps (never handed out twice)"""
     a = _bn_sum_arena
-    need = (2 * k + 63) // 64 * 64
+    need = (2 * k + (k + 1) // 2 + 63) // 64 * 64  # (+ K floats: the backward reduce keeps every channel's max |dz| there)
     if a["buf"] is None or a["buf"].device != dev or a["off"] + need > a["buf"].numel():
         a["buf"] = torch.zeros((max(1 << 22, need),), dtype=torch.float64, device=dev)
         a["off"] = 0
@@ -469,21 +520,29 @@ def _krsc_master(weight):
     return wp
 
 
-def weight_operand(weight, mode, dtype, cpad=None):
-    """mode 0: [K][R][S][Cpad] forward operand; mode 1: [C][R][S][K] flipped dgrad operand.
+def _split_fmt(dtype, x3):
+    """pre-split operand format of an f32 conv weight: None (plain), F32X6 (three bf16 parts: classic bf16x6 kernel, pre-split
+    kernels in their three-part mode) or F16X3 (two scaled f16 parts: pre-split kernels under the "f16x3" engine)"""
+    if dtype != torch.float32 or _state["f32_mma"] not in ("bf16x6", "f16x3"):
+        return None
+    return F16X3 if (x3 and _state["f32_mma"] == "f16x3") else F32X6
+
+
+def weight_operand(weight, mode, dtype, cpad=None, x3=False):
+    """mode 0: [K][R][S][Cpad] forward operand; mode 1: [C][R][S][K] flipped dgrad operand; x3: for the pre-split kernels.
     Cached on (storage, version) so eval / MC passes transform once."""
     k, c, r, s = weight.shape
     cdst = c if cpad is None else cpad
-    split6 = dtype == torch.float32 and _state["f32_mma"] == "bf16x6"
+    split6 = _split_fmt(dtype, x3)
     key = (weight.data_ptr(), weight._version, mode, dtype, cdst, tuple(weight.shape), split6)
-    hit = _wcache.get((id(weight), mode))
+    hit = _wcache.get((id(weight), mode, split6))
     if hit is not None and hit[0] == key and hit[2]() is weight:
         return hit[1]
     master = _krsc_master(weight)
     if split6:
         if master.data_ptr() == weight.data_ptr():  # zero-copy master: eligible for the one-launch refresh of all weights
-            return _split6_registered(weight, master, mode, cdst)
-        op = _split6_operand(master, k, r, s, c, cdst, mode)
+            return _split6_registered(weight, master, mode, cdst, split6)
+        op = _split6_operand(master, k, r, s, c, cdst, mode, split6)
     elif mode == 0 and dtype == torch.float32 and cdst == c:
         op = master
     else:
@@ -496,29 +555,29 @@ def weight_operand(weight, mode, dtype, cpad=None):
     if len(_wcache) > 4096:  # entries of parameters that no longer exist
         for kk in [kk for kk, v in _wcache.items() if v[2]() is None]:
             del _wcache[kk]
-    _wcache[(id(weight), mode)] = (key, op, weakref.ref(weight))
+    _wcache[(id(weight), mode, split6)] = (key, op, weakref.ref(weight))
     return op
 
 
 class _SplitEntry(object):
-    __slots__ = ("weight", "master", "mode", "cdst", "op", "version", "items")
+    __slots__ = ("weight", "master", "mode", "cdst", "op", "version", "items", "fmt")
 
 
-_split_reg = {"entries": {}, "table_key": None, "table": None}
+_split_reg = {"entries": {}, "table_key": {}, "table": {}}
 
 
-def _split6_registered(weight, master, mode, cdst):
-    """bf16x6 operand of a parameter, refreshed together with every other registered conv weight in ONE launch when
-    its version went stale (an optimizer step bumps them all): dass_weight_split_batch."""
+def _split6_registered(weight, master, mode, cdst, fmt=F32X6):
+    """pre-split operand (format fmt) of a parameter, refreshed together with every other registered conv weight of that format
+    in ONE call when its version went stale (an optimizer step bumps them all): dass_weight_split_batch(_f16)."""
     k, c, r, s = weight.shape
-    ent = _split_reg["entries"].get((id(weight), mode))
+    ent = _split_reg["entries"].get((id(weight), mode, fmt))
     if ent is None or ent.weight() is not weight or ent.master.data_ptr() != master.data_ptr() or ent.cdst != cdst:
         ent = _SplitEntry()
-        ent.weight, ent.master, ent.mode, ent.cdst, ent.version = weakref.ref(weight), master, mode, cdst, -1
+        ent.weight, ent.master, ent.mode, ent.cdst, ent.version, ent.fmt = weakref.ref(weight), master, mode, cdst, -1, fmt
         rows, red = (k, cdst) if mode == 0 else (c, k)
-        ent.op = torch.empty((lib.dass_weight_split_bytes(rows, r, s, red),), dtype=torch.uint8, device=weight.device)
+        ent.op = torch.empty((lib.dass_weight_operand_bytes(rows, r, s, red, fmt),), dtype=torch.uint8, device=weight.device)
         ent.items = ((rows + 31) // 32) * r * s * ((red + 31) // 32)  # tiles of 32 rows x one slab
-        _split_reg["entries"][(id(weight), mode)] = ent
+        _split_reg["entries"][(id(weight), mode, fmt)] = ent
     if ent.version != weight._version:
         dead = [kk for kk, e in _split_reg["entries"].items() if e.weight() is None]
         for kk in dead:  # parameters that no longer exist: release their operands
@@ -526,39 +585,51 @@ def _split6_registered(weight, master, mode, cdst):
         stale = []
         for e in _split_reg["entries"].values():
             wt = e.weight()
-            if e.version != wt._version and wt.device == weight.device and wt.data_ptr() == e.master.data_ptr():
+            if e.fmt == fmt and e.version != wt._version and wt.device == weight.device and wt.data_ptr() == e.master.data_ptr():
                 stale.append((e, wt))
         key = tuple((e.master.data_ptr(), e.mode, e.op.data_ptr()) for e, _ in stale)
-        if _split_reg["table_key"] != key:
+        if _split_reg["table_key"].get(fmt) != key:
             rows_, start, acc = [], [], 0
             for e, wt in stale:
                 kk, cc, rr, ss = wt.shape
                 rows_.append([e.master.data_ptr(), e.op.data_ptr(), kk, rr, ss, cc, e.cdst, e.mode])
                 start.append(acc)
                 acc += e.items
-            _split_reg["table"] = (torch.tensor(rows_, dtype=torch.int64).to(weight.device), torch.tensor(start, dtype=torch.int64).to(weight.device), acc)
-            _split_reg["table_key"] = key
-        desc, start_t, total = _split_reg["table"]
-        check(lib.dass_weight_split_batch(_p(desc), _p(start_t), len(stale), total, _stream()), "dass_weight_split_batch")
+            _split_reg["table"][fmt] = (torch.tensor(rows_, dtype=torch.int64).to(weight.device), torch.tensor(start, dtype=torch.int64).to(weight.device), acc)
+            _split_reg["table_key"][fmt] = key
+        desc, start_t, total = _split_reg["table"][fmt]
+        if fmt == F16X3:
+            check(lib.dass_weight_split_batch_f16(_p(desc), _p(start_t), len(stale), total, _stream()), "dass_weight_split_batch_f16")
+        else:
+            check(lib.dass_weight_split_batch(_p(desc), _p(start_t), len(stale), total, _stream()), "dass_weight_split_batch")
         for e, wt in stale:
             e.version = wt._version
     return ent.op
 
 
-def _split6_operand(master, k, r, s, c, cdst, mode):
-    """DASS_F32X6 conv operand: the three bf16 parts of every weight, slab-major (dass_weight_transform)"""
-    nbytes = lib.dass_weight_split_bytes(k if mode == 0 else c, r, s, cdst if mode == 0 else k)
-    op = torch.empty((nbytes,), dtype=torch.uint8, device=master.device)
-    check(lib.dass_weight_transform(_p(master), _p(op), k, r, s, c, cdst, mode, F32X6, _stream()), "dass_weight_transform")
+def _split6_operand(master, k, r, s, c, cdst, mode, fmt=F32X6):
+    """pre-split conv operand of one weight tensor: DASS_F32X6 (three bf16 parts, dass_weight_transform) or DASS_F16X3 (two
+    scaled f16 parts + trailer: a one-entry dass_weight_split_batch_f16)"""
+    rows, red = (k, cdst) if mode == 0 else (c, k)
+    op = torch.empty((lib.dass_weight_operand_bytes(rows, r, s, red, fmt),), dtype=torch.uint8, device=master.device)
+    if fmt == F16X3:
+        desc = torch.tensor([[master.data_ptr(), op.data_ptr(), k, r, s, c, cdst, mode]], dtype=torch.int64).to(master.device)
+        start = torch.zeros((1,), dtype=torch.int64, device=master.device)
+        total = ((rows + 31) // 32) * r * s * ((red + 31) // 32)
+        check(lib.dass_weight_split_batch_f16(_p(desc), _p(start), 1, total, _stream()), "dass_weight_split_batch_f16")
+        op._dass_keep = (master, desc, start)  # (the launches read these asynchronously)
+    else:
+        check(lib.dass_weight_transform(_p(master), _p(op), k, r, s, c, cdst, mode, F32X6, _stream()), "dass_weight_transform")
     return op
 
 
-def prepare_conv_weight(w_krsc, mode=0):
-    """tools / bench: the operand conv_launch() wants for a raw [K][R][S][C] f32 (or bf16) weight tensor in the
-    current engine (identity except for bf16x6, which multiplies pre-split weights)"""
-    if w_krsc.dtype == torch.float32 and _state["f32_mma"] == "bf16x6":
+def prepare_conv_weight(w_krsc, mode=0, x3=False):
+    """tools / bench: the operand conv_launch() (x3=True: conv_x3_launch()) wants for a raw [K][R][S][C] f32 (or bf16) weight
+    tensor in the current engine (identity except for the split engines, which multiply pre-split weights)"""
+    fmt = _split_fmt(w_krsc.dtype, x3)
+    if fmt:
         k, r, s, c = w_krsc.shape
-        return _split6_operand(w_krsc.contiguous(), k, r, s, c, c, mode)
+        return _split6_operand(w_krsc.contiguous(), k, r, s, c, c, mode, fmt)
     return w_krsc
 
 
@@ -660,7 +731,11 @@ class _ConvBnAct(torch.autograd.Function):
         taps = r * weight.shape[3]
         x3_on = x3_pipeline(training=need_grad)  # the whole network runs pre-split: producers hand split rows on
         x3_fwd = x3_on or (need_grad and _x3_train_layer(taps, c))
-        use_x3 = (x3_fwd and dt == torch.float32 and not spec.depthwise and not rowtap and not image_input and k > 32)
+        # (a handful of rows -- the ASPP image-pool 1x1 over [N, C, 1, 1] -- stays on the classic kernel: its tiles would be
+        # padding, and under "f16x3" its operands then stay exact: the two-sample-per-channel BN behind it amplifies every
+        # rounding of that conv by ~1e3, tests/test_grad_parity_gpu.py)
+        use_x3 = (x3_fwd and dt == torch.float32 and not spec.depthwise and not rowtap and not image_input and k > 32
+                  and m >= _X3_MIN_ROWS)
         dims = (n, h, w, c, oh, ow, k, r, weight.shape[3], spec.stride, spec.pad, spec.dil)
         if fuse and use_x3:
             scale = shift = None
@@ -673,9 +748,10 @@ class _ConvBnAct(torch.autograd.Function):
             if in_scale is not None:
                 assert not need_grad and tuple(in_scale.shape) == (n, c) and in_scale.dtype == torch.float32
             x3 = x3_operand(x, xs, ldx, n * h * w, c, in_scale, h * w)
-            w_op = weight_operand(weight, 0, dt, cpad=c)
-            want_y3 = getattr(spec, "emit_x3", False) and nc_scale is None and kpad == k
-            y3 = x3_alloc(m, k, dev) if want_y3 else None
+            w_op = weight_operand(weight, 0, dt, cpad=c, x3=True)
+            # (two-part format: the fused x3 output would need the OUTPUT's bound before the launch; the consumer converts)
+            want_y3 = getattr(spec, "emit_x3", False) and nc_scale is None and kpad == k and x3_parts() == 3
+            y3 = x3_alloc_for(m, k, dev) if want_y3 else None
             conv_x3_launch(x3, w_op, out, ldo, dims, y3=y3, scale=scale, shift=shift, residual=res_t, ldr=ldr or 0, act=spec.act)
             if y3 is not None:
                 attach_x3(out, y3, m, k)
@@ -712,7 +788,7 @@ class _ConvBnAct(torch.autograd.Function):
                     x3 = x3_operand(x, xs, ldx, n * h * w, c)
                     x3_saved = x3 if x3_on else None
                     ws = _x3_workspace(dev)
-                    check(lib.dass_conv2d_x3_sums(_p(x3), _p(weight_operand(weight, 0, dt, cpad=c)), _p(y_raw), k, n, h, w, c, oh, ow, k, r,
+                    check(lib.dass_conv2d_x3_sums(_p(x3), _p(weight_operand(weight, 0, dt, cpad=c, x3=True)), _p(y_raw), k, n, h, w, c, oh, ow, k, r,
                                                   weight.shape[3], spec.stride, spec.pad, spec.dil, _p(sums), _p(ws), ws.numel(),
                                                   _stream()), "dass_conv2d_x3_sums")
                 else:
@@ -722,7 +798,7 @@ class _ConvBnAct(torch.autograd.Function):
             elif use_x3:
                 x3 = x3_operand(x, xs, ldx, n * h * w, c)
                 x3_saved = x3 if x3_on else None  # "select": the weight gradient stays on the classic kernel (f32 rows)
-                w_op = weight_operand(weight, 0, dt, cpad=c)
+                w_op = weight_operand(weight, 0, dt, cpad=c, x3=True)
                 partial = None
                 if batch_stats:
                     partial = torch.empty((lib.dass_conv2d_igemm_stats_rows(m), 2, k), dtype=torch.float32, device=dev)
@@ -749,7 +825,7 @@ class _ConvBnAct(torch.autograd.Function):
                 scale, shift = None, (bias.detach().float() if bias is not None else None)
             out3 = None
             if ((x3_on or (need_grad and getattr(spec, "x3_consumer", False))) and dt == torch.float32
-                    and getattr(spec, "emit_x3", True) and k >= 32 and kpad == k):
+                    and getattr(spec, "emit_x3", True) and k >= 32 and kpad == k and (x3_parts() == 3 or sums is not None)):
                 out3 = x3_alloc_for(m, k, dev)  # the consumer is (almost always) the next dense conv: hand it split rows
             if sums is not None:
                 state = BNState(k, dev)
@@ -758,10 +834,13 @@ class _ConvBnAct(torch.autograd.Function):
                     # residual layers cannot re-derive the activation gate from the conv output alone: keep it as one byte
                     # per 4-channel group, which the backward reads instead of the 16 bytes of `out`
                     gates = torch.empty((m, k // 4), dtype=torch.uint8, device=dev)
+                res_keep, res_bound = None, None
+                if out3 is not None and x3_parts() == 2 and res_t is not None:  # the output's bound includes the residual's
+                    res_keep, res_bound = bound_of(residual, res_t, ldr, m, k)
                 check(lib.dass_bn_apply_train(_p(y_raw), k, _p(out), ldo, _p(sums), float(m), _p(bn.weight), _p(bn.bias), _p(rm), _p(rv),
                                               mom, float(bn.eps), _p(state.mean), _p(state.invstd), _p(state.scale), _p(state.shift),
                                               _p(res_t), ldr or 0, _p(nc_scale), m, k, oh * ow, spec.act, _dt(out), _p(out3), _p(gates),
-                                              _stream()), "dass_bn_apply_train")
+                                              gates.numel() if gates is not None else 0, res_bound, _stream()), "dass_bn_apply_train")
                 _running_stats_written(bn, rm, rv)
             else:
                 scale_shift_act(y_raw, k, out, ldo, m, k, scale, shift, residual=res_t, ldr=ldr or 0,
@@ -771,7 +850,7 @@ class _ConvBnAct(torch.autograd.Function):
         if need_grad:
             ctx.spec = spec
             ctx.x3_on = x3_on
-            ctx.x3_dgrad = x3_on or _x3_train_layer(taps, k)  # the input gradient reduces over k x taps
+            ctx.x3_dgrad = (x3_on or _x3_train_layer(taps, k)) and n * h * w >= _X3_MIN_ROWS  # the input gradient reduces over k x taps
             ctx.image_input = image_input
             ctx.dims = (n, h, w, c, oh, ow, k, ldx, ldo, c_in)
             ctx.train_stats = batch_stats
@@ -846,7 +925,8 @@ class _ConvBnAct(torch.autograd.Function):
                 no_out = gate or gates is not None
                 check(lib.dass_bn_bwd_reduce_sums(_p(dout_r), lddo, _p(None if no_out else out), ldo, _p(y_raw), k, _p(mean_v), _p(invstd_v),
                                                   _p(bn_scale if gate else None), _p(bn_shift if gate else None), _p(nc_scale), m, k,
-                                                  oh * ow, spec.act, _p(bsums), _p(gates), _dt(out), _stream()), "dass_bn_bwd_reduce_sums")
+                                                  oh * ow, spec.act, _p(bsums), _p(gates), gates.numel() if gates is not None else 0, _dt(out),
+                                                  _stream()), "dass_bn_bwd_reduce_sums")
                 pg = torch.empty((2, k), dtype=torch.float32, device=dev)
                 dbeta, dgamma = pg[0], pg[1]
             elif need_red:
@@ -876,13 +956,15 @@ class _ConvBnAct(torch.autograd.Function):
             dy3 = None
             if (dt == torch.float32 and not spec.depthwise and not ctx.image_input and k >= 32
                     and ((ctx.x3_dgrad and ctx.needs_input_grad[0] and c > 32)
-                         or (ctx.x3_on and ctx.needs_input_grad[1] and x3_in is not None))):
+                         or (ctx.x3_on and ctx.needs_input_grad[1] and x3_in is not None))
+                    and (x3_parts() == 3 or bsums is not None)):  # two-part rows need max |dz|: the sums path supplies it
                 dy3 = x3_alloc_for(m, k, dev)  # dy also as split rows: operand of the input- and weight-gradient launches
             if bsums is not None:
                 check(lib.dass_bn_bwd_apply_sums(_p(dout_r), lddo, _p(None if (gate or gates is not None) else out), ldo, _p(y_raw), k,
                                                  _p(mean_v), _p(invstd_v), _p(gamma_v.detach()), _p(bsums), _p(dbeta), _p(dgamma),
                                                  _p(bn_scale if gate else None), _p(bn_shift if gate else None), _p(nc_scale), _p(dy), lddy,
-                                                 _p(dres), k, m, k, oh * ow, float(m), spec.act, _p(gates), _dt(out), _p(dy3), _stream()),
+                                                 _p(dres), k, m, k, oh * ow, float(m), spec.act, _p(gates), gates.numel() if gates is not None else 0,
+                                                 _dt(out), _p(dy3), _stream()),
                       "dass_bn_bwd_apply_sums")
             elif gate:
                 check(lib.dass_bn_bwd_apply_gate(_p(dout_r), lddo, _p(y_raw), k, _p(mean_v), _p(invstd_v), _p(gamma_v.detach()), _p(db), _p(dg),
@@ -931,10 +1013,19 @@ class _ConvBnAct(torch.autograd.Function):
                     wstream = ctypes.c_void_p(side.cuda_stream)
                 else:
                     wstream = _stream()
-                dy3_w = dy.__dict__.get("_dass_x3") if x3_in is not None and kk == k and ctx.x3_on else None
-                if dy3_w is not None and dy3_w[0] == (dy.data_ptr(), dy._version, m, k):
+                dy3_w = None
+                if x3_in is not None and kk == k and ctx.x3_on and x3_in.numel() == lib.dass_x3_bytes(n * h * w, c):
+                    dy3_w = attached_x3(dy, m, k)
+                    if dy3_w is None and x3_parts() == 2 and lddy % 4 == 0:  # (no BN pass emitted them: convert once, both gradients use them)
+                        dy3_w = x3_operand(dy, dy, lddy, m, k)
+                if dy3_w is not None and _wg["on"] and side is None and c == c_in:
+                    # a weight gradient has no consumer before the optimizer step: queue it; ALL queued layers are computed by
+                    # one grouped launch per tile class when this backward pass ends (_wgrad_flush), which then sets .grad
+                    _wgrad_enqueue(weight, x3_in, dy3_w, dwk, (n, h, w, c, oh, ow, kk, r, s, spec.stride, spec.pad, spec.dil), k, c_in)
+                    generic_dw = False
+                elif dy3_w is not None:
                     # both operands already exist as split rows (forward producer / BN-backward pass): copy + MFMA only
-                    check(lib.dass_conv2d_wgrad_x3(_p(x3_in), _p(dy3_w[1]), _p(dwk), n, h, w, c, oh, ow, kk, r, s, spec.stride, spec.pad,
+                    check(lib.dass_conv2d_wgrad_x3(_p(x3_in), _p(dy3_w), _p(dwk), n, h, w, c, oh, ow, kk, r, s, spec.stride, spec.pad,
                                                    spec.dil, 0, wstream), "dass_conv2d_wgrad_x3")
                 else:
                     check(lib.dass_conv2d_wgrad_acc(_p(xs), ldx, _p(dy), lddy, _p(dwk), n, h, w, c, oh, ow, kk, r, s,
@@ -943,7 +1034,8 @@ class _ConvBnAct(torch.autograd.Function):
                     _EV_JOIN.record(side)
                     join = _EV_JOIN
             if want_dx:
-                w_t = weight_operand(wsrc, 1, dt) if wsrc is weight else _dgrad_operand_uncached(wsrc, dt)
+                dg_x3 = bool(ctx.x3_dgrad and dt == torch.float32 and c > 32 and kk == k and lddy % 4 == 0)
+                w_t = weight_operand(wsrc, 1, dt, x3=dg_x3) if wsrc is weight else _dgrad_operand_uncached(wsrc, dt, x3=dg_x3)
                 dx = new_act(n, c, h, w, dt, dev)
                 pad_t = spec.dil * (r - 1) - spec.pad
                 # forked input: its other gradient rides in as the epilogue's residual (stride-1 launches)
@@ -955,7 +1047,7 @@ class _ConvBnAct(torch.autograd.Function):
                     else:
                         d_fork = None
                 # dgrad = stride-1 conv over dy with flipped/transposed taps; ustride re-inserts the stride
-                if ctx.x3_dgrad and dt == torch.float32 and c > 32 and kk == k and lddy % 4 == 0:
+                if dg_x3:
                     dy3 = x3_operand(dy, dy, lddy, m, kk)
                     conv_x3_launch(dy3, w_t, dx, c, (n, oh, ow, kk, h, w, c, r, s, 1, pad_t, spec.dil), ustride=spec.stride,
                                    residual=add_t, ldr=add_ld or 0)
@@ -979,6 +1071,61 @@ class _ConvBnAct(torch.autograd.Function):
         if d_fork is not None and ctx.needs_input_grad[0]:  # not folded into the launch above
             dx = d_fork if dx is None else dx + d_fork.to(dx.dtype)
         return dx, dw, dgamma, dbeta, dbias, dres, None, None, None
+
+
+# ---- deferred, grouped weight gradients (csrc/wgrad_x3.hip "GROUPED form").  A conv weight gradient is consumed only by the
+# optimizer step, so the pre-split weight-gradient launches of a backward pass are queued and run as ONE grouped launch per tile
+# class when the pass ends (autograd's final callback): hundreds of output tiles fill the chip without cutting the 8712-pixel
+# reductions into atomically-added pieces, and the fill / drain of ~100 small launches is paid once.  The gradient is then
+# written to `weight.grad` (accumulated if one exists) and the parameter's post-accumulate-grad hooks are fired, exactly what
+# autograd's AccumulateGrad node would have done; the Function itself returns None for the weight.  DASS_WGRAD_DEFER=0 /
+# set_deferred_wgrad(False): per-layer launches inside backward.
+_wg = {"on": os.environ.get("DASS_WGRAD_DEFER", "1") == "1", "queue": [], "armed": False}
+
+
+def set_deferred_wgrad(on):
+    _wg["on"] = bool(on)
+
+
+def deferred_wgrad():
+    return _wg["on"]
+
+
+def _wgrad_enqueue(weight, x3, dy3, dwk, dims, k, c_in):
+    _wg["queue"].append((weight, x3, dy3, dwk, dims, k, c_in))
+    if not _wg["armed"]:
+        _wg["armed"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_wgrad_flush)
+
+
+def _wgrad_flush():
+    """runs once at the end of the backward pass that queued work (on the caller's stream)"""
+    import numpy as np
+
+    q = _wg["queue"]
+    _wg["queue"], _wg["armed"] = [], False
+    if not q:
+        return
+    dev = q[0][3].device
+    items = np.zeros((len(q), 16), dtype=np.int64)
+    for i, (weight, x3, dy3, dwk, dims, k, c_in) in enumerate(q):
+        items[i, :3] = (x3.data_ptr(), dy3.data_ptr(), dwk.data_ptr())
+        items[i, 3:15] = dims
+    nbytes = lib.dass_conv2d_wgrad_x3_group_scratch_bytes(len(q)) + 128
+    scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    check(lib.dass_conv2d_wgrad_x3_group(items.ctypes.data_as(ctypes.c_void_p), len(q), _p(scratch), scratch.numel(), _stream()),
+          "dass_conv2d_wgrad_x3_group")
+    with torch.no_grad():
+        for weight, x3, dy3, dwk, dims, k, c_in in q:
+            dw = dwk[:k, :, :, :c_in].permute(0, 3, 1, 2)
+            if weight.grad is None:
+                weight.grad = dw
+            else:
+                weight.grad.add_(dw)
+            hooks = getattr(weight, "_post_accumulate_grad_hooks", None)
+            if hooks:
+                for hook in list(hooks.values()):
+                    hook(weight)
 
 
 _dw_arena = {"buf": None, "off": 0, "size": 1 << 21, "on": os.environ.get("DASS_DW_ARENA", "1") == "1"}
@@ -1024,11 +1171,11 @@ def _side_stream(dev):
     return st
 
 
-def _dgrad_operand_uncached(wsrc, dtype):
+def _dgrad_operand_uncached(wsrc, dtype, x3=False):
     k, c, r, s = wsrc.shape
     master = _krsc_master(wsrc)
-    if dtype == torch.float32 and _state["f32_mma"] == "bf16x6":
-        return _split6_operand(master, k, r, s, c, c, 1)
+    if _split_fmt(dtype, x3):
+        return _split6_operand(master, k, r, s, c, c, 1, _split_fmt(dtype, x3))
     op = torch.empty((c, r, s, k), dtype=dtype, device=wsrc.device)
     check(lib.dass_weight_transform(_p(master), _p(op), k, r, s, c, c, 1, F32 if dtype == torch.float32 else BF16,
                                     _stream()), "dass_weight_transform")
@@ -1058,7 +1205,15 @@ def conv_bn_act(x, conv, bn=None, act=ACT_NONE, residual=None, nc_scale=None, ex
         spec.in_scale = in_scale.contiguous()
     gamma = bn.weight if bn is not None else None
     beta = bn.bias if bn is not None else None
-    return _ConvBnAct.apply(x, conv.weight, gamma, beta, conv.bias, residual, nc_scale, spec, image_input)
+    res = _ConvBnAct.apply(x, conv.weight, gamma, beta, conv.bias, residual, nc_scale, spec, image_input)
+    if spec.fork:
+        # the alias of x handed back for the identity branch is a new tensor object over the same memory: let it keep the split
+        # rows (and with them the bound of max |x|) the producer attached to x
+        hit = x.__dict__.get("_dass_x3") if hasattr(x, "__dict__") else None
+        alias = res[1]
+        if hit is not None and hit[0][:2] == (x.data_ptr(), x._version) and alias.data_ptr() == x.data_ptr():
+            alias.__dict__["_dass_x3"] = ((alias.data_ptr(), alias._version) + tuple(hit[0][2:]), hit[1])
+    return res
 
 
 # ----------------------------------------------------------------------------- max pool (resnet.py:68)

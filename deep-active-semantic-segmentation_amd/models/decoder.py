@@ -65,8 +65,8 @@ class Decoder(nn.Module):
         hit = self.__dict__.get("_dass_split_w")
         if hit is None or hit[0] != key:
             krsc = wt.detach().float().permute(0, 2, 3, 1)
-            wa = ops.prepare_conv_weight(krsc[..., :256].contiguous())
-            wb = ops.prepare_conv_weight(krsc[..., 256:].contiguous())
+            wa = ops.prepare_conv_weight(krsc[..., :256].contiguous(), x3=ops.x3_pipeline())
+            wb = ops.prepare_conv_weight(krsc[..., 256:].contiguous(), x3=ops.x3_pipeline())
             hit = self.__dict__["_dass_split_w"] = (key, wa, wb)
         return hit[1], hit[2]
 
@@ -94,8 +94,11 @@ class Decoder(nn.Module):
         wa = prep[0]
         t, n, c = masks1.shape
         order, lim = ops.dropout_pack(masks1.reshape(t * n, c))
+        if ops.x3_parts() == 2:  # every operand ends in its own trailer (the weights' scale): one buffer per pass
+            return [(order[i * n:(i + 1) * n], lim[i * n:(i + 1) * n],
+                     ops.w3_pack_per_image(wa, 256 * 9, 256, order[i * n:(i + 1) * n], lim[i * n:(i + 1) * n])) for i in range(t)]
         wan = ops.w3_pack_per_image(wa, 256 * 9, 256, order, lim)
-        per = wan.numel() // t
+        per = (wan.numel() - 16) // t
         return [(order[i * n:(i + 1) * n], lim[i * n:(i + 1) * n], wan[i * per:(i + 1) * per]) for i in range(t)]
 
     def head_mc_pass(self, feats, prep, m1, m2, packed=None):
@@ -116,7 +119,11 @@ class Decoder(nn.Module):
             # of this conv's multiplications are never issued.
             m = n * h * w
             m1 = m1.contiguous()
-            h1_3 = ops.x3_alloc(m, 256, feats.device)
+            # three-part format: the first conv hands its result to the second as x3 rows from its epilogue; two-part format:
+            # it writes f32 rows and the rows are converted by dass_split3_rows (the per-tensor scale needs max |h1| first)
+            fused3 = ops.x3_parts() == 3
+            h1_3 = ops.x3_alloc(m, 256, feats.device) if fused3 else None
+            h1 = None if fused3 else ops.new_act(n, 256, h, w, torch.float32, feats.device)
             if ops.mc_sparse():
                 if packed is not None:
                     order, lim, wan = packed
@@ -124,15 +131,17 @@ class Decoder(nn.Module):
                     order, lim = ops.dropout_pack(m1)
                     wan = ops.w3_pack_per_image(wa, 256 * 9, 256, order, lim)
                 xa3 = ops.split3_rows_packed(xa, lda, m, 256, m1, order, lim, h * w)
-                ops.conv_x3_per_image_launch(xa3, wan, lim, None, 0, dims, y3=h1_3, scale=st.scale, shift=st.shift, residual=yb,
+                ops.conv_x3_per_image_launch(xa3, wan, lim, h1, 256, dims, y3=h1_3, scale=st.scale, shift=st.shift, residual=yb,
                                              ldr=256, act=ops.ACT_RELU)
             else:
                 xa3 = ops.split3_rows(xa, lda, m, 256, nc_scale=m1, rows_per_image=h * w)
-                ops.conv_x3_launch(xa3, wa, None, 0, dims, y3=h1_3, scale=st.scale, shift=st.shift, residual=yb, ldr=256,
+                ops.conv_x3_launch(xa3, wa, h1, 256, dims, y3=h1_3, scale=st.scale, shift=st.shift, residual=yb, ldr=256,
                                    act=ops.ACT_RELU)
+            if not fused3:
+                h1_3 = ops.split3_rows(h1, 256, m, 256)
             st2 = ops.bn_eval_state(lc[4], 256, feats.device)
             h2 = ops.new_act(n, 256, h, w, torch.float32, feats.device)
-            ops.conv_x3_launch(h1_3, ops.weight_operand(lc[3].weight, 0, torch.float32, cpad=256), h2, 256, dims,
+            ops.conv_x3_launch(h1_3, ops.weight_operand(lc[3].weight, 0, torch.float32, cpad=256, x3=True), h2, 256, dims,
                                scale=st2.scale, shift=st2.shift, act=ops.ACT_RELU)
             return ops.conv_bn_act(h2, lc[7], in_scale=m2)
         h1 = ops.new_act(n, 256, h, w, torch.float32, feats.device)

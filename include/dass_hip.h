@@ -40,6 +40,8 @@ extern "C" {
 #define DASS_BF16 1
 #define DASS_F32X3 2 /* conv2d_igemm / conv2d_igemm_stats / conv2d_wgrad only */
 #define DASS_F32X6 3 /* same entry points: three-way bf16 split, six products -- f32-exact products */
+#define DASS_F16X3 4 /* weight-operand format of the pre-split kernels in their two-part mode (dass_set_x3_parts(2)):
+                        w * s as two f16 parts, s = a per-tensor power of two; three products per pair.  See "x3 rows". */
 
 #define DASS_ACT_NONE 0
 #define DASS_ACT_RELU 1
@@ -109,10 +111,14 @@ int dass_conv2d_rowtap_wgrad(const void *x, const void *dy, int64_t lddy, float 
 int dass_weight_transform(const float *src, void *dst, int K, int R, int S, int Csrc, int Cdst,
                           int mode, int dtype, void *stream);
 int64_t dass_weight_split_bytes(int rows, int R, int S, int red);
+/* bytes of the pre-split operand of `dtype`: DASS_F32X6 (= dass_weight_split_bytes) or DASS_F16X3 (128 B per slab + trailer) */
+int64_t dass_weight_operand_bytes(int rows, int R, int S, int red, int dtype);
 /* the DASS_F32X6 transform of n weights in one launch (after an optimizer step every conv weight is stale at once):
  * desc = n x 8 int64 on the device {src ptr, dst ptr, K, R, S, Csrc, Cdst, mode}, start[w] = sum over earlier weights of
  * their tiles ceil(rows/32)*R*S*ceil(red/32) (32 operand rows x one 32-wide slab), total = the sum over all n. */
 int dass_weight_split_batch(const void *desc, const int64_t *start, int n, int64_t total, void *stream);
+/* the same table, DASS_F16X3 operands: zero the trailers, max |w| per tensor (the scale), split -- three launches */
+int dass_weight_split_batch_f16(const void *desc, const int64_t *start, int n, int64_t total, void *stream);
 
 /* depthwise 3x3 (MobileNetV2 InvertedResidual, mobilenet.py:49,59): w[c][3][3] f32 */
 int dass_dwconv3x3_fwd(const void *x, int64_t ldx, const float *w, void *y, int64_t ldy,
@@ -172,6 +178,13 @@ int dass_bn_rows_bwd(const float *g, const float *x, const float *mean, const fl
  *                                                  byte [m][k/4] = channel k+e passes gradient); the backward pair then
  *                                                  reads that byte instead of the 16 bytes of `out` (layers with a
  *                                                  residual cannot re-derive the gate from the conv output alone).
+ *   gates_bytes                                    size of that buffer: all three entry points return DASS_ERR_ARG when it is
+ *                                                  smaller than M * K / 4 (a short buffer would be written / read out of
+ *                                                  bounds by every row: the GPU memory fault of round 2).
+ *   sums                                           backward: [2][K] f64 followed by K floats (zeroed like the rest) in which
+ *                                                  dass_bn_bwd_reduce_sums keeps every channel's max |dz| (atomic max).
+ *   residual_bound (dass_bn_apply_train, nullable) device float >= max |residual|; required when out3 is written in the
+ *                                                  two-part x3 format (dass_set_x3_parts(2)) and a residual is added.
  * Arithmetic is that of the partial-row entry points (f32 inside a tile / slab, f64 across); only the order of the f64
  * additions is unspecified.  K <= 2048 for dass_bn_apply_train (DASS_ERR_UNSUPPORTED beyond). */
 int dass_conv2d_igemm_sums(const void *x, int64_t ldx, const void *w, void *y, int64_t ldy, int N, int H, int W, int C,
@@ -185,17 +198,17 @@ int dass_bn_apply_train(const void *x, int64_t ldx, void *out, int64_t ldo, cons
                         const float *gamma, const float *beta, float *running_mean, float *running_var, float momentum,
                         float eps, float *mean, float *invstd, float *scale, float *shift, const void *residual,
                         int64_t ldr, const float *nc_scale, int64_t M, int K, int64_t rows_per_image, int act, int dtype,
-                        void *out3, void *gates, void *stream);
+                        void *out3, void *gates, int64_t gates_bytes, const float *residual_bound, void *stream);
 int dass_bn_bwd_reduce_sums(const void *dout, int64_t lddo, const void *out, int64_t ldo, const void *x, int64_t ldx,
                             const float *mean, const float *invstd, const float *gate_scale, const float *gate_shift,
                             const float *nc_scale, int64_t M, int K, int64_t rows_per_image, int act, double *sums,
-                            const void *gates, int dtype, void *stream);
+                            const void *gates, int64_t gates_bytes, int dtype, void *stream);
 int dass_bn_bwd_apply_sums(const void *dout, int64_t lddo, const void *out, int64_t ldo, const void *x, int64_t ldx,
                            const float *mean, const float *invstd, const float *gamma, const double *sums,
                            float *dbeta_out, float *dgamma_out, const float *gate_scale, const float *gate_shift,
                            const float *nc_scale, void *dx, int64_t lddx, void *dres, int64_t lddr, int64_t M, int K,
-                           int64_t rows_per_image, double count, int act, const void *gates, int dtype, void *dx3,
-                           void *stream);
+                           int64_t rows_per_image, double count, int act, const void *gates, int64_t gates_bytes, int dtype,
+                           void *dx3, void *stream);
 /* eval-mode BN folded to scale/shift from running stats */
 int dass_bn_eval_scale_shift(const float *gamma, const float *beta, const float *running_mean,
                              const float *running_var, float eps, int K,
@@ -357,6 +370,25 @@ int dass_sgd_step_multi(void *const *p, const void *const *g, void *const *buf, 
  * dass_x3_bytes: allocation size.  dass_split3_rows: f32 rows -> x3 rows; nc_scale (nullable) multiplies row m by
  * nc_scale[m / rows_per_image][c] first (Dropout2d mask of the producer, aspp.py:89 / decoder.py:35). */
 int64_t dass_x3_bytes(int64_t rows, int C);
+/* Operand format of the pre-split kernels and of every x3 buffer written from now on (process-wide, like
+ * dass_set_deterministic): 3 (default) = three bf16 parts, six products per pair ("bf16x6"); 2 = "f16x3": x * s as TWO f16
+ * parts (11 + 1 + 11 significant bits; s = a power of two per tensor with bound * s in [2^14, 2^15), bound >= max |x|), three
+ * products per pair on the f16 MFMA pipe, the accumulator multiplied by 1 / (s_a s_b) -- half the matrix work for the same
+ * f32-level product accuracy (2^-22 per product; measured against f64 in tests/test_f16x3_gpu.py).  Every x3 / weight operand
+ * then ends in a 16-B trailer {float inv_scale, float bound, 0, 0} behind its zero row.  Where the bound comes from:
+ *   dass_split3_rows / _packed     max |x| by dass_absmax_rows (one more read of the tensor),
+ *   dass_bn_apply_train (out3)     batch statistics: |gamma xhat + beta| <= max|gamma| sqrt(M - 1) + max|beta| (+ residual_bound),
+ *   dass_bn_bwd_apply_sums (dx3)   max over channels of |gamma invstd| (max|dz| + |mean dz| + sqrt(M - 1) |mean(dz xhat)|),
+ *   weights                        max |w| (dass_weight_split_batch_f16).
+ * Not available in the two-part format (DASS_ERR_UNSUPPORTED): y3 of dass_conv2d_x3*, out3 of dass_scale_shift_act, dx3 of
+ * dass_bn_bwd_apply / _gate -- their consumers convert with dass_split3_rows instead. */
+int dass_set_x3_parts(int parts);
+int dass_get_x3_parts(void);
+/* bound[0] = max over rows of |x[m][c] * nc_scale[m / rows_per_image][c]| (nc_scale nullable), as an atomic max: zero it first */
+int dass_absmax_rows(const float *x, int64_t ld, int64_t M, int C, const float *nc_scale, int64_t rows_per_image, float *bound,
+                     void *stream);
+/* bytes of dass_w3_pack_per_image's output: N copies of the [rows][ceil(C/32)] operand + the trailer */
+int64_t dass_w3_pack_bytes(int64_t rows, int C, int N);
 /* tuning / test knob: tile + 10 * mode + 100 * shape (shape 0 = default MFMA shape = 16x16x32, 1 = 32x32x16, 2 = 16x16x32; DASS_X3_MFMA=32 makes 32x32x16 the default).  tile 0 = the dispatcher's choice, 1..7 = force one tile variant of
  * dass_conv2d_x3 (csrc/conv_x3.hip); mode 0 = auto, 1 = one output tile per workgroup, 2 = stream-K (whole rounds of
  * tiles one per workgroup + the remainder as equal slab ranges), 3 = stream-K slab ranges over all tiles */
@@ -408,6 +440,14 @@ int dass_get_deterministic(void);
  * row; csrc/wgrad_x3.hip).  zero_first = 1 clears dw, 0 accumulates (pixel splits add with f32 atomics either way). */
 int dass_conv2d_wgrad_x3(const void *x3, const void *dy3, float *dw, int N, int H, int W, int C, int OH, int OW, int K,
                          int R, int S, int stride, int pad, int dil, int zero_first, void *stream);
+/* The weight gradients of MANY conv layers in one launch per tile class (csrc/wgrad_x3.hip "GROUPED form"): items = n x 16 int64
+ * on the HOST {x3, dy3, dw, N, H, W, C, OH, OW, K, R, S, stride, pad, dil, 0}, arguments as dass_conv2d_wgrad_x3; every dw must
+ * be zeroed by the caller (tiles are added).  Replaces the per-layer launches of a backward pass whose weight gradients have no
+ * consumer before the optimizer step: with hundreds of output tiles in one grid no pixel reduction has to be cut into
+ * atomically-added pieces just to fill the chip, and the fill / drain of ~100 launches is paid once.  scratch: device buffer of
+ * dass_conv2d_wgrad_x3_group_scratch_bytes(n) bytes that receives the problem table (asynchronous copy on `stream`). */
+int dass_conv2d_wgrad_x3_group(const int64_t *items, int n, void *scratch, int64_t scratch_bytes, void *stream);
+int64_t dass_conv2d_wgrad_x3_group_scratch_bytes(int n);
 /* ---------------------------------------------------------------- pool reader
  * dataloaders/dataset/paths_dataset.py:27-52: a record is uint8 [H][W][4] (RGB + label).  dass_resample_bilinear_u8 =
  * scipy.misc.imresize(image, (OH, OW)) of custom_transforms.py:153,228,291 = PIL's two-pass bilinear resampler, bit for bit:

@@ -252,7 +252,7 @@ def test_config_b_r101_769_forward_and_mc_dropout():
     x, lab = O.synthetic_batch(n, hw, hw, 19, first_index=30)
     xd = x.cuda()
     outs = {}
-    keep = ops._state["x3"]
+    keep = ops.x3_mode()
     try:
         for mode in ("infer", "off"):
             ops.set_x3_pipeline(mode)

@@ -30,10 +30,10 @@ def _setup():
 def _restore():
     from dass_hip import ops
 
-    mode, x3 = ops.f32_mma(), ops._state["x3"]
+    mode, x3, x3f = ops.f32_mma(), ops._state["x3"], ops._state["x3_f16"]
     yield
     ops.set_f32_mma(mode)
-    ops.set_x3_pipeline(x3)
+    ops._state["x3"], ops._state["x3_f16"] = x3, x3f
 
 
 class _GateReplay(object):
@@ -88,7 +88,7 @@ class _GateReplay(object):
 
 
 @pytest.mark.parametrize("train_bn", [False, True])
-@pytest.mark.parametrize("engine", ["bf16x6", "f32", "bf16x6+x3"])
+@pytest.mark.parametrize("engine", ["bf16x6", "f32", "bf16x6+x3", "f16x3+x3"])
 def test_resnet_gradients_with_oracle_gates_injected(engine, train_bn):
     ops, O, S = _setup()
     from models.deeplab import DeepLab
@@ -157,7 +157,7 @@ def test_resnet_gradients_with_oracle_gates_injected(engine, train_bn):
         assert max(down) <= 3e-4, max(down)
 
 
-@pytest.mark.parametrize("engine", ["bf16x6", "f32"])
+@pytest.mark.parametrize("engine", ["bf16x6", "f32", "f16x3"])
 def test_resnet50_train_mode_bn_step_vs_f64_oracle(engine):
     """one training step of ResNet-50 DeepLab at 65^2 with batch statistics, TRUE ReLU on both sides: loss, every gradient
     and the running statistics against the f64 oracle; the gradient bound is a multiple of what stock f32 PyTorch itself

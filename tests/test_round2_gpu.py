@@ -200,7 +200,9 @@ def test_x3_engine_in_training_matches_classic_engine():
     pm.train()
     pm.freeze_bn()  # running statistics: no batch-statistics amplification in the comparison
     res = {}
-    keep = ops._state["x3"]
+    engine = ops.f32_mma()
+    ops.set_f32_mma("bf16x6")  # (a property of the six-product kernels: the two engines multiply the same parts in the same order)
+    keep = ops.x3_mode()
     try:
         for mode in ("off", "all", "select"):
             ops.set_x3_pipeline(mode)
@@ -210,6 +212,7 @@ def test_x3_engine_in_training_matches_classic_engine():
             res[mode] = (loss.item(), {k: p.grad.detach().double().cpu() for k, p in pm.named_parameters()})
     finally:
         ops.set_x3_pipeline(keep)
+        ops.set_f32_mma(engine)
     for mode in ("all", "select"):
         assert abs(res["off"][0] - res[mode][0]) <= 1e-6 * abs(res["off"][0])
         worst = max(((res[mode][1][k] - g).norm().item() / max(g.norm().item(), 1e-12), k) for k, g in res["off"][1].items())

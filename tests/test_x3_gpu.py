@@ -54,7 +54,7 @@ def _x3_of(ops, t_nchw):
 def _decode_x3(buf, rows, c):
     """x3 bytes -> f32 [rows, c] (x0 + x1 + x2), and the raw zero row"""
     cc = (c + 31) // 32
-    v = buf.view(torch.bfloat16).view(rows + 1, cc, 3, 32).float()
+    v = buf[:-16].view(torch.bfloat16).view(rows + 1, cc, 3, 32).float()   # (the last 16 B are the operand's trailer)
     full = (v[:, :, 0] + v[:, :, 1]) + v[:, :, 2]
     return full[:rows].reshape(rows, cc * 32)[:, :c], v[rows]
 
@@ -75,7 +75,7 @@ def test_split3_rows_is_exact():
     assert torch.equal(back.cpu(), x), (back.cpu() - x).abs().max()     # three bf16 parts carry all 24 significand bits
     assert float(zero.abs().max()) == 0.0
     cc = 3
-    v = buf.view(torch.bfloat16).view(38, cc, 3, 32)
+    v = buf[:-16].view(torch.bfloat16).view(38, cc, 3, 32)
     assert float(v[:37, 2, :, 8:].float().abs().max()) == 0.0           # channels 72..95 of the last slab are zero
     mask = (torch.rand(1, 72, generator=g) > 0.5).float() * 2.0
     buf2 = ops.split3_rows(xr, 72, 37, 72, nc_scale=mask.cuda(), rows_per_image=37)

@@ -11,7 +11,7 @@ import torch  # noqa: E402
 from dass_hip import ops  # noqa: E402
 from dass_hip._lib import check, lib  # noqa: E402
 
-PEAK = {"f32": 157.3, "bf16x6": 2500.0 / 6, "bf16x3": 2500.0 / 3}[ops.f32_mma()]  # engine from DASS_F32_MMA
+PEAK = {"f32": 157.3, "bf16x6": 2500.0 / 6, "bf16x3": 2500.0 / 3, "f16x3": 2500.0 / 3}[ops.f32_mma()]  # engine from DASS_F32_MMA
 
 
 def r101_shapes(batch=8, size=513):

@@ -16,7 +16,7 @@ from conv_sweep import r101_shapes, timeit  # noqa: E402
 
 def main():
     tiles = [int(a) for a in sys.argv[1:]] or [0, 11, 12, 14, 21, 22, 23, 24]
-    ops.set_f32_mma("bf16x6")
+    ops.set_f32_mma(os.environ.get("DASS_F32_MMA", "bf16x6"))   # (f16x3: the same kernels in their two-part mode)
     dev = "cuda"
     tot_old, tot_new, tot_best, tot_flop, tot_split = 0.0, {t: 0.0 for t in tiles}, 0.0, 0.0, 0.0
     print("%-14s %3s %7s %5s %5s | %8s | %s | %7s" % ("shape", "cnt", "M", "C", "K", "old us", " ".join("t%-2d us " % t for t in tiles), "split us"))
@@ -28,9 +28,10 @@ def main():
         wt = torch.randn((k, ks, ks, c), device=dev) * 0.05
         y = torch.empty((n, oh, ow, k), device=dev)
         dims = (n, h, w, c, oh, ow, k, ks, ks, st, pad, dil)
-        w3 = ops.prepare_conv_weight(wt)
+        w3 = ops.prepare_conv_weight(wt, x3=True)
+        w6 = ops.prepare_conv_weight(wt)
         x3 = ops.split3_rows(x, c, n * h * w, c)
-        t_old = timeit(lambda: ops.conv_launch(x, c, w3, y, k, dims)) * 1e3
+        t_old = timeit(lambda: ops.conv_launch(x, c, w6, y, k, dims)) * 1e3
         t_split = timeit(lambda: ops.split3_rows(x, c, n * h * w, c)) * 1e3
         res = {}
         for t in tiles:
