@@ -19,7 +19,7 @@ from ._lib import check, lib
 F32, BF16, F32X3, F32X6, F16X3 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 
-_state = {"dtype": torch.float32, "f32_mma": os.environ.get("DASS_F32_MMA", "bf16x6"),
+_state = {"dtype": torch.float32, "f32_mma": os.environ.get("DASS_F32_MMA", "f16x3"),
           "x3": os.environ.get("DASS_X3", "select"), "mc_sparse": os.environ.get("DASS_MC_SPARSE", "1") != "0"}
 assert _state["x3"] in ("off", "infer", "select", "all"), "DASS_X3 must be off, infer, select or all"
 assert _state["f32_mma"] in ("f32", "bf16x3", "bf16x6", "f16x3"), "DASS_F32_MMA must be f32, bf16x3, bf16x6 or f16x3"
@@ -39,13 +39,13 @@ def compute_dtype():
 
 def set_f32_mma(mode):
     """how the dense convs multiply f32 tensors (tensors, BN, loss and every other kernel stay f32 in all three):
-      "bf16x6" (default) each operand is split exactly into three bf16 parts (x = x0+x1+x2 to 2^-26) and the six
+      "bf16x6" each operand is split exactly into three bf16 parts (x = x0+x1+x2 to 2^-26) and the six
                products of order <= 2^-18 are accumulated in f32 on v_mfma_f32_32x32x16_bf16 (DASS_F32X6): the f32
                product to below f32 rounding at 3/8 of the matrix-pipe time -- same parity bars as "f32";
       "f32"    v_mfma_f32_32x32x2_f32, the plain f32 fma chain;
       "bf16x3" two parts, three products (DASS_F32X3): 17-bit products (~4.5e-6 per conv), 3/16 of the pipe time;
                does NOT meet the 1e-3 logit bar on MobileNet -- a fast training mode, not a parity mode;
-      "f16x3"  the pre-split kernels in their two-part mode (dass_set_x3_parts(2)): every operand tensor is scaled by a power of
+      "f16x3"  (default) the pre-split kernels in their two-part mode (dass_set_x3_parts(2)): every operand tensor is scaled by a power of
                two (from a guaranteed bound of its max |x|) and split into TWO f16 parts -- 23 significant bits -- and three
                products per pair run on the f16 MFMA pipe: the f32 product to 2^-22, half the matrix work of "bf16x6"; same
                parity bars (include/dass_hip.h "dass_set_x3_parts").  Layers the pre-split kernels do not take (<= 32 output

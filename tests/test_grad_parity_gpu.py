@@ -36,55 +36,7 @@ def _restore():
     ops._state["x3"], ops._state["x3_f16"] = x3, x3f
 
 
-class _GateReplay(object):
-    """records (out > 0) of every ReLU site of the HIP forward; replays them, matched by shape in call order, in place of
-    torch.nn.functional.relu during the oracle's forward"""
-
-    def __init__(self, ops):
-        self.ops, self.gates, self.used = ops, [], []
-        self._orig_cba, self._orig_relu = ops.conv_bn_act, torch.nn.functional.relu
-
-    def record(self):
-        ops, rec = self.ops, self
-
-        def wrapped(x, conv, bn=None, act=ops.ACT_NONE, **kw):
-            out = rec._orig_cba(x, conv, bn, act, **kw)
-            if act == ops.ACT_RELU:
-                first = out[0] if isinstance(out, tuple) else out  # fork=True: (out, the input again)
-                rec.gates.append((first.detach() > 0).cpu())
-            return out
-
-        ops.conv_bn_act = wrapped
-
-    def stop_recording(self):
-        self.ops.conv_bn_act = self._orig_cba
-        self.used = [False] * len(self.gates)
-
-    def replay(self):
-        rec = self
-
-        class Gate(torch.autograd.Function):
-            @staticmethod
-            def forward(ctx, x, gate):
-                ctx.save_for_backward(gate)
-                return x * gate
-
-            @staticmethod
-            def backward(ctx, g):
-                return g * ctx.saved_tensors[0], None
-
-        def relu(x, inplace=False):
-            for i, gt in enumerate(rec.gates):
-                if not rec.used[i] and tuple(gt.shape) == tuple(x.shape):
-                    rec.used[i] = True
-                    return Gate.apply(x, gt.to(x.dtype))
-            raise AssertionError("no recorded gate of shape %s left" % (tuple(x.shape),))
-
-        torch.nn.functional.relu = relu
-
-    def restore(self):
-        torch.nn.functional.relu = self._orig_relu
-        self.ops.conv_bn_act = self._orig_cba
+from gate_replay import GateReplay as _GateReplay  # noqa: E402
 
 
 @pytest.mark.parametrize("train_bn", [False, True])

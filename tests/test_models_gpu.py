@@ -46,12 +46,12 @@ def _restore_mma_mode():
     ops.set_f32_mma(mode)
 
 
-@pytest.mark.parametrize("engine", ["bf16x6", "f32"])
+@pytest.mark.parametrize("engine", ["f16x3", "bf16x6", "f32"])
 @pytest.mark.parametrize("tag,backbone", [("mobilenet", "mobilenet"), ("resnet50", "resnet"), ("resnet101", "resnet101"),
                                           ("mobilenet_voc", "mobilenet")])
 def test_e2e_logits_vs_reference_golden(tag, backbone, engine):
-    """both parity-grade conv engines (exact three-way bf16 split on the bf16 MFMA pipe; plain f32 MFMA) against the
-    reference's own logits"""
+    """the three parity-grade conv engines (two scaled f16 parts / three products -- the default; exact three-way bf16 split / six
+    products; plain f32 MFMA) against the reference's own logits"""
     ops, O, S = _setup()
     ops.set_f32_mma(engine)
     g = np.load(os.path.join(GOLD, "e2e_%s.npz" % tag))
@@ -78,7 +78,7 @@ def test_e2e_logits_vs_reference_golden(tag, backbone, engine):
     assert (pooled - torch.from_numpy(g["feat_pooled"])).abs().max().item() <= 1e-3
 
 
-@pytest.mark.parametrize("engine", ["bf16x6", "f32"])
+@pytest.mark.parametrize("engine", ["f16x3", "bf16x6", "f32"])
 def test_mc_dropout_votes_and_entropy_vs_reference_golden(engine):
     ops, O, S = _setup()
     ops.set_f32_mma(engine)
@@ -511,14 +511,27 @@ def test_output_stride_8_vs_oracle(backbone):
         if isinstance(m, torch.nn.BatchNorm2d):
             m.eval()
     m1, m2 = O.dropout_masks(n, 1, seed=34)
-    S.ce_loss(o64(x.double(), (m1[0].double(), m2[0].double())), lab).backward()
     crit = SegmentationLosses(cuda=True).build_loss("ce")
-    crit(pm(x.cuda(), dropout_masks=(m1[0].cuda(), m2[0].cuda())), lab.cuda()).backward()
+    # the HIP forward's own activation gates are replayed inside the f64 oracle (tests/gate_replay.py): both sides then
+    # differentiate the same piecewise-linear function and EVERY parameter can be held to the rounding level -- with true
+    # ReLUs one pre-activation within rounding of 0 moves all the layers upstream of it by ~1e-3, in any f32 arithmetic
+    from gate_replay import GateReplay
+
+    rec = GateReplay(ops)
+    try:
+        rec.record()
+        crit(pm(x.cuda(), dropout_masks=(m1[0].cuda(), m2[0].cuda())), lab.cuda()).backward()
+        rec.stop_recording()
+        rec.replay()
+        S.ce_loss(o64(x.double(), (m1[0].double(), m2[0].double())), lab).backward()
+    finally:
+        rec.restore()
+    assert all(rec.used) and len(rec.gates) >= 40
     g64 = {k: p.grad for k, p in o64.named_parameters()}
     floor = 1e-3 * float(np.median([v.norm().item() for v in g64.values()]))
     rels = sorted((((p.grad.double().cpu() - g64[k]).norm().item() / max(g64[k].norm().item(), floor), k)
                    for k, p in pm.named_parameters()), reverse=True)
     med = float(np.median([r for r, _ in rels]))
-    print("os8 %s grads vs f64 oracle: worst %.2e (%s) median %.2e" % (backbone, rels[0][0], rels[0][1], med))
-    # typical parameter at the f32 rounding level; the worst one bounded at the gate-flip scale (see the os16 test above)
-    assert med <= (1e-4 if backbone == "resnet" else 1e-3) and rels[0][0] <= 5e-2, rels[:3]
+    print("os8 %s grads vs f64 oracle (gates injected): worst %.2e (%s) median %.2e over %d parameters, %d gate sites"
+          % (backbone, rels[0][0], rels[0][1], med, len(rels), len(rec.gates)))
+    assert rels[0][0] <= (5e-5 if backbone == "resnet" else 3e-4) and med <= (1e-5 if backbone == "resnet" else 5e-5), rels[:3]

@@ -28,7 +28,7 @@ def _restore_modes():
     ops.set_compute_dtype(dt)
 
 
-@pytest.mark.parametrize("engine", ["bf16x6", "f32", "bf16"])
+@pytest.mark.parametrize("engine", ["f16x3", "bf16x6", "f32", "bf16"])
 def test_hip_sgd_refreshes_weight_operands(engine):
     """dass_hip.optim.SGD writes parameters through raw pointers; the split / transposed / bf16 weight operands and the
     eval-BN vectors are cached on (data_ptr, _version).  Three train steps + an eval forward with the HIP optimizer
