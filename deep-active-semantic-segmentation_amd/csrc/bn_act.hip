@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
         const int k = kq << 2;
         f32x4 g = ld4<T>(dout + m * lddo + k);
         f32x4 xin = {0.f, 0.f, 0.f, 0.f};
-        if ((!out && !gates) || (dx && train)) xin = ld4<T>(x + m * ldx + k);
+        if ((!out && !gates) || ((dx || dx3) && train)) xin = ld4<T>(x + m * ldx + k);
         if (gates) {
             const unsigned gb = gates[m * (K >> 2) + kq];
 #pragma unroll
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
         for (int e = 0; e < 4; ++e) g[e] *= act_grad_from_out(o[e], act);
         }
         if (dres) st4<T>(dres + m * lddr + k, g);
-        if (dx) {
+        if (dx || dx3) {  // (dx == NULL: only the split rows are consumed -- pre-split input- and weight-gradient launches)
             const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + k);
             f32x4 ga = {1.f, 1.f, 1.f, 1.f};
             if (gamma) ga = *reinterpret_cast<const f32x4 *>(gamma + k);
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
                 r = g - (db + xh * dg) * inv_count;
             }
             const f32x4 dxv = r * (ga * is);
-            st4<T>(dx + m * lddx + k, dxv);
+            if (dx) st4<T>(dx + m * lddx + k, dxv);
             if (dx3) x3_store4r(dx3, m, cc3, k, dxv, parts, x3s);  // operand of the producing conv's input- and weight-gradient launches
         }
     }
@@ -758,7 +758,7 @@ extern "C" int dass_bn_bwd_apply_sums(const void *dout, int64_t lddo, const void
                                       float *dgamma_out, const float *gate_scale, const float *gate_shift, const float *nc_scale,
                                       void *dx, int64_t lddx, void *dres, int64_t lddr, int64_t M, int K, int64_t rows_per_image,
                                       double count, int act, const void *gates, int64_t gates_bytes, int dtype, void *dx3, void *stream) {
-    if (!dout || !x || !dx || !mean || !invstd || !sums || count <= 0 || M <= 0 || !ok4(K, lddo, out ? ldo : 4, ldx, lddx) ||
+    if (!dout || !x || (!dx && !dx3) || !mean || !invstd || !sums || count <= 0 || M <= 0 || !ok4(K, lddo, out ? ldo : 4, ldx, dx ? lddx : 4) ||
         rows_per_image <= 0)
         return DASS_ERR_ARG;
     if (!out && !gates && (!gate_scale || !gate_shift || dtype != DASS_F32)) return DASS_ERR_ARG;

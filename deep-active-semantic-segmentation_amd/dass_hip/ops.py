@@ -135,6 +135,7 @@ def _x3_train_layer(taps, red_channels):
 
 _SELECT = (int(os.environ.get("DASS_X3_SELECT_TAPS", "9")), int(os.environ.get("DASS_X3_SELECT_C", "256")))  # measured optimum
 _X3_MIN_ROWS = 256  # output rows below which a conv stays on the classic kernel
+_SKIP_DY32 = os.environ.get("DASS_SKIP_DY32", "1") == "1"  # BN backward writes only the split rows of dy when nothing reads its f32 form
 
 
 def _cdt(t):
@@ -960,9 +961,18 @@ class _ConvBnAct(torch.autograd.Function):
                     and (x3_parts() == 3 or bsums is not None)):  # two-part rows need max |dz|: the sums path supplies it
                 dy3 = x3_alloc_for(m, k, dev)  # dy also as split rows: operand of the input- and weight-gradient launches
             if bsums is not None:
+                if dy3 is not None and not spec.depthwise and not getattr(spec, "rowtap", False):
+                    # the f32 form of dy is dead weight when both gradient launches read the split rows: write dy3 only
+                    dg3 = bool(ctx.x3_dgrad and c > 32 and ctx.needs_input_grad[0] and not ctx.image_input)
+                    wg3 = bool(ctx.x3_on and x3_in is not None and x3_in.numel() == lib.dass_x3_bytes(n * h * w, c))
+                    need32 = ((ctx.needs_input_grad[0] and not ctx.image_input and not dg3)
+                              or (ctx.needs_input_grad[1] and not wg3))
+                    if not need32 and _SKIP_DY32:
+                        dy = torch.empty((0,), dtype=dt, device=dev)
                 check(lib.dass_bn_bwd_apply_sums(_p(dout_r), lddo, _p(None if (gate or gates is not None) else out), ldo, _p(y_raw), k,
                                                  _p(mean_v), _p(invstd_v), _p(gamma_v.detach()), _p(bsums), _p(dbeta), _p(dgamma),
-                                                 _p(bn_scale if gate else None), _p(bn_shift if gate else None), _p(nc_scale), _p(dy), lddy,
+                                                 _p(bn_scale if gate else None), _p(bn_shift if gate else None), _p(nc_scale),
+                                                 _p(dy) if dy.numel() else None, lddy,
                                                  _p(dres), k, m, k, oh * ow, float(m), spec.act, _p(gates), gates.numel() if gates is not None else 0,
                                                  _dt(out), _p(dy3), _stream()),
                       "dass_bn_bwd_apply_sums")
