@@ -212,7 +212,7 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
     torch.manual_seed(1234)  # identical random-init weights on every rank
     model = DeepLab(backbone=args.backbone, output_stride=16, num_classes=args.classes, sync_bn=False,
                     freeze_bn=False, pretrained=False).to(dev)
-    criterion = SegmentationLosses(cuda=True).build_loss("ce")
+    criterion = SegmentationLosses(cuda=True, global_batch=True).build_loss("ce")  # DataParallel loss semantics under N > 1
     lr = 0.01
     from dass_hip.optim import SGD  # torch.optim.SGD surface and state, update arithmetic in dass_sgd_step_multi
 

@@ -97,7 +97,7 @@ class ActiveSelectionMaxSubset(ActiveSelectionBase):
             per_image = nr * nc
             if h == w:  # square cells: the pooled-feature kernel with kernel = stride = cell (channel-major rows)
                 pooled = ops.avgpool_features(feats, h, h).view(b, c, nr, nc)  # (hh - h) // h + 1 == floor(hh / h) cells
-                rows_out.append(pooled.permute(0, 2, 3, 1).reshape(b * nr * nc, c))
+                rows_out.append(pooled.permute(0, 2, 3, 1).reshape(b * nr * nc, c).float())
             else:
                 cells = [ops.global_avgpool(feats[:, :, r * h:r * h + h, q * w:q * w + w].contiguous(memory_format=torch.channels_last)).reshape(b, 1, c)
                          for r in range(nr) for q in range(nc)]
@@ -105,8 +105,15 @@ class ActiveSelectionMaxSubset(ActiveSelectionBase):
         local = torch.cat(rows_out) if rows_out else torch.zeros((0, 304), dtype=torch.float32, device=dev)
         if not self.shard:
             return local
-        from active_selection.base import all_gather_rows
+        from active_selection.base import _dist, all_gather_rows
 
+        dist = _dist()
+        if dist is not None and dist.get_world_size() > 1:
+            # a rank whose shard is empty (fewer images than ranks) never saw a feature map: the cells-per-image count is agreed
+            # on by all ranks before the gather, or its padded buffer would have another shape than its peers'
+            t = torch.tensor([per_image], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            per_image = int(t.item())
         full = all_gather_rows(local.view(-1, per_image, local.shape[1]), len(images))  # image-granular shards
         return full.reshape(-1, local.shape[1])
 

@@ -488,9 +488,20 @@ def bn_eval_state(bn, k, device):
     return st
 
 
+def written_in_place(t):
+    """`t` was (or is about to be) rewritten through its raw pointer: bump its version counter -- every cache keyed on
+    (data_ptr, _version) then misses -- and drop the split rows a producer attached to it"""
+    if hasattr(t, "__dict__"):
+        t.__dict__.pop("_dass_x3", None)
+    if not t.is_inference():
+        torch.autograd.graph.increment_version(t)
+
+
 def scale_shift_act(x, ldx, out, ldo, m, k, scale, shift, residual=None, ldr=0, nc_scale=None, rows_per_image=1,
                     act=ACT_NONE, out3=None):
     """out3: optional x3 buffer that receives the same values as three bf16 parts (operand of the next dense conv)"""
+    if out is not None and out.data_ptr() == x.data_ptr() and out3 is None:
+        written_in_place(out)
     check(lib.dass_scale_shift_act(_p(x), ldx, _p(out), ldo, _p(scale), _p(shift), _p(residual), ldr, _p(nc_scale),
                                    m, k, rows_per_image, act, _dt(x), _p(out3), _stream()), "dass_scale_shift_act")
 
@@ -1705,6 +1716,7 @@ def box_sum(maps, r):
 def zero_rect(maps, i, r0, r1, c0, c1):
     n, h, w = maps.shape
     r0, c0, r1, c1 = max(r0, 0), max(c0, 0), min(r1, h), min(c1, w)
+    written_in_place(maps)
     check(lib.dass_zero_rect(_p(maps), i, h, w, r0, r1, c0, c1, _stream()), "dass_zero_rect")
 
 
@@ -1795,5 +1807,8 @@ def add_noise_(x, std, generator=None):
     noise = torch.randn((n, h, w, c), device=xs.device, dtype=torch.float32, generator=generator).mul_(std).to(xs.dtype)
     if c % 4 == 0 and ld % 4 == 0:
         check(lib.dass_add_channels(_p(noise), c, _p(xs), ld, n * h * w, c, _dt(xs), _stream()), "dass_add_channels")
+        written_in_place(xs)  # (split rows attached to the un-noised tensor are stale now)
+        if xs is not x:
+            written_in_place(x)
         return xs
     return xs + noise.permute(0, 3, 1, 2)

@@ -4,6 +4,17 @@ Same constructor, build_loss(mode) -> bound callable (logit[N,C,H,W], target[N,H
 tensor with autograd, NotImplementedError for unknown modes.  The log-softmax + NLL + ignore-index mean
 (and its gradient) are the fused dass_ce_* kernels; the scalar focal transform stays scalar torch math,
 exactly as the reference composes it on top of the CE scalar.
+
+Multi-process training (one process per GPU).  The reference evaluates the loss on the logits GATHERED from all DataParallel
+replicas and divides by the GLOBAL batch size (utils/loss.py:39-51 behind active_train.py:82-85,104-105).  That form is an
+explicit opt-in here -- SegmentationLosses(..., global_batch=True) -- because it issues collectives inside every loss call:
+  * contract: EVERY rank calls the loss the same number of times, and the gradients are then AVERAGED over the ranks
+    (dass_hip.dist.GradientAverager / average_gradients, torch DDP): the backward pre-multiplies by the world size so that
+    the averaged gradient equals the single-process one;
+  * calls with autograd disabled (validation under torch.no_grad(), where ranks may hold different numbers of batches) stay
+    rank-local unless global_batch_in_eval=True;
+  * the default (global_batch=False) never communicates: a process group that exists only for sharded pool scoring does not
+    change what a rank-local training step computes.
 """
 import torch
 
@@ -13,11 +24,17 @@ from dass_hip.dist import global_batch_mean, sum_over_ranks, world_size
 
 class SegmentationLosses(object):
 
-    def __init__(self, weight=None, batch_average=True, ignore_index=255, cuda=True):
+    def __init__(self, weight=None, batch_average=True, ignore_index=255, cuda=True, global_batch=False, global_batch_in_eval=False):
         self.ignore_index = ignore_index
         self.weight = weight
         self.batch_average = batch_average
         self.cuda = cuda
+        self.global_batch = global_batch
+        self.global_batch_in_eval = global_batch_in_eval
+
+    def _global(self):
+        """does this call exchange its numerator / counts with the other ranks?"""
+        return bool(self.global_batch) and world_size() > 1 and (torch.is_grad_enabled() or self.global_batch_in_eval)
 
     def build_loss(self, mode='ce'):
         if mode == 'ce':
@@ -39,7 +56,7 @@ class SegmentationLosses(object):
         ranks exchange numerator, valid-pixel count and image count (dass_hip/dist.py:global_batch_mean); a single
         process takes the fused mean kernel path unchanged."""
         n = logit.size(0)
-        if world_size() == 1:
+        if not self._global():
             return ops.cross_entropy(logit, target, self._weight_on(logit.device), self.ignore_index), n
         s, cnt = ops.cross_entropy_parts(logit, target, self._weight_on(logit.device), self.ignore_index)
         return global_batch_mean(s, cnt, n)
@@ -50,7 +67,7 @@ class SegmentationLosses(object):
         # reduction='none' then .mean(-1).mean(-1): ignored pixels count as zeros in the H*W mean
         per_image = torch.stack([ops.cross_entropy_sum(logit[i:i + 1], target[i:i + 1], self._weight_on(logit.device),
                                                        self.ignore_index) for i in range(n)]) / float(h * w)
-        if world_size() > 1:  # mean over the GLOBAL batch (the reference sees the gathered batch on device 0)
+        if self._global():  # mean over the GLOBAL batch (the reference sees the gathered batch on device 0)
             ng = int(round(float(sum_over_ranks(torch.tensor(float(n), device=logit.device), differentiable=False))))
             loss = sum_over_ranks(torch.sum(torch.mul(per_image, weights))) / ng
             n = ng

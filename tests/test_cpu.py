@@ -489,6 +489,16 @@ for mode in ("ce", "focal"):
     avg.finish()
     for (name, p), q in zip(m.named_parameters(), ref.parameters()):
         assert torch.allclose(p.grad, q.grad, rtol=2e-5, atol=1e-8), (mode, name, (p.grad - q.grad).abs().max())
+# utils.loss.SegmentationLosses: the global-batch form is an explicit opt-in, and never runs with autograd disabled (ranks may
+# validate different numbers of batches: rank 0 asks three times here, rank 1 once -- a collective would hang)
+from utils.loss import SegmentationLosses
+assert SegmentationLosses(cuda=False)._global() is False
+opt_in = SegmentationLosses(cuda=False, global_batch=True)
+assert opt_in._global() is True
+with torch.no_grad():
+    for _ in range(3 if rank == 0 else 1):
+        assert opt_in._global() is False
+    assert SegmentationLosses(cuda=False, global_batch=True, global_batch_in_eval=True)._global() is True
 print("rank %d loss ok" % rank)
 dist.destroy_process_group()
 """

@@ -237,3 +237,55 @@ def test_core_set_get_k_center_greedy_selections_vs_reference_execution():
     want = g["core_features"]
     assert feats.shape == (len(keys), 2736)
     assert np.abs(feats[:, ::16] - want).max() <= 1e-3 * max(1.0, np.abs(want).max())
+
+
+# ------------------------------------------------------------------------------------------- ADVICE r2 (latent cache / padding bugs)
+@pytest.mark.parametrize("engine", ["bf16x6", "f16x3"])
+def test_in_place_writers_invalidate_attached_split_rows(engine):
+    """ops.add_noise_ rewrites an activation through its raw pointer: split rows a producer attached to the tensor must not
+    survive it (the next pre-split conv would multiply the un-noised values)"""
+    ops, O, S = _setup()
+    keep = ops.f32_mma()
+    try:
+        ops.set_f32_mma(engine)
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(2, 64, 17, 17, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+        conv = torch.nn.Conv2d(64, 64, 3, 1, 1, bias=False).cuda()
+        conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            xs, ld = ops.rows(x)
+            ops.attach_x3(x, ops.split3_rows(xs, ld, 2 * 17 * 17, 64), 2 * 17 * 17, 64)   # what a producing pass would have done
+            v0 = x._version
+            noisy = ops.add_noise_(x, 0.5, generator=torch.Generator(device="cuda").manual_seed(1))
+            assert noisy._version > v0 and ops.attached_x3(noisy, 2 * 17 * 17, 64) is None
+            got = ops.conv_bn_act(noisy, conv).float().cpu()
+            want = torch.nn.functional.conv2d(noisy.float().cpu().double(), conv.weight.detach().cpu().double(), padding=1)
+        assert (got.double() - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+    finally:
+        ops.set_f32_mma(keep)
+
+
+@pytest.mark.parametrize("k", [48, 144])
+def test_fused_inference_chain_with_ragged_channel_slab(k):
+    """K % 32 != 0 between two fused inference convs (three-part engine: the first conv's epilogue emits the split rows the
+    second one reads): the tail of the last 32-channel slab must be zeros, not whatever the allocator left there"""
+    ops, O, S = _setup()
+    keep = ops.f32_mma()
+    try:
+        ops.set_f32_mma("bf16x6")
+        torch.manual_seed(4)
+        c1 = torch.nn.Conv2d(64, k, 3, 1, 1, bias=False).cuda()
+        c2 = torch.nn.Conv2d(k, 64, 3, 1, 1, bias=False).cuda()
+        for c in (c1, c2):
+            c.weight.data = c.weight.data.contiguous(memory_format=torch.channels_last)
+        x = torch.randn(2, 64, 33, 33, generator=torch.Generator().manual_seed(6)).cuda()
+        junk = torch.full((64 << 20,), float("nan"), device="cuda")   # poison the allocator's free list
+        del junk
+        with torch.no_grad():
+            y = ops.conv_bn_act(ops.conv_bn_act(x.contiguous(memory_format=torch.channels_last), c1, act=ops.ACT_RELU), c2).float().cpu()
+            want = torch.nn.functional.conv2d(torch.relu(torch.nn.functional.conv2d(x.double().cpu(), c1.weight.detach().double().cpu(), padding=1)),
+                                              c2.weight.detach().double().cpu(), padding=1)
+        assert torch.isfinite(y).all()
+        assert (y.double() - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+    finally:
+        ops.set_f32_mma(keep)

@@ -83,7 +83,7 @@ params = [conv.weight, bn.weight, bn.bias]
 avg = GradientAverager(params, bucket_bytes=4096)
 xd2 = x[sl].cuda().contiguous(memory_format=torch.channels_last)
 lg = ops.conv_bn_act(xd2, conv, bn, ops.ACT_NONE)
-loss = SegmentationLosses(cuda=True).build_loss("ce")(lg.float().contiguous(), lab[sl].cuda())
+loss = SegmentationLosses(cuda=True, global_batch=True).build_loss("ce")(lg.float().contiguous(), lab[sl].cuda())
 assert abs(loss.item() - ref_loss.item()) <= 1e-5 * abs(ref_loss.item()), (loss.item(), ref_loss.item())
 loss.backward()
 assert avg.finish() >= 1
