@@ -244,6 +244,33 @@ def test_abi_argument_checks_without_gpu():
     assert L.dass_vote_entropy(None, None, 1, 10, 10, 19, None, None, None, None) == 1
     with pytest.raises(RuntimeError):
         _lib.check(1, "dass_conv2d_igemm")
+    # the activation-gate buffer of the BN sums path (one byte per 4-channel group of every row): a buffer smaller than
+    # M * K / 4 is rejected by all three entry points before anything is launched (round 2's GPU memory fault)
+    import ctypes
+
+    M, K = 100, 64
+    buf = (ctypes.c_char * 4096)()
+    p = ctypes.cast(buf, ctypes.c_void_p)   # any non-null, 16-B aligned host address: the checks return before a launch
+    good, short = M * (K // 4), M * (K // 4) - 1
+    args_apply = lambda nbytes: (p, K, p, K, p, float(M), None, None, None, None, -1.0, 1e-5, p, p, p, p, None, 0, None, M, K, M, 1, 0,
+                                 None, p, nbytes, None, None)  # noqa: E731
+    assert L.dass_bn_apply_train(*args_apply(short)) == 1
+    args_red = lambda nbytes: (p, K, None, 0, p, K, p, p, None, None, None, M, K, M, 1, p, p, nbytes, 0, None)  # noqa: E731
+    assert L.dass_bn_bwd_reduce_sums(*args_red(short)) == 1
+    args_bwd = lambda nbytes: (p, K, None, 0, p, K, p, p, p, p, p, p, None, None, None, p, K, None, 0, M, K, M, float(M), 1, p, nbytes,
+                               0, None, None)  # noqa: E731
+    assert L.dass_bn_bwd_apply_sums(*args_bwd(short)) == 1
+    assert good > short
+    # two-part x3 output with a residual needs the residual's bound
+    parts_before = L.dass_get_x3_parts()
+    assert L.dass_set_x3_parts(2) == 0
+    try:
+        a = list(args_apply(good))
+        a[16], a[17], a[24] = p, K, p          # residual + out3, no residual_bound
+        assert L.dass_bn_apply_train(*a) == 1
+    finally:
+        assert L.dass_set_x3_parts(parts_before) == 0
+    assert L.dass_set_x3_parts(5) == 1 and L.dass_get_x3_parts() == parts_before
 
 
 def test_product_fails_loudly_without_gpu_or_library(tmp_path):
