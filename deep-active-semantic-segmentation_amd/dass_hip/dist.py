@@ -181,6 +181,10 @@ class GradientAverager(object):
         self.works = []
 
     def _hook(self, p):
+        from . import ops
+
+        if ops.wgrad_pending(p):  # its gradient is still queued for the grouped launch (ops._wgrad_flush calls again when it is set)
+            return
         bi = self.where[id(p)]
         self.pending[bi] -= 1
         self._launch_ready()

@@ -1101,7 +1101,7 @@ class _ConvBnAct(torch.autograd.Function):
 # written to `weight.grad` (accumulated if one exists) and the parameter's post-accumulate-grad hooks are fired, exactly what
 # autograd's AccumulateGrad node would have done; the Function itself returns None for the weight.  DASS_WGRAD_DEFER=0 /
 # set_deferred_wgrad(False): per-layer launches inside backward.
-_wg = {"on": os.environ.get("DASS_WGRAD_DEFER", "1") == "1", "queue": [], "armed": False}
+_wg = {"on": os.environ.get("DASS_WGRAD_DEFER", "1") == "1", "queue": [], "armed": False, "pending": set()}
 
 
 def set_deferred_wgrad(on):
@@ -1112,8 +1112,16 @@ def deferred_wgrad():
     return _wg["on"]
 
 
+def wgrad_pending(p):
+    """is the weight gradient of parameter `p` still queued for the grouped launch of the running backward pass?  (autograd may
+    run the parameter's AccumulateGrad node -- and its post-accumulate hooks -- with an undefined gradient when a Function
+    returns None: hook owners that count gradients in, like dist.GradientAverager, ask here and wait for _wgrad_flush's call)"""
+    return id(p) in _wg["pending"]
+
+
 def _wgrad_enqueue(weight, x3, dy3, dwk, dims, k, c_in):
     _wg["queue"].append((weight, x3, dy3, dwk, dims, k, c_in))
+    _wg["pending"].add(id(weight))
     if not _wg["armed"]:
         _wg["armed"] = True
         torch.autograd.Variable._execution_engine.queue_callback(_wgrad_flush)
@@ -1136,13 +1144,17 @@ def _wgrad_flush():
     scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
     check(lib.dass_conv2d_wgrad_x3_group(items.ctypes.data_as(ctypes.c_void_p), len(q), _p(scratch), scratch.numel(), _stream()),
           "dass_conv2d_wgrad_x3_group")
+    _wg["pending"] = set()
     with torch.no_grad():
+        done = {}
         for weight, x3, dy3, dwk, dims, k, c_in in q:
             dw = dwk[:k, :, :, :c_in].permute(0, 3, 1, 2)
             if weight.grad is None:
                 weight.grad = dw
             else:
                 weight.grad.add_(dw)
+            done[id(weight)] = weight
+        for weight in done.values():  # (a module applied twice in one forward queued twice: its hooks fire once, after both)
             hooks = getattr(weight, "_post_accumulate_grad_hooks", None)
             if hooks:
                 for hook in list(hooks.values()):

@@ -1,0 +1,55 @@
+"""SURVEY.md 8f row 4, second half: the DataParallel-free active-learning round (tools/active_round.py: train k steps ->
+score the sharded pool -> extend the labelled set -> train again, active_train.py:82-85,440-527) on two ranks.  gloo here: the
+box has one GPU and RCCL refuses two ranks on one device; every collective call is backend-agnostic (the driver's default
+backend is nccl = RCCL).  Both ranks must end with identical selections and bit-identical parameters, and -- with SyncBN,
+where two half-batches ARE one batch -- with the selections and (to rounding) the losses of ONE process on the whole batch."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "tools", "active_round.py")
+
+
+def _run(world, dump, extra, port):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), DASS_BENCH_ONE_DEVICE="1",
+               DASS_BENCH_BACKEND="gloo", DASS_ROUND_DUMP=str(dump))
+    procs = [subprocess.Popen([sys.executable, TOOL] + extra, env=dict(env, RANK=str(r), LOCAL_RANK="0"), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    return [json.load(open(os.path.join(str(dump), "rank%d.json" % r))) for r in range(world)]
+
+
+@pytest.mark.parametrize("mode", ["mc_dropout", "coreset"])
+def test_two_ranks_agree_on_selections_and_weights(tmp_path, mode):
+    size = "513" if mode == "coreset" else "97"   # the core-set feature is avg_pool(64, 32) of the 1/4-scale map: needs 513
+    common = ["--mode", mode, "--rounds", "2", "--steps", "3", "--pool", "14", "--seed-set", "4", "--select", "3", "--size", size,
+              "--batch", "2", "--mc-steps", "3"]
+    r = _run(2, tmp_path, common, 29561 if mode == "coreset" else 29563)
+    assert r[0]["selections"] == r[1]["selections"] and len(r[0]["selections"]) == 2 and all(len(s) == 3 for s in r[0]["selections"])
+    assert len(set(sum(r[0]["selections"], []))) == 6                    # nothing selected twice
+    assert r[0]["param_sha256"] == r[1]["param_sha256"]                  # averaged gradients: bit-identical replicas
+    assert r[0]["losses"] == r[1]["losses"]                              # the global-batch loss has one value on every rank
+    assert r[0]["labelled"] == 4 + 6
+
+
+def test_two_ranks_with_syncbn_equal_one_process(tmp_path):
+    common = ["--mode", "ceal_entropy", "--rounds", "2", "--steps", "3", "--pool", "12", "--seed-set", "4", "--select", "2", "--size", "97",
+              "--sync-bn"]
+    d2, d1 = tmp_path / "w2", tmp_path / "w1"
+    d2.mkdir()
+    d1.mkdir()
+    two = _run(2, d2, common + ["--batch", "2"], 29565)
+    one = _run(1, d1, common + ["--batch", "4"], 29567)[0]
+    assert two[0]["selections"] == two[1]["selections"]
+    # against ONE process: the same images every round (their order inside a round may swap: the scores of these noise images lie
+    # within 1e-4 of each other and the two runs agree to rounding only)
+    assert [sorted(s) for s in two[0]["selections"]] == [sorted(s) for s in one["selections"]], (two[0]["selections"], one["selections"])
+    assert two[0]["param_sha256"] == two[1]["param_sha256"]
+    for a, b in zip(two[0]["losses"], one["losses"]):
+        assert abs(a - b) <= 2e-4 * abs(b), (two[0]["losses"], one["losses"])
