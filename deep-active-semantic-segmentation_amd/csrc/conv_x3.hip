@@ -39,7 +39,9 @@ struct X3P {
     float *ws;  // stream-K workspace: 2 slabs of BM x BN f32 per workgroup of the main launch
     long ldy, ldr;
     unsigned x3_bytes, w3_bytes, zero_off, row_pitch;  // row_pitch = CC * (parts * 64)
-    unsigned x3_tr, w3_tr;  // byte offsets of the operands' trailers {inv_scale, bound} (two-part format)
+    unsigned x3_tr, w3_tr;  // byte offsets of the operands' trailers {inv_scale, bound, amax} (two-part format)
+    unsigned *y_amax;       // optional: atomic max of |output| (bit pattern of a non-negative float); for a two-part y3 its trailer[2]
+    int y3_parts;           // format of y3: 3, or 2 (its trailer {inv_scale, bound} was written by dass_x3_prepare_out BEFORE this launch)
     int cc_out;
     int N, H, W, CC, OH, OW, K, R, S, stride, pad, dil, act;
     int M, mtiles, ntiles, sk_wgs;
@@ -93,7 +95,7 @@ template <> struct Terms<3> { static constexpr int N = 6; static constexpr int P
 template <> struct Terms<2> { static constexpr int N = 3; static constexpr int PA[3] = {0, 1, 0}; static constexpr int PB[3] = {1, 0, 0}; };
 
 // fused epilogue of ONE 4-channel group of output pixel m (tile-independent: used by the main kernel and the fix-up pass)
-__device__ __forceinline__ void x3_store_out(const X3P &p, f32x4 v, int m, int k, int ohw, bool vec_ok) {
+__device__ __forceinline__ void x3_store_out(const X3P &p, f32x4 v, int m, int k, int ohw, bool vec_ok, float y3_scale, float &vmax) {
     float *y = reinterpret_cast<float *>(p.y);
     const float *res = reinterpret_cast<const float *>(p.res);
     long mo = m;  // output pixel index; differs from m only for a phase sub-grid
@@ -109,15 +111,29 @@ __device__ __forceinline__ void x3_store_out(const X3P &p, f32x4 v, int m, int k
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
         if (y) *reinterpret_cast<f32x4 *>(y + mo * p.ldy + k) = v;
-        if (p.y3) x3_store4(p.y3, mo, p.cc_out, k, v);
+        if (p.y3) x3_store4r(p.y3, mo, p.cc_out, k, v, p.y3_parts, y3_scale);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vmax = fmaxf(vmax, fabsf(v[e]));
     } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (k + e >= p.K) break;
             float u = v[e] * (p.scale ? p.scale[k + e] : 1.f) + (p.shift ? p.shift[k + e] : 0.f);
             if (res) u += res[mo * p.ldr + k + e];
-            y[mo * p.ldy + k + e] = apply_act(u, p.act);
+            u = apply_act(u, p.act);
+            y[mo * p.ldy + k + e] = u;
+            vmax = fmaxf(vmax, fabsf(u));
         }
+    }
+}
+// one atomic max per wave of the largest |output| its lanes stored
+__device__ __forceinline__ void x3_amax_commit(unsigned *slot, float vmax) {
+    if (!slot) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    if ((threadIdx.x & 63) == 0) {
+        if (!(vmax >= 0.f)) vmax = __uint_as_float(0x7f800000u);
+        if (__float_as_uint(vmax) > *reinterpret_cast<volatile unsigned *>(slot)) atomicMax(slot, __float_as_uint(vmax));
     }
 }
 
@@ -630,9 +646,14 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     float *patch = reinterpret_cast<float *>(smem) + wave * 32 * PITCH;
     const bool vec_ok = (!y || (p.ldy & 3) == 0) && ((p.K & 3) == 0) && (!res || (p.ldr & 3) == 0);
     float *slab = complete ? nullptr : p.ws + ((long)wgid * 2 + (sk_seg > 0 ? 1 : 0)) * (BM * BN);
-    if (p.y3 && tile == 0 && s_lo == 0)  // the zero row consumers point padded taps at (+ the trailer; y3 is a three-part tensor)
-        for (int i = tid; i < p.cc_out * 12 + 1; i += 64 * NW)
-            *reinterpret_cast<uint4 *>(p.y3 + (long)p.M * p.cc_out * 192 + i * 16) = i < p.cc_out * 12 ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(0x3f800000u, 0u, 0u, 0u);
+    float y3_scale = 1.f, vmax = 0.f;
+    if (p.y3 && p.y3_parts == 2)  // the output's scale: from the bound dass_x3_prepare_out left in y3's trailer (same in every workgroup)
+        y3_scale = x3_scale_of(*reinterpret_cast<const float *>(p.y3 + ((long)p.M + 1) * p.cc_out * 128 + 4));
+    if (p.y3 && tile == 0 && s_lo == 0) {  // the zero row consumers point padded taps at (+ the trailer of a three-part y3)
+        const int zb = p.y3_parts * 64, n16 = p.cc_out * p.y3_parts * 4;
+        for (int i = tid; i < n16 + (p.y3_parts == 3 ? 1 : 0); i += 64 * NW)
+            *reinterpret_cast<uint4 *>(p.y3 + (long)p.M * p.cc_out * zb + i * 16) = i < n16 ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(0x3f800000u, 0u, 0u, 0u);
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -669,12 +690,13 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
                 }
                 const int m = m0 + lr, k = n0 + lc;
                 if (m >= m_end || k >= p.K) continue;
-                x3_store_out(p, v, m, k, ohw, vec_ok);
+                x3_store_out(p, v, m, k, ohw, vec_ok, y3_scale, vmax);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
     }
+    x3_amax_commit(p.y_amax, vmax);
     }  // segments
 }
 
@@ -721,6 +743,8 @@ template <int BM, int BN> __global__ __launch_bounds__(256) void conv_x3_fixup_k
     const int nc = ncontrib;
     const int c4 = tid % C4, r0 = tid / C4;
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    float y3_scale = 1.f, vmax = 0.f;
+    if (p.y3 && p.y3_parts == 2) y3_scale = x3_scale_of(*reinterpret_cast<const float *>(p.y3 + ((long)p.M + 1) * p.cc_out * 128 + 4));
     // blockIdx.y cuts the tile's rows (more blocks in flight: the pass is latency-bound); BN statistics need the whole tile
     const int rows_per_block = BM / gridDim.y, row_lo = blockIdx.y * rows_per_block;
     for (int lr = row_lo + r0; lr < row_lo + rows_per_block; lr += RPP) {
@@ -729,8 +753,9 @@ template <int BM, int BN> __global__ __launch_bounds__(256) void conv_x3_fixup_k
         s1 += v;
         s2 += v * v;
         const int m = m0 + lr, k = n0 + c4 * 4;
-        if (m < m_end && k < p.K) x3_store_out(p, v, m, k, ohw, vec_ok);
+        if (m < m_end && k < p.K) x3_store_out(p, v, m, k, ohw, vec_ok, y3_scale, vmax);
     }
+    x3_amax_commit(p.y_amax, vmax);
     if (p.stat_partial || p.stat_sums) {  // rows >= M of the slabs are exact zeros
         constexpr int NR = RPP;
         for (int e = 0; e < 4; ++e) {
@@ -761,7 +786,10 @@ __global__ __launch_bounds__(256) void split3_rows_kernel(const float *__restric
     if constexpr (NP == 2) {
         unsigned *tr = reinterpret_cast<unsigned *>(out + (M + 1) * CC * SB);
         scale = x3_scale_of(__uint_as_float(tr[1]));
-        if (blockIdx.x == 0 && threadIdx.x == 0) tr[0] = __float_as_uint(x3_inv_of(scale));
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            tr[0] = __float_as_uint(x3_inv_of(scale));
+            tr[2] = tr[1];  // (here the bound IS max |x|)
+        }
     }
     const long units = (M + 1) * CC * 4;  // 8-channel units
     for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (long)gridDim.x * blockDim.x) {
@@ -997,7 +1025,8 @@ extern "C" int dass_split3_rows(const float *x, int64_t ld, void *out, int64_t M
 static int conv_x3_impl(const void *x3, const void *w3, void *y, int64_t ldy, void *y3, const float *scale, const float *shift,
                         const void *residual, int64_t ldr, int N, int H, int W, int C, int OH, int OW, int K, int R, int S, int stride,
                         int pad, int dil, int ustride, int act, float *stat_partial, int *stat_rows, void *workspace,
-                        int64_t workspace_bytes, void *stream, bool per_image, const int *cc_limit, double *stat_sums = nullptr) {
+                        int64_t workspace_bytes, void *stream, bool per_image, const int *cc_limit, double *stat_sums = nullptr,
+                        void *y_amax = nullptr) {
     if (!x3 || !w3 || (!y && !y3)) return DASS_ERR_ARG;
     if (workspace && ((uintptr_t)workspace & 15)) return DASS_ERR_ARG;
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || K <= 0 || R <= 0 || S <= 0) return DASS_ERR_ARG;
@@ -1006,7 +1035,6 @@ static int conv_x3_impl(const void *x3, const void *w3, void *y, int64_t ldy, vo
     if ((long)N * OH * OW >= (1l << 31)) return DASS_ERR_ARG;
     const int CC = (C + 31) / 32;
     const int parts = g_x3_parts, SB = parts * 64;
-    if (parts == 2 && y3) return DASS_ERR_UNSUPPORTED;  // the fused x3 output needs the OUTPUT's bound before the kernel runs (not built)
     const long xtr = x3_trailer_off((long)N * H * W, CC, parts), wtr = (long)K * R * S * CC * SB * (per_image ? N : 1);
     const long xbytes = xtr + 16, wbytes = wtr + 16;
     if (per_image && ustride != 1) return DASS_ERR_UNSUPPORTED;
@@ -1023,6 +1051,9 @@ static int conv_x3_impl(const void *x3, const void *w3, void *y, int64_t ldy, vo
     p.res = (const char *)residual;
     p.stat_partial = stat_partial;
     p.stat_sums = stat_sums;
+    p.y3_parts = parts;
+    // two-part y3: scale from the bound dass_x3_prepare_out wrote into its trailer; the true max |output| goes to trailer[2]
+    p.y_amax = (y3 && parts == 2) ? (unsigned *)((char *)y3 + x3_trailer_off((long)N * OH * OW, (K + 31) / 32, 2) + 8) : (unsigned *)y_amax;
     p.ws = (float *)workspace;
     p.ldy = ldy;
     p.ldr = ldr;
@@ -1083,9 +1114,9 @@ static int conv_x3_impl(const void *x3, const void *w3, void *y, int64_t ldy, vo
 extern "C" int dass_conv2d_x3(const void *x3, const void *w3, void *y, int64_t ldy, void *y3, const float *scale, const float *shift,
                               const void *residual, int64_t ldr, int N, int H, int W, int C, int OH, int OW, int K, int R, int S,
                               int stride, int pad, int dil, int ustride, int act, float *stat_partial, int *stat_rows, void *workspace,
-                              int64_t workspace_bytes, void *stream) {
+                              int64_t workspace_bytes, void *y_amax, void *stream) {
     return conv_x3_impl(x3, w3, y, ldy, y3, scale, shift, residual, ldr, N, H, W, C, OH, OW, K, R, S, stride, pad, dil, ustride, act,
-                        stat_partial, stat_rows, workspace, workspace_bytes, stream, false, nullptr);
+                        stat_partial, stat_rows, workspace, workspace_bytes, stream, false, nullptr, nullptr, y_amax);
 }
 
 /* plain conv + batch statistics added into [2][K] f64 accumulators (zeroed by the caller): see dass_bn_apply_train */
@@ -1105,9 +1136,9 @@ extern "C" int dass_conv2d_x3_sums(const void *x3, const void *w3, void *y, int6
 extern "C" int dass_conv2d_x3_per_image(const void *x3, const void *w3, const int *cc_limit, void *y, int64_t ldy, void *y3,
                                         const float *scale, const float *shift, const void *residual, int64_t ldr, int N, int H, int W,
                                         int C, int OH, int OW, int K, int R, int S, int stride, int pad, int dil, int act,
-                                        void *workspace, int64_t workspace_bytes, void *stream) {
+                                        void *workspace, int64_t workspace_bytes, void *y_amax, void *stream) {
     return conv_x3_impl(x3, w3, y, ldy, y3, scale, shift, residual, ldr, N, H, W, C, OH, OW, K, R, S, stride, pad, dil, 1, act, nullptr,
-                        nullptr, workspace, workspace_bytes, stream, true, cc_limit);
+                        nullptr, workspace, workspace_bytes, stream, true, cc_limit, nullptr, y_amax);
 }
 
 namespace {
@@ -1147,7 +1178,10 @@ __global__ __launch_bounds__(256) void split3_rows_packed_kernel(const float *__
     if constexpr (NP == 2) scale = x3_scale_of(__uint_as_float(*reinterpret_cast<const unsigned *>(out + (M + 1) * CC * SB + 4)));
     if ((long)n * rows_per_image >= M) {  // the extra block: the zero row (+ the trailer's inverse scale)
         for (int i = threadIdx.x; i < CC * NP * 4; i += blockDim.x) *reinterpret_cast<uint4 *>(out + M * CC * SB + i * 16) = make_uint4(0u, 0u, 0u, 0u);
-        if (threadIdx.x == 0) *reinterpret_cast<float *>(out + (M + 1) * CC * SB) = x3_inv_of(scale);
+        if (threadIdx.x == 0) {
+            *reinterpret_cast<float *>(out + (M + 1) * CC * SB) = x3_inv_of(scale);
+            if constexpr (NP == 2) *reinterpret_cast<unsigned *>(out + (M + 1) * CC * SB + 8) = *reinterpret_cast<const unsigned *>(out + (M + 1) * CC * SB + 4);
+        }
         return;
     }
     if (threadIdx.x >= upr * rstep || cc >= cc_limit[n]) return;
@@ -1276,3 +1310,74 @@ extern "C" int dass_w3_pack_per_image(const void *w3, void *out, int64_t rows, i
 
 /* bytes of dass_w3_pack_per_image's output (N copies + the trailer) */
 extern "C" int64_t dass_w3_pack_bytes(int64_t rows, int C, int N) { return (int64_t)N * rows * ((C + 31) / 32) * (g_x3_parts * 64) + 16; }
+
+// ---- fused two-part output (y3 of dass_conv2d_x3* under dass_set_x3_parts(2)).  The per-tensor scale of y3 must be fixed before
+// the conv runs, from a bound of its output:  |act(scale_k * sum_c x w + shift_k + res)| <= max_k(|scale_k| L1_k) * max|x| +
+// max_k |shift_k| + max|res|,  L1_k = sum over taps and channels of |w_k| (dass_weight_l1, cached with the weight operand).
+// max|x| is the TRUE maximum of the input (trailer[2]: exact for dass_split3_rows, tracked by the producing conv's epilogue for a
+// fused chain), so the looseness does not compound from layer to layer: it stays at ~sqrt(fan-in) * (max / rms of x), 2^8 .. 2^11
+// for this network, inside the 2^14 the format tolerates (dass_common.h).  One tiny launch per conv.
+namespace {
+__global__ __launch_bounds__(256) void weight_l1_kernel(const float *__restrict__ w, long row_len, float *__restrict__ l1) {
+    const float *row = w + (long)blockIdx.x * row_len;
+    float a = 0.f;
+    for (long i = threadIdx.x; i < row_len; i += blockDim.x) a += fabsf(row[i]);
+    a = wave_sum(a);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) l1[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void x3_prepare_out_kernel(char *y3, long out_rows, int K, const float *__restrict__ l1, const float *__restrict__ scale,
+                                                             const float *__restrict__ shift, const char *x3_in, long in_tr,
+                                                             const float *__restrict__ res_amax, float mask_max, int act) {
+    float c1 = 0.f, c2 = 0.f;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        c1 = fmaxf(c1, fabsf(scale ? scale[k] : 1.f) * l1[k]);
+        if (shift) c2 = fmaxf(c2, fabsf(shift[k]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        c1 = fmaxf(c1, __shfl_xor(c1, o, 64));
+        c2 = fmaxf(c2, __shfl_xor(c2, o, 64));
+    }
+    __shared__ float red[2][4];
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = c1;
+        red[1][threadIdx.x >> 6] = c2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c1 = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+        c2 = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+        const float amax_in = *reinterpret_cast<const float *>(x3_in + in_tr + 8);
+        float bound = 1.0625f * c1 * amax_in * mask_max + c2 + (res_amax ? *res_amax : 0.f);  // (1/16 slack: f32 rounding of l1 and of the sums)
+        if (act == DASS_ACT_RELU6) bound = fminf(bound, 6.f);
+        const float sc = x3_scale_of(bound);
+        char *tr = y3 + x3_trailer_off(out_rows, (K + 31) >> 5, 2);
+        *reinterpret_cast<uint4 *>(tr) = make_uint4(__float_as_uint(x3_inv_of(sc)), __float_as_uint(bound), 0u, 0u);  // [2]: the epilogues' atomic max
+    }
+}
+}  // namespace
+
+/* l1[k] = sum |w[k][...]| over a row of row_len floats (K rows): the weight-side factor of the output bound of a fused two-part conv */
+extern "C" int dass_weight_l1(const float *w, int K, int64_t row_len, float *l1, void *stream) {
+    if (!w || !l1 || K <= 0 || row_len <= 0) return DASS_ERR_ARG;
+    hipLaunchKernelGGL(weight_l1_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, w, (long)row_len, l1);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+/* Prepare the trailer of a two-part y3 [out_rows][K] that the NEXT dass_conv2d_x3* launch on this stream will write from its epilogue:
+ * bound = max_k(|scale_k| l1_k) * amax(x3_in) * mask_max + max_k |shift_k| + *res_amax  (scale / shift / res_amax nullable; ReLU6 caps
+ * at 6; mask_max = the largest multiplier of a Dropout2d mask folded into the operand, 1 if none), inverse scale, zeroed amax slot. */
+extern "C" int dass_x3_prepare_out(void *y3, int64_t out_rows, int K, const float *l1, const float *scale, const float *shift, const void *x3_in,
+                                   int64_t in_rows, int in_C, const float *res_amax, float mask_max, int act, void *stream) {
+    if (!y3 || !l1 || !x3_in || out_rows <= 0 || K <= 0 || in_rows <= 0 || in_C <= 0 || !(mask_max > 0.f)) return DASS_ERR_ARG;
+    if (g_x3_parts != 2) return DASS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(x3_prepare_out_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (char *)y3, (long)out_rows, K, l1, scale, shift,
+                       (const char *)x3_in, x3_trailer_off(in_rows, (in_C + 31) / 32, 2), res_amax, mask_max, act);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}

@@ -74,7 +74,7 @@ __device__ __forceinline__ void split3_4(f32x4 v, uint2 &p0, uint2 &p1, uint2 &p
 }
 // ---- x3 operand formats (csrc/conv_x3.hip).  An activation [rows][C] f32 is kept as rows x ceil(C/32) slabs of
 //   [NP parts][32 ch] 2-byte elements (NP * 64 B), then ONE all-zero row (padded taps point at it), then a 16-B trailer
-//   {float inv_scale, uint bound_bits, 0, 0}.
+//   {float inv_scale, float bound >= max |x|, float amax (max |x| itself where the producer knows it, else the bound), 0}.
 //   NP = 3 ("bf16x6" engine): x = x0 + x1 + x2, three bf16 parts, exact to 2^-26 |x|; six products per pair; trailer unused (1.0).
 //   NP = 2 ("f16x3" engine): x * s = h0 + h1, two f16 parts (h0 = f16(x s), h1 = f16(x s - h0): 11 + 1 + 11 significant bits,
 //            |x s - h0 - h1| <= 2^-23 |x s|); s = a power of two chosen per TENSOR from a guaranteed bound B >= max |x| so that
@@ -134,7 +134,8 @@ __device__ __forceinline__ void x3_store4r(char *base, long m, int cc, int k, f3
 __device__ __forceinline__ void x3_zero_row(char *base, long rows, int cc, int parts = 3, float inv_scale = 1.f, float bound = 0.f) {
     char *z = base + rows * cc * (parts * 64);
     for (int i = threadIdx.x; i < cc * parts * 4; i += blockDim.x) *reinterpret_cast<uint4 *>(z + i * 16) = make_uint4(0u, 0u, 0u, 0u);
-    if (threadIdx.x == 0) *reinterpret_cast<uint4 *>(z + cc * parts * 64) = make_uint4(__float_as_uint(inv_scale), __float_as_uint(bound), 0u, 0u);
+    if (threadIdx.x == 0)  // {inv_scale, bound, max |x| where it is known exactly -- else the bound again --, 0}
+        *reinterpret_cast<uint4 *>(z + cc * parts * 64) = make_uint4(__float_as_uint(inv_scale), __float_as_uint(bound), __float_as_uint(bound), 0u);
 }
 // host + device: bytes of an x3 tensor (rows + zero row + trailer) and the trailer's offset
 static inline __host__ __device__ long x3_trailer_off(long rows, int cc, int parts) { return (rows + 1) * cc * (long)(parts * 64); }

@@ -226,15 +226,54 @@ def split3_rows(x, ld, m, c, nc_scale=None, rows_per_image=1):
 
 
 def conv_x3_launch(x3, w3, y, ldy, dims, y3=None, scale=None, shift=None, residual=None, ldr=0, act=ACT_NONE, ustride=1,
-                   stats=None):
-    """dims as conv_launch; stats: None or a [rows, 2, K] f32 buffer -> returns the number of partial rows written"""
+                   stats=None, y_amax=None):
+    """dims as conv_launch; stats: None or a [rows, 2, K] f32 buffer -> returns the number of partial rows written.
+    y3 under the two-part format: call x3_prepare_out(y3, ...) first (the output's scale must exist before the launch);
+    y_amax: optional zeroed 1-element tensor that receives max |output| (bit pattern) when only f32 rows are written"""
     n, h, w, c, oh, ow, k, r, s, stride, pad, dil = dims
     nrows = ctypes.c_int(0)
     ws = _x3_workspace(x3.device)
     check(lib.dass_conv2d_x3(_p(x3), _p(w3), _p(y), ldy, _p(y3), _p(scale), _p(shift), _p(residual), ldr, n, h, w, c, oh, ow, k,
                              r, s, stride, pad, dil, ustride, act, _p(stats), ctypes.byref(nrows) if stats is not None else None,
-                             _p(ws), ws.numel(), _stream()), "dass_conv2d_x3")
+                             _p(ws), ws.numel(), _p(y_amax), _stream()), "dass_conv2d_x3")
     return nrows.value
+
+
+_l1_cache = {}
+
+
+def weight_l1(weight_or_krsc, key=None):
+    """[K] f32: sum |w_k| over taps and input channels (the weight-side factor of a fused two-part conv's output bound), cached
+    on (storage, version) for parameters; a raw [K][R][S][C] tensor is reduced as is"""
+    t = weight_or_krsc
+    if key is None and t.dim() == 4 and isinstance(t, torch.nn.Parameter):
+        ck = (id(t), t.data_ptr(), t._version)
+        hit = _l1_cache.get(id(t))
+        if hit is not None and hit[0] == ck and hit[2]() is t:
+            return hit[1]
+        master = _krsc_master(t)
+    else:
+        ck, master = None, t.contiguous().float()
+    k = master.shape[0]
+    l1 = torch.empty((k,), dtype=torch.float32, device=master.device)
+    check(lib.dass_weight_l1(_p(master), k, master.numel() // k, _p(l1), _stream()), "dass_weight_l1")
+    if ck is not None:
+        if len(_l1_cache) > 4096:
+            for kk in [kk for kk, v in _l1_cache.items() if v[2]() is None]:
+                del _l1_cache[kk]
+        _l1_cache[id(t)] = (ck, l1, weakref.ref(t))
+    return l1
+
+
+def x3_amax_ptr(buf):
+    """device float: max |x| of a two-part x3 buffer (exact when written by dass_split3_rows or tracked by a conv epilogue)"""
+    return ctypes.c_void_p(buf.data_ptr() + buf.numel() - 8)
+
+
+def x3_prepare_out(y3, out_rows, k, l1, scale, shift, x3_in, in_rows, in_c, res_amax=None, act=ACT_NONE, mask_max=1.0):
+    """fix the scale of a two-part y3 before the conv that writes it (include/dass_hip.h dass_x3_prepare_out)"""
+    check(lib.dass_x3_prepare_out(_p(y3), out_rows, k, _p(l1), _p(scale), _p(shift), _p(x3_in), in_rows, in_c, res_amax, float(mask_max), act,
+                                  _stream()), "dass_x3_prepare_out")
 
 
 def dropout_pack(mask):
@@ -268,7 +307,7 @@ def conv_x3_per_image_launch(x3, w3n, lim, y, ldy, dims, y3=None, scale=None, sh
     n, h, w, c, oh, ow, k, r, s, stride, pad, dil = dims
     ws = _x3_workspace(x3.device)
     check(lib.dass_conv2d_x3_per_image(_p(x3), _p(w3n), _p(lim), _p(y), ldy, _p(y3), _p(scale), _p(shift), _p(residual), ldr,
-                                       n, h, w, c, oh, ow, k, r, s, stride, pad, dil, act, _p(ws), ws.numel(), _stream()),
+                                       n, h, w, c, oh, ow, k, r, s, stride, pad, dil, act, _p(ws), ws.numel(), None, _stream()),
           "dass_conv2d_x3_per_image")
 
 
@@ -761,9 +800,19 @@ class _ConvBnAct(torch.autograd.Function):
                 assert not need_grad and tuple(in_scale.shape) == (n, c) and in_scale.dtype == torch.float32
             x3 = x3_operand(x, xs, ldx, n * h * w, c, in_scale, h * w)
             w_op = weight_operand(weight, 0, dt, cpad=c, x3=True)
-            # (two-part format: the fused x3 output would need the OUTPUT's bound before the launch; the consumer converts)
-            want_y3 = getattr(spec, "emit_x3", False) and nc_scale is None and kpad == k and x3_parts() == 3
+            want_y3 = getattr(spec, "emit_x3", False) and nc_scale is None and kpad == k
             y3 = x3_alloc_for(m, k, dev) if want_y3 else None
+            if y3 is not None and x3_parts() == 2:
+                # two-part format: the output's scale is fixed BEFORE the launch from a bound of the result (weights' L1 norms x
+                # the input's true maximum + shift + residual); the epilogue then tracks the true maximum for the next layer
+                res_keep, res_amax = None, None
+                if res_t is not None:
+                    rbuf = attached_x3(residual, m, k)
+                    if rbuf is not None:
+                        res_keep, res_amax = rbuf, x3_amax_ptr(rbuf)
+                    else:
+                        res_keep, res_amax = bound_of(residual, res_t, ldr, m, k)
+                x3_prepare_out(y3, m, k, weight_l1(weight), scale, shift, x3, n * h * w, c, res_amax, spec.act)
             conv_x3_launch(x3, w_op, out, ldo, dims, y3=y3, scale=scale, shift=shift, residual=res_t, ldr=ldr or 0, act=spec.act)
             if y3 is not None:
                 attach_x3(out, y3, m, k)

@@ -67,8 +67,9 @@ class Decoder(nn.Module):
             krsc = wt.detach().float().permute(0, 2, 3, 1)
             wa = ops.prepare_conv_weight(krsc[..., :256].contiguous(), x3=ops.x3_pipeline())
             wb = ops.prepare_conv_weight(krsc[..., 256:].contiguous(), x3=ops.x3_pipeline())
-            hit = self.__dict__["_dass_split_w"] = (key, wa, wb)
-        return hit[1], hit[2]
+            la = ops.weight_l1(krsc[..., :256].contiguous()) if ops.x3_pipeline() and ops.x3_parts() == 2 else None
+            hit = self.__dict__["_dass_split_w"] = (key, wa, wb, la)
+        return hit[1], hit[2], hit[3]
 
     def head_mc_prepare(self, feats):
         """-> state for head_mc_pass: operands + eval-BN vectors + the deterministic low-level share (f32 tensors only)"""
@@ -76,15 +77,17 @@ class Decoder(nn.Module):
 
         n, c, h, w = feats.shape
         assert c == 304 and feats.dtype == torch.float32
-        wa, wb = self._split_first_conv()
+        wa, wb, la = self._split_first_conv()
         st = ops.bn_eval_state(self.last_conv[1], 256, feats.device)
         xb, ldb = ops.rows(feats[:, 256:])
         yb = ops.new_act(n, 256, h, w, torch.float32, feats.device)
+        yb_amax = torch.zeros((4,), dtype=torch.float32, device=feats.device) if la is not None else None  # max |yb|: part of every pass's output bound
         if ops.x3_pipeline():
-            ops.conv_x3_launch(ops.split3_rows(xb, ldb, n * h * w, 48), wb, yb, 256, (n, h, w, 48, h, w, 256, 3, 3, 1, 1, 1), scale=st.scale)
+            ops.conv_x3_launch(ops.split3_rows(xb, ldb, n * h * w, 48), wb, yb, 256, (n, h, w, 48, h, w, 256, 3, 3, 1, 1, 1), scale=st.scale,
+                               y_amax=yb_amax)
         else:
             ops.conv_launch(xb, ldb, wb, yb, 256, (n, h, w, 48, h, w, 256, 3, 3, 1, 1, 1), scale=st.scale)
-        return wa, st, yb
+        return wa, st, yb, la, yb_amax
 
     def head_mc_pack(self, prep, masks1):
         """the Dropout2d-sparse operands of ALL T passes in two launches: masks1 [T, N, 256] -> per pass (order, limit,
@@ -106,7 +109,7 @@ class Decoder(nn.Module):
         packed: this pass's entry of head_mc_pack (else the operands are packed here)"""
         import torch
 
-        wa, st, yb = prep
+        wa, st, yb, la, yb_amax = prep
         n, c, h, w = feats.shape
         lc = self.last_conv
         xa, lda = ops.rows(feats[:, :256])
@@ -119,11 +122,15 @@ class Decoder(nn.Module):
             # of this conv's multiplications are never issued.
             m = n * h * w
             m1 = m1.contiguous()
-            # three-part format: the first conv hands its result to the second as x3 rows from its epilogue; two-part format:
-            # it writes f32 rows and the rows are converted by dass_split3_rows (the per-tensor scale needs max |h1| first)
-            fused3 = ops.x3_parts() == 3
-            h1_3 = ops.x3_alloc(m, 256, feats.device) if fused3 else None
-            h1 = None if fused3 else ops.new_act(n, 256, h, w, torch.float32, feats.device)
+            # the first conv hands its result to the second as x3 rows from its epilogue (two-part format: the rows' scale is fixed
+            # before the launch by x3_prepare_out from a bound of the result -- L1 norms of wa x max |masked xa| + shift + max |yb|)
+            h1_3 = ops.x3_alloc(m, 256, feats.device)
+            h1 = None
+
+            def prepare(xa3):
+                if la is not None:
+                    ops.x3_prepare_out(h1_3, m, 256, la, st.scale, st.shift, xa3, m, 256, ops._p(yb_amax), ops.ACT_RELU)
+
             if ops.mc_sparse():
                 if packed is not None:
                     order, lim, wan = packed
@@ -131,14 +138,14 @@ class Decoder(nn.Module):
                     order, lim = ops.dropout_pack(m1)
                     wan = ops.w3_pack_per_image(wa, 256 * 9, 256, order, lim)
                 xa3 = ops.split3_rows_packed(xa, lda, m, 256, m1, order, lim, h * w)
+                prepare(xa3)
                 ops.conv_x3_per_image_launch(xa3, wan, lim, h1, 256, dims, y3=h1_3, scale=st.scale, shift=st.shift, residual=yb,
                                              ldr=256, act=ops.ACT_RELU)
             else:
                 xa3 = ops.split3_rows(xa, lda, m, 256, nc_scale=m1, rows_per_image=h * w)
+                prepare(xa3)
                 ops.conv_x3_launch(xa3, wa, h1, 256, dims, y3=h1_3, scale=st.scale, shift=st.shift, residual=yb, ldr=256,
                                    act=ops.ACT_RELU)
-            if not fused3:
-                h1_3 = ops.split3_rows(h1, 256, m, 256)
             st2 = ops.bn_eval_state(lc[4], 256, feats.device)
             h2 = ops.new_act(n, 256, h, w, torch.float32, feats.device)
             ops.conv_x3_launch(h1_3, ops.weight_operand(lc[3].weight, 0, torch.float32, cpad=256, x3=True), h2, 256, dims,

@@ -380,8 +380,16 @@ int64_t dass_x3_bytes(int64_t rows, int C);
  *   dass_bn_apply_train (out3)     batch statistics: |gamma xhat + beta| <= max|gamma| sqrt(M - 1) + max|beta| (+ residual_bound),
  *   dass_bn_bwd_apply_sums (dx3)   max over channels of |gamma invstd| (max|dz| + |mean dz| + sqrt(M - 1) |mean(dz xhat)|),
  *   weights                        max |w| (dass_weight_split_batch_f16).
- * Not available in the two-part format (DASS_ERR_UNSUPPORTED): y3 of dass_conv2d_x3*, out3 of dass_scale_shift_act, dx3 of
- * dass_bn_bwd_apply / _gate -- their consumers convert with dass_split3_rows instead. */
+ *   y3 of dass_conv2d_x3*          dass_x3_prepare_out BEFORE the launch: max_k(|scale_k| L1_k) * max|x| + max_k |shift_k| + max|res|
+ *                                  with L1_k = sum |w_k| (dass_weight_l1) and the TRUE max |x| (trailer[2]; the conv epilogues
+ *                                  maintain it for their own outputs, so the looseness does not compound along a fused chain),
+ * Not available in the two-part format (DASS_ERR_UNSUPPORTED): out3 of dass_scale_shift_act, dx3 of dass_bn_bwd_apply / _gate
+ * -- their consumers convert with dass_split3_rows instead.
+ * y_amax (dass_conv2d_x3 / _per_image, nullable): device uint32, zeroed by the caller, that receives the bit pattern of
+ * max |output| (atomic max) when only f32 rows are written; a two-part y3 keeps it in its own trailer. */
+int dass_weight_l1(const float *w, int K, int64_t row_len, float *l1, void *stream);
+int dass_x3_prepare_out(void *y3, int64_t out_rows, int K, const float *l1, const float *scale, const float *shift, const void *x3_in,
+                        int64_t in_rows, int in_C, const float *res_amax, float mask_max, int act, void *stream);
 int dass_set_x3_parts(int parts);
 int dass_get_x3_parts(void);
 /* bound[0] = max over rows of |x[m][c] * nc_scale[m / rows_per_image][c]| (nc_scale nullable), as an atomic max: zero it first */
@@ -409,7 +417,7 @@ int dass_split3_rows(const float *x, int64_t ld, void *out, int64_t M, int C, co
 int dass_conv2d_x3(const void *x3, const void *w3, void *y, int64_t ldy, void *y3, const float *scale,
                    const float *shift, const void *residual, int64_t ldr, int N, int H, int W, int C, int OH, int OW,
                    int K, int R, int S, int stride, int pad, int dil, int ustride, int act, float *stat_partial,
-                   int *stat_rows, void *workspace, int64_t workspace_bytes, void *stream);
+                   int *stat_rows, void *workspace, int64_t workspace_bytes, void *y_amax, void *stream);
 /* Dropout2d-sparse form of the same conv for the MC-dropout tail (active_selection/mc_dropout.py:38-51: T stochastic
  * passes through models/decoder.py:23-36 with the ASPP Dropout2d(0.5) of models/aspp.py:89 active).  A dropped input
  * channel contributes exact zeros, so instead of multiplying zeros the surviving channels of every image are packed to the
@@ -429,7 +437,7 @@ int dass_w3_pack_per_image(const void *w3, void *out, int64_t rows, int C, int N
 int dass_conv2d_x3_per_image(const void *x3, const void *w3, const int *cc_limit, void *y, int64_t ldy, void *y3,
                              const float *scale, const float *shift, const void *residual, int64_t ldr, int N, int H,
                              int W, int C, int OH, int OW, int K, int R, int S, int stride, int pad, int dil, int act,
-                             void *workspace, int64_t workspace_bytes, void *stream);
+                             void *workspace, int64_t workspace_bytes, void *y_amax, void *stream);
 /* Weight gradients are accumulated over several pixel splits per tile with f32 atomics (fast, but the last bits depend on
  * arrival order).  dass_set_deterministic(1) makes every weight-gradient launch use ONE split per tile: each dW element is
  * summed by one workgroup in a fixed order -> bit-reproducible (slower on layers with few output tiles). */
