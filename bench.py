@@ -77,6 +77,8 @@ def parse():
     ap.add_argument("--no-mc", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-second-dtype", action="store_true", help="skip the informational legs in the other modes")
+    ap.add_argument("--only", default="", choices=["", "mc", "coreset"],
+                    help="profiling aid: run ONLY the MC-dropout leg / the core-set leg (no train steps; the JSON line then carries no headline)")
     return ap.parse_args()
 
 
@@ -253,6 +255,9 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
         return loss
 
     model.train()
+    if args.only:
+        steps = warmup = 0
+    loss = torch.zeros((), device=dev)
     for i in range(warmup):
         tw = time.perf_counter()
         train_step()
@@ -264,8 +269,8 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
     for _ in range(steps):
         loss = train_step()
     barrier()
-    dt = tmax(time.perf_counter() - t0)
-    res = {"train_ips": b * world * steps / dt, "ms_per_step": dt / steps * 1e3, "final_loss": float(loss.detach())}
+    dt = max(tmax(time.perf_counter() - t0), 1e-9)
+    res = {"train_ips": b * world * steps / dt, "ms_per_step": dt / max(steps, 1) * 1e3, "final_loss": float(loss.detach())}
     if rank == 0:
         log("[%s] train: %.2f images/s (%.1f ms/step)" % (dtype_name, res["train_ips"], res["ms_per_step"]))
 
@@ -294,9 +299,12 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
         selector.get_vote_entropy_for_images(model, warm, 1, steps=args.mc_steps)
         barrier()
         t0 = time.perf_counter()
-        selected = selector.get_vote_entropy_for_images(model, pool_keys, max(1, len(pool_keys) // 8), steps=args.mc_steps)
+        if args.only == "coreset":
+            selected = []
+        else:
+            selected = selector.get_vote_entropy_for_images(model, pool_keys, max(1, len(pool_keys) // 8), steps=args.mc_steps)
         barrier()
-        dts = tmax(time.perf_counter() - t0)
+        dts = max(tmax(time.perf_counter() - t0), 1e-9)
         pool_ips = len(pool_keys) / dts
         if rank == 0:
             log("[%s] mc-dropout T=%d: %.2f pool images/s (%d images)" % (dtype_name, args.mc_steps, pool_ips, len(pool_keys)))
@@ -309,7 +317,7 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
                      "sharding": "contiguous key shards per rank + RCCL all_gather of per-image scores" if world > 1 else "single rank"}
 
         # -------------------------------------------------------------- config E: core-set features + k-center greedy
-        if not args.no_coreset:
+        if not args.no_coreset and args.only != "mc":
             from active_selection.core_set import ActiveSelectionCoreSet
             from dass_hip.dist import ModuleWrapper
 
