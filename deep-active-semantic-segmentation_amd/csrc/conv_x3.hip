@@ -1169,19 +1169,23 @@ __global__ __launch_bounds__(64) void dropout_compact_kernel(const float *__rest
 template <int NP>
 __global__ __launch_bounds__(256) void split3_rows_packed_kernel(const float *__restrict__ x, long ld, char *__restrict__ out, long M, int C,
                                                                  int CC, const float *__restrict__ mask, const int *__restrict__ order,
-                                                                 const int *__restrict__ cc_limit, long rows_per_image, int chunks) {
+                                                                 const int *__restrict__ cc_limit, long rows_per_image, int chunks,
+                                                                 const float *__restrict__ bound_src, float bound_mul) {
     constexpr int SB = NP * 64;
     const int n = blockIdx.x / chunks, chunk = blockIdx.x - n * chunks;
     const int upr = CC * 4, unit = threadIdx.x % upr, rstep = blockDim.x / upr;
     const int cc = unit >> 2, oct = unit & 3;
-    float scale = 1.f;  // NP = 2: from the bound dass_absmax_rows left in the trailer
-    if constexpr (NP == 2) scale = x3_scale_of(__uint_as_float(*reinterpret_cast<const unsigned *>(out + (M + 1) * CC * SB + 4)));
-    if ((long)n * rows_per_image >= M) {  // the extra block: the zero row (+ the trailer's inverse scale)
+    // NP = 2: the scale from *bound_src * bound_mul (dass_absmax_rows of x * mask, or max |x| of the UNMASKED tensor -- the same for
+    // all T passes of a scoring batch -- times the largest mask multiplier)
+    float scale = 1.f, bound = 0.f;
+    if constexpr (NP == 2) {
+        bound = bound_src[0] * bound_mul;
+        scale = x3_scale_of(bound);
+    }
+    if ((long)n * rows_per_image >= M) {  // the extra block: the zero row (+ the trailer)
         for (int i = threadIdx.x; i < CC * NP * 4; i += blockDim.x) *reinterpret_cast<uint4 *>(out + M * CC * SB + i * 16) = make_uint4(0u, 0u, 0u, 0u);
-        if (threadIdx.x == 0) {
-            *reinterpret_cast<float *>(out + (M + 1) * CC * SB) = x3_inv_of(scale);
-            if constexpr (NP == 2) *reinterpret_cast<unsigned *>(out + (M + 1) * CC * SB + 8) = *reinterpret_cast<const unsigned *>(out + (M + 1) * CC * SB + 4);
-        }
+        if (threadIdx.x == 0)
+            *reinterpret_cast<uint4 *>(out + (M + 1) * CC * SB) = make_uint4(__float_as_uint(x3_inv_of(scale)), __float_as_uint(bound), __float_as_uint(bound), 0u);
         return;
     }
     if (threadIdx.x >= upr * rstep || cc >= cc_limit[n]) return;
@@ -1266,8 +1270,8 @@ extern "C" int dass_dropout_compact(const float *mask, int N, int C, int *order,
     return DASS_OK;
 }
 
-extern "C" int dass_split3_rows_packed(const float *x, int64_t ld, void *out, int64_t M, int C, const float *mask, const int *order,
-                                       const int *cc_limit, int64_t rows_per_image, void *stream) {
+static int split_packed_impl(const float *x, int64_t ld, void *out, int64_t M, int C, const float *mask, const int *order,
+                             const int *cc_limit, int64_t rows_per_image, const float *bound, float bound_mul, void *stream) {
     if (!x || !out || !mask || !order || !cc_limit || M <= 0 || C <= 0 || ld < C || rows_per_image <= 0) return DASS_ERR_ARG;
     if (((uintptr_t)out & 15) || M % rows_per_image) return DASS_ERR_ARG;
     const int CC = (C + 31) / 32;
@@ -1280,17 +1284,34 @@ extern "C" int dass_split3_rows_packed(const float *x, int64_t ld, void *out, in
     if (g_x3_parts == 2) {
         if ((ld & 3) || (C & 3) || ((uintptr_t)x & 15)) return DASS_ERR_ARG;
         char *tr = (char *)out + x3_trailer_off(M, CC, 2);
-        if (hipMemsetAsync(tr, 0, 16, st) != hipSuccess) return DASS_ERR_LAUNCH;
-        const int rc = dass_absmax_rows(x, ld, M, C, mask, rows_per_image, (float *)(tr + 4), stream);
-        if (rc != DASS_OK) return rc;
+        if (!bound) {  // no bound supplied: max |x * mask| by one more pass over the tensor
+            if (hipMemsetAsync(tr, 0, 16, st) != hipSuccess) return DASS_ERR_LAUNCH;
+            const int rc = dass_absmax_rows(x, ld, M, C, mask, rows_per_image, (float *)(tr + 4), stream);
+            if (rc != DASS_OK) return rc;
+            bound = (const float *)(tr + 4);
+            bound_mul = 1.f;
+        }
         hipLaunchKernelGGL(split3_rows_packed_kernel<2>, dim3((unsigned)(images * chunks + 1)), dim3(256), 0, st, x, (long)ld, (char *)out, (long)M,
-                           C, CC, mask, order, cc_limit, (long)rows_per_image, (int)chunks);
+                           C, CC, mask, order, cc_limit, (long)rows_per_image, (int)chunks, bound, bound_mul);
     } else {
         hipLaunchKernelGGL(split3_rows_packed_kernel<3>, dim3((unsigned)(images * chunks + 1)), dim3(256), 0, st, x, (long)ld, (char *)out, (long)M,
-                           C, CC, mask, order, cc_limit, (long)rows_per_image, (int)chunks);
+                           C, CC, mask, order, cc_limit, (long)rows_per_image, (int)chunks, (const float *)nullptr, 1.f);
     }
     DASS_LAUNCH_CHECK();
     return DASS_OK;
+}
+
+extern "C" int dass_split3_rows_packed(const float *x, int64_t ld, void *out, int64_t M, int C, const float *mask, const int *order,
+                                       const int *cc_limit, int64_t rows_per_image, void *stream) {
+    return split_packed_impl(x, ld, out, M, C, mask, order, cc_limit, rows_per_image, nullptr, 1.f, stream);
+}
+
+/* the same with the tensor's bound supplied: *bound * bound_mul >= max |x * mask| (two-part format; e.g. max |x| of the unmasked
+ * tensor, computed once for all T passes of a scoring batch, times the largest Dropout2d multiplier) -- no pass over x for it */
+extern "C" int dass_split3_rows_packed_bound(const float *x, int64_t ld, void *out, int64_t M, int C, const float *mask, const int *order,
+                                             const int *cc_limit, int64_t rows_per_image, const float *bound, float bound_mul, void *stream) {
+    if (!bound || !(bound_mul > 0.f)) return DASS_ERR_ARG;
+    return split_packed_impl(x, ld, out, M, C, mask, order, cc_limit, rows_per_image, bound, bound_mul, stream);
 }
 
 extern "C" int dass_w3_pack_per_image(const void *w3, void *out, int64_t rows, int C, int N, const int *order, const int *cc_limit,

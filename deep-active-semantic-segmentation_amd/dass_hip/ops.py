@@ -286,12 +286,24 @@ def dropout_pack(mask):
     return order, lim
 
 
-def split3_rows_packed(x, ld, m, c, mask, order, lim, rows_per_image):
-    """x3 rows of the surviving channels (packed per image, multiplied by the mask); slabs beyond lim[n] stay unwritten"""
+def split3_rows_packed(x, ld, m, c, mask, order, lim, rows_per_image, bound=None, bound_mul=1.0):
+    """x3 rows of the surviving channels (packed per image, multiplied by the mask); slabs beyond lim[n] stay unwritten.
+    bound (two-part format): device float with *bound * bound_mul >= max |x * mask| -- saves the pass that would find it"""
     out = x3_alloc(m, c, x.device)
-    check(lib.dass_split3_rows_packed(_p(x), ld, _p(out), m, c, _p(mask), _p(order), _p(lim), rows_per_image, _stream()),
-          "dass_split3_rows_packed")
+    if bound is not None and x3_parts() == 2:
+        check(lib.dass_split3_rows_packed_bound(_p(x), ld, _p(out), m, c, _p(mask), _p(order), _p(lim), rows_per_image, _p(bound),
+                                                float(bound_mul), _stream()), "dass_split3_rows_packed_bound")
+    else:
+        check(lib.dass_split3_rows_packed(_p(x), ld, _p(out), m, c, _p(mask), _p(order), _p(lim), rows_per_image, _stream()),
+              "dass_split3_rows_packed")
     return out
+
+
+def absmax_rows(x, ld, m, c):
+    """device float [1] = max |x| over rows (dass_absmax_rows)"""
+    b = torch.zeros((1,), dtype=torch.float32, device=x.device)
+    check(lib.dass_absmax_rows(_p(x), ld, m, c, None, 1, _p(b), _stream()), "dass_absmax_rows")
+    return b
 
 
 def w3_pack_per_image(w3, rows, c, order, lim):

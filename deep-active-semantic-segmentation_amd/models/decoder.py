@@ -87,7 +87,10 @@ class Decoder(nn.Module):
                                y_amax=yb_amax)
         else:
             ops.conv_launch(xb, ldb, wb, yb, 256, (n, h, w, 48, h, w, 256, 3, 3, 1, 1, 1), scale=st.scale)
-        return wa, st, yb, la, yb_amax
+        # max |xa| of the 256 masked channels BEFORE masking: with the largest Dropout2d multiplier it bounds every pass's operand
+        xa, lda = ops.rows(feats[:, :256])
+        xa_amax = ops.absmax_rows(xa, lda, n * h * w, 256) if la is not None else None
+        return wa, st, yb, la, yb_amax, xa_amax
 
     def head_mc_pack(self, prep, masks1):
         """the Dropout2d-sparse operands of ALL T passes in two launches: masks1 [T, N, 256] -> per pass (order, limit,
@@ -98,18 +101,20 @@ class Decoder(nn.Module):
         t, n, c = masks1.shape
         order, lim = ops.dropout_pack(masks1.reshape(t * n, c))
         if ops.x3_parts() == 2:  # every operand ends in its own trailer (the weights' scale): one buffer per pass
+            # one bound for the masked operand of ALL T passes: max |xa| (head_mc_prepare) x the largest mask multiplier, on the device
+            bnd = (prep[5] * masks1.amax()).reshape(1) if prep[5] is not None else None
             return [(order[i * n:(i + 1) * n], lim[i * n:(i + 1) * n],
-                     ops.w3_pack_per_image(wa, 256 * 9, 256, order[i * n:(i + 1) * n], lim[i * n:(i + 1) * n])) for i in range(t)]
+                     ops.w3_pack_per_image(wa, 256 * 9, 256, order[i * n:(i + 1) * n], lim[i * n:(i + 1) * n]), bnd) for i in range(t)]
         wan = ops.w3_pack_per_image(wa, 256 * 9, 256, order, lim)
         per = (wan.numel() - 16) // t
-        return [(order[i * n:(i + 1) * n], lim[i * n:(i + 1) * n], wan[i * per:(i + 1) * per]) for i in range(t)]
+        return [(order[i * n:(i + 1) * n], lim[i * n:(i + 1) * n], wan[i * per:(i + 1) * per], None) for i in range(t)]
 
     def head_mc_pass(self, feats, prep, m1, m2, packed=None):
         """one stochastic pass of last_conv: masks m1 (ASPP Dropout2d, [N,256]) and m2 (last_conv[6]) folded into loaders;
         packed: this pass's entry of head_mc_pack (else the operands are packed here)"""
         import torch
 
-        wa, st, yb, la, yb_amax = prep
+        wa, st, yb, la, yb_amax, xa_amax = prep
         n, c, h, w = feats.shape
         lc = self.last_conv
         xa, lda = ops.rows(feats[:, :256])
@@ -132,12 +137,13 @@ class Decoder(nn.Module):
                     ops.x3_prepare_out(h1_3, m, 256, la, st.scale, st.shift, xa3, m, 256, ops._p(yb_amax), ops.ACT_RELU)
 
             if ops.mc_sparse():
+                bnd = None
                 if packed is not None:
-                    order, lim, wan = packed
+                    order, lim, wan, bnd = packed
                 else:
                     order, lim = ops.dropout_pack(m1)
                     wan = ops.w3_pack_per_image(wa, 256 * 9, 256, order, lim)
-                xa3 = ops.split3_rows_packed(xa, lda, m, 256, m1, order, lim, h * w)
+                xa3 = ops.split3_rows_packed(xa, lda, m, 256, m1, order, lim, h * w, bound=bnd)
                 prepare(xa3)
                 ops.conv_x3_per_image_launch(xa3, wan, lim, h1, 256, dims, y3=h1_3, scale=st.scale, shift=st.shift, residual=yb,
                                              ldr=256, act=ops.ACT_RELU)

@@ -432,6 +432,9 @@ int dass_conv2d_x3(const void *x3, const void *w3, void *y, int64_t ldy, void *y
 int dass_dropout_compact(const float *mask, int N, int C, int *order, int *cc_limit, void *stream);
 int dass_split3_rows_packed(const float *x, int64_t ld, void *out, int64_t M, int C, const float *mask, const int *order,
                             const int *cc_limit, int64_t rows_per_image, void *stream);
+/* the same with the bound of the two-part format supplied by the caller: *bound * bound_mul >= max |x * mask| (no pass over x) */
+int dass_split3_rows_packed_bound(const float *x, int64_t ld, void *out, int64_t M, int C, const float *mask, const int *order,
+                                  const int *cc_limit, int64_t rows_per_image, const float *bound, float bound_mul, void *stream);
 int dass_w3_pack_per_image(const void *w3, void *out, int64_t rows, int C, int N, const int *order, const int *cc_limit,
                            void *stream);
 int dass_conv2d_x3_per_image(const void *x3, const void *w3, const int *cc_limit, void *y, int64_t ldy, void *y3,
