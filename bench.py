@@ -129,6 +129,46 @@ def r101_conv_layers(batch, size):
             (1, b, s4, s4, 256, 48, 1, 1, 0, 1), (1, b, s4, s4, 304, 256, 3, 1, 1, 1), (1, b, s4, s4, 256, 256, 3, 1, 1, 1)]
 
 
+def mobilenet_train_bytes(batch, size, classes):
+    """ALGORITHMIC HBM bytes of one DeepLab-MobileNetV2 (os16) train step in f32 -- the network is bandwidth-bound (SURVEY.md 8a/8d:
+    5 of 61 layers MFMA-bound): every conv reads its input and writes its output once per pass (forward, input gradient, weight
+    gradient: 3 x (E_in + E_out) x 4 B) and every train-mode BN moves its tensor four more times (statistics / apply, reduce /
+    apply backward: SURVEY 8d "BN train traffic 2 x (2 x elems)").  -> (bytes, conv elements in + out, BN elements)"""
+    def o(h, k, s, p, d):
+        return (h + 2 * p - d * (k - 1) - 1) // s + 1
+    h = o(size, 3, 2, 1, 1)
+    conv_e = batch * (3 * size * size + 32 * h * h)
+    bn_e = batch * 32 * h * h
+    cin, cur, rate = 32, 2, 1
+    low_h = None
+    for t, c, n, s_ in [(1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1)]:
+        if cur == 16:
+            stride, dil = 1, rate
+            rate *= s_
+        else:
+            stride, dil = s_, 1
+            cur *= s_
+        for i in range(n):
+            st = stride if i == 0 else 1
+            hid = cin * t
+            hp = h + 2 * dil  # fixed_padding before the expand conv (mobilenet.py:70-77)
+            if t != 1:
+                conv_e += batch * (cin * hp * hp + hid * hp * hp)
+                bn_e += batch * hid * hp * hp
+            ho = o(hp, 3, st, 0, dil)
+            conv_e += batch * (hid * hp * hp + hid * ho * ho) + batch * (hid * ho * ho + c * ho * ho)
+            bn_e += batch * (hid + c) * ho * ho
+            cin, h = c, ho
+        if c == 24:
+            low_h = h
+    # ASPP (320 -> 256 x4, image pool, merge 1280 -> 256) and decoder (24 -> 48, 304 -> 256, 256 -> 256, 256 -> classes)
+    conv_e += 4 * batch * (320 + 256) * h * h + batch * (1280 + 256) * h * h
+    bn_e += 5 * batch * 256 * h * h
+    conv_e += batch * (24 + 48) * low_h * low_h + batch * (304 + 256) * low_h * low_h + batch * 512 * low_h * low_h + batch * (256 + classes) * low_h * low_h
+    bn_e += batch * (48 + 512) * low_h * low_h
+    return 3 * conv_e * 4 + 4 * bn_e * 4, conv_e, bn_e
+
+
 def conv_aggregate(args, ops, tdt):
     """times forward, input-gradient and weight-gradient launch of every conv layer shape of the train step through the
     C-ABI (events on the launch stream, 5 reps) and weights them by their count: the time-weighted conv roofline"""
@@ -137,6 +177,7 @@ def conv_aggregate(args, ops, tdt):
     dev = "cuda"
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
     gflop = 0.0
+    group = []
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def timeit(fn, reps=5):
@@ -183,7 +224,12 @@ def conv_aggregate(args, ops, tdt):
         else:
             tot["dgrad"] += cnt * timeit(lambda: check(lib.dass_conv2d_igemm(ops._p(dy), k, ops._p(wop_t), ops._p(dx), c, None, None, None, 0, None,
                                                                             n, oh, ow, k, h, w, c, ks, ks, 1, pad_t, dil, st, 0, ops._cdt(dx), stream), "dgrad"))
-        if x3_wg:
+        if x3_wg and ops.deferred_wgrad():
+            # the train step computes these in ONE grouped launch per tile class at the end of backward: collect, time below
+            x3w, dy3w = ops.split3_rows(x, c, n * h * w, c), ops.split3_rows(dy, k, n * oh * ow, k)
+            for _ in range(cnt):
+                group.append((x3w, dy3w, torch.zeros((k, ks, ks, c), device=dev), (n, h, w, c, oh, ow, k, ks, ks, st, pad, dil)))
+        elif x3_wg:
             x3w, dy3w = ops.split3_rows(x, c, n * h * w, c), ops.split3_rows(dy, k, n * oh * ow, k)
             tot["wgrad"] += cnt * timeit(lambda: check(lib.dass_conv2d_wgrad_x3(ops._p(x3w), ops._p(dy3w), ops._p(dw), n, h, w, c, oh, ow, k, ks, ks,
                                                                                st, pad, dil, 1, stream), "wgrad_x3"))
@@ -192,6 +238,19 @@ def conv_aggregate(args, ops, tdt):
             tot["wgrad"] += cnt * timeit(lambda: check(lib.dass_conv2d_wgrad(ops._p(x), c, ops._p(dy), k, ops._p(dw), n, h, w, c, oh, ow, k, ks, ks,
                                                                             st, pad, dil, ops._cdt(dy), stream), "wgrad"))
         gflop += cnt * 2.0 * n * oh * ow * k * ks * ks * c / 1e9
+    if group:
+        import ctypes
+
+        import numpy as np
+
+        items = np.zeros((len(group), 16), dtype=np.int64)
+        for i, (x3w, dy3w, dwg, dims) in enumerate(group):
+            items[i, :3] = (x3w.data_ptr(), dy3w.data_ptr(), dwg.data_ptr())
+            items[i, 3:15] = dims
+        scratch = torch.empty((lib.dass_conv2d_wgrad_x3_group_scratch_bytes(len(group)) + 128,), dtype=torch.uint8, device=dev)
+        tot["wgrad"] += timeit(lambda: check(lib.dass_conv2d_wgrad_x3_group(items.ctypes.data_as(ctypes.c_void_p), len(group), ops._p(scratch),
+                                                                           scratch.numel(), ops._stream()), "wgrad_x3_group"))
+        del group[:]
     ms = tot["fwd"] + tot["dgrad"] + tot["wgrad"]
     return {"ms_per_step": round(ms, 3), "fwd_ms": round(tot["fwd"], 3), "dgrad_ms": round(tot["dgrad"], 3), "wgrad_ms": round(tot["wgrad"], 3),
             "gflop": round(3 * gflop, 1), "achieved": round(3 * gflop / ms, 2)}
@@ -356,7 +415,15 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
     b = args.batch  # (the scoring legs may have used --mc-batch)
     # ------------------------------------------------------------------ roofline of the dominant kernel
     res["roofline"] = None
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and args.backbone == "mobilenet":
+        nbytes, conv_e, bn_e = mobilenet_train_bytes(b, s, args.classes)
+        gbs = nbytes / (res["ms_per_step"] * 1e-3) / 1e9
+        res["roofline"] = {"bound": "hbm", "kernel": "whole train step (61 conv layers: depthwise 3x3, pointwise 1x1, BN passes)", "achieved": round(gbs, 1),
+                           "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": None,
+                           "algorithmic_bytes_per_step": nbytes,
+                           "note": "f32 tensors; 3 x (in + out) x 4 B per conv layer and pass + 4 BN passes per train-mode BN tensor (SURVEY 8d); "
+                                   "per-family kernel times: profiles/r03_train_C_mbv2_summary.md"}
+    elif rank == 0 and not args.no_roofline:
         tdt = torch.bfloat16 if engine == "bf16" else torch.float32
         n_, h_, c_, k_ = b, (s + 3) // 4, 304, 256  # decoder.last_conv.0: 3x3 304->256 @129^2, the largest single layer
         x = torch.randn((n_, h_, h_, c_), device=dev).to(tdt)
@@ -386,13 +453,15 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
         peak = round(MFMA_PEAK_TFLOPS[engine], 1)
         log("[%s] dominant conv kernel: %.3f ms/launch = %.1f TFLOP/s" % (dtype_name, ms, achieved))
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r02_traffic_x3.json" if x3_best else "r01_traffic_%s.json" % engine)
+        tfile = os.path.join(ROOT, "profiles", ("r03_traffic_x3_f16.json" if engine == "f16x3" else "r02_traffic_x3.json") if x3_best
+                             else "r01_traffic_%s.json" % engine)
         if os.path.exists(tfile):  # HBM bytes per launch from the rocprofv3 --pmc passes (collected offline, see profiles/)
             traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
         kname = {"f32": "float,128,128,2,2", "bf16": "bf16,128,128,2,2", "bf16x6": "float,128,128,4,1,split=3",
                  "bf16x3": "float,128,128,2,2,split=2", "f16x3": "float,128,128,4,1,split=3"}[engine]
         if x3_best:
-            kname_full = "conv_x3_kernel<256,128,4,2,2> + fix-up, pre-split operands (3x3 304->256 @%dx%d, batch %d)" % (h_, h_, n_)
+            kname_full = "conv_x3_kernel<256,128,4,2,2,%s> + fix-up, pre-split operands (3x3 304->256 @%dx%d, batch %d)" % (
+                "NP=2: two f16 parts" if engine == "f16x3" else "NP=3: three bf16 parts", h_, h_, n_)
         else:
             kname_full = "conv_igemm_kernel<%s> (3x3 304->256 @%dx%d, batch %d)" % (kname, h_, h_, n_)
         best = {"kernel": kname_full, "achieved": round(achieved, 2),
