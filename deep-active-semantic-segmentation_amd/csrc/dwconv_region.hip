@@ -12,15 +12,15 @@ template <typename T>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(const T *__restrict__ x, long ldx, const float *__restrict__ w,
                                                      T *__restrict__ y, long ldy, int N, int H, int W, int C, int OH,
                                                      int OW, int stride, int pad, int dil) {
+    // one output ROW (n, oh) per blockIdx.y (grid-strided), threads over (ow, 4-channel group): no 64-bit index arithmetic per element
     const int cv = C >> 2;
-    const long total = (long)N * OH * OW * cv;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cv) << 2;
-        long t = i / cv;
-        const int ow = (int)(t % OW);
-        t /= OW;
-        const int oh = (int)(t % OH);
-        const long n = t / OH;
+    const int row_items = OW * cv;
+    for (long row = blockIdx.y; row < (long)N * OH; row += gridDim.y) {
+      const long n = row / OH;
+      const int oh = (int)(row - n * OH);
+      for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < row_items; j += gridDim.x * blockDim.x) {
+        const int ow = j / cv;
+        const int c = (j - ow * cv) << 2;
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const T *__restrict__ x, lo
             }
         }
         st4<T>(y + ((n * OH + oh) * OW + ow) * ldy + c, a);
+      }
     }
 }
 
@@ -48,14 +49,13 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const T *__restrict__ 
                                                           int N, int H, int W, int C, int OH, int OW, int stride,
                                                           int pad, int dil) {
     const int cv = C >> 2;
-    const long total = (long)N * H * W * cv;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cv) << 2;
-        long t = i / cv;
-        const int ix = (int)(t % W);
-        t /= W;
-        const int iy = (int)(t % H);
-        const long n = t / H;
+    const int row_items = W * cv;
+    for (long row = blockIdx.y; row < (long)N * H; row += gridDim.y) {
+      const long n = row / H;
+      const int iy = (int)(row - n * H);
+      for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < row_items; j += gridDim.x * blockDim.x) {
+        const int ix = j / cv;
+        const int c = (j - ix * cv) << 2;
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -78,52 +78,73 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const T *__restrict__ 
             }
         }
         st4<T>(dx + ((n * H + iy) * W + ix) * lddx + c, a);
+      }
     }
 }
 
-// grid (C/64, pixel slabs); thread = (channel c of 64, pixel lane of 4); 9 accumulators per thread
+// grid (C/64, pixel slabs); thread = (4-channel group cq of 16, pixel lane pl of 16): 9 taps x 4 channels of accumulators, 16-B
+// loads (16 lanes = 256 contiguous bytes of one pixel), the (n, oh, ow) cursor advanced by adds -- the round-1 kernel loaded
+// single floats and paid two 64-bit divisions per pixel (0.44 TB/s of algorithmic traffic in the config-C profile; this: see
+// profiles/r03_train_C_mbv2_summary.md)
 template <typename T>
 __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const T *__restrict__ x, long ldx,
                                                             const T *__restrict__ dy, long lddy,
                                                             float *__restrict__ dw, int N, int H, int W, int C,
                                                             int OH, int OW, int stride, int pad, int dil,
                                                             long pix_per_block) {
-    __shared__ float red[4][9][64];
-    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ float red[16][9][64 + 4];
+    const int cq = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cq * 4;
     const long M = (long)N * OH * OW;
     const long p0 = (long)blockIdx.y * pix_per_block;
     long p1 = p0 + pix_per_block;
     if (p1 > M) p1 = M;
-    float a[9];
+    f32x4 a[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) a[t] = 0.f;
+    for (int t = 0; t < 9; ++t) a[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (c < C) {
         const long ohw = (long)OH * OW;
-        for (long p = p0 + pl; p < p1; p += 4) {
-            const long n = p / ohw;
-            const long rem = p - n * ohw;
-            const int oh = (int)(rem / OW), ow = (int)(rem - (long)oh * OW);
-            const float g = Elem<T>::ld(dy + p * lddy + c);
+        long p = p0 + pl;
+        long n = p / ohw;
+        const long rem = p - n * ohw;
+        int oh = (int)(rem / OW), ow = (int)(rem - (long)oh * OW);
+        for (; p < p1; p += 16) {
+            const f32x4 g = ld4<T>(dy + p * lddy + c);
+            const T *xn = x + n * H * W * ldx + c;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 const int iy = oh * stride - pad + r * dil;
                 if (iy < 0 || iy >= H) continue;
 #pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    const int ix = ow * stride - pad + s * dil;
+                for (int s2 = 0; s2 < 3; ++s2) {
+                    const int ix = ow * stride - pad + s2 * dil;
                     if (ix < 0 || ix >= W) continue;
-                    a[r * 3 + s] += g * Elem<T>::ld(x + ((n * H + iy) * W + ix) * ldx + c);
+                    a[r * 3 + s2] += g * ld4<T>(xn + ((long)iy * W + ix) * ldx);
+                }
+            }
+            ow += 16;
+            while (ow >= OW) {
+                ow -= OW;
+                if (++oh >= OH) {
+                    oh = 0;
+                    ++n;
                 }
             }
         }
     }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) red[pl][t][cl] = a[t];
-    __syncthreads();
-    if (pl == 0 && c < C) {
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) atomicAdd(dw + (long)c * 9 + t, red[0][t][cl] + red[1][t][cl] + red[2][t][cl] + red[3][t][cl]);
+        for (int e = 0; e < 4; ++e) red[pl][t][cq * 4 + e] = a[t][e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * 64; i += 256) {
+        const int t = i >> 6, cl = i & 63;
+        const int cc = blockIdx.x * 64 + cl;
+        if (cc >= C) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v += red[q][t][cl];
+        atomicAdd(dw + (long)cc * 9 + t, v);
     }
 }
 
@@ -367,12 +388,14 @@ extern "C" int dass_dwconv3x3_fwd(const void *x, int64_t ldx, const float *w, vo
     const void *x_ = x;
     const void *y_ = y;
     if (!DW_ARGS_OK || !w || ldx % 4 || ldy % 4) return DASS_ERR_ARG;
-    const int grid = dass_grid_1d((long)N * OH * OW * (C / 4), 256);
+    const int gx = (OW * (C / 4) + 255) / 256;
+    const long rows_ = (long)N * OH;
+    const dim3 grid((unsigned)(gx < 1024 ? gx : 1024), (unsigned)(rows_ < 8192 ? rows_ : 8192));  // (ow, channel group) x output rows
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DASS_F32)
-        hipLaunchKernelGGL(dw_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, ldx, w, (float *)y, ldy, N, H, W, C, OH, OW, stride, pad, dil);
+        hipLaunchKernelGGL(dw_fwd_kernel<float>, grid, dim3(256), 0, st, (const float *)x, ldx, w, (float *)y, ldy, N, H, W, C, OH, OW, stride, pad, dil);
     else if (dtype == DASS_BF16)
-        hipLaunchKernelGGL(dw_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)x, ldx, w, (bf16_t *)y, ldy, N, H, W, C, OH, OW, stride, pad, dil);
+        hipLaunchKernelGGL(dw_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)x, ldx, w, (bf16_t *)y, ldy, N, H, W, C, OH, OW, stride, pad, dil);
     else
         return DASS_ERR_UNSUPPORTED;
     DASS_LAUNCH_CHECK();
@@ -385,12 +408,14 @@ extern "C" int dass_dwconv3x3_bwd_data(const void *dy, int64_t lddy, const float
     const void *x_ = dy;
     const void *y_ = dx;
     if (!DW_ARGS_OK || !w || lddx % 4 || lddy % 4) return DASS_ERR_ARG;
-    const int grid = dass_grid_1d((long)N * H * W * (C / 4), 256);
+    const int gx = (W * (C / 4) + 255) / 256;
+    const long rows_ = (long)N * H;
+    const dim3 grid((unsigned)(gx < 1024 ? gx : 1024), (unsigned)(rows_ < 8192 ? rows_ : 8192));  // (ix, channel group) x input rows
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DASS_F32)
-        hipLaunchKernelGGL(dw_bwd_data_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)dy, lddy, w, (float *)dx, lddx, N, H, W, C, OH, OW, stride, pad, dil);
+        hipLaunchKernelGGL(dw_bwd_data_kernel<float>, grid, dim3(256), 0, st, (const float *)dy, lddy, w, (float *)dx, lddx, N, H, W, C, OH, OW, stride, pad, dil);
     else if (dtype == DASS_BF16)
-        hipLaunchKernelGGL(dw_bwd_data_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)dy, lddy, w, (bf16_t *)dx, lddx, N, H, W, C, OH, OW, stride, pad, dil);
+        hipLaunchKernelGGL(dw_bwd_data_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)dy, lddy, w, (bf16_t *)dx, lddx, N, H, W, C, OH, OW, stride, pad, dil);
     else
         return DASS_ERR_UNSUPPORTED;
     DASS_LAUNCH_CHECK();
@@ -402,7 +427,7 @@ extern "C" int dass_dwconv3x3_bwd_weight(const void *x, int64_t ldx, const void 
                                          void *stream) {
     const void *x_ = x;
     const void *y_ = dy;
-    if (!DW_ARGS_OK || !dw) return DASS_ERR_ARG;
+    if (!DW_ARGS_OK || !dw || ldx % 4 || lddy % 4) return DASS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)C * 9, st) != hipSuccess) return DASS_ERR_LAUNCH;
     const long M = (long)N * OH * OW;
