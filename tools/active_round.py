@@ -116,17 +116,23 @@ def main():
                 dist.broadcast(b, src=0)
 
     constants.MC_STEPS = args.mc_steps
+    score_log = []
     if args.mode == "mc_dropout":
         selector = ActiveSelectionMCDropout(args.classes, None, args.size, args.batch, loader_factory=loader_factory)
         pick = lambda cand, k: list(selector.get_vote_entropy_for_images(model, cand, k))  # noqa: E731
     elif args.mode == "ceal_entropy":
         selector = ActiveSelectionCEAL(args.classes, None, args.size, args.batch, loader_factory=loader_factory)
-        pick = lambda cand, k: list(selector.get_maximum_entropy_samples(model, cand, k)[0])  # noqa: E731
+
+        def pick(cand, k):
+            chosen, entropies = selector.get_maximum_entropy_samples(model, cand, k)
+            score_log.append([round(float(e), 7) for e in entropies])   # (this selector returns its scores: kept for the tests)
+            return list(chosen)
     else:
         selector = ActiveSelectionCoreSet(None, args.size, args.batch, loader_factory=loader_factory)
         pick = lambda cand, k: selector.get_k_center_greedy_selections(k, model, cand, list(labelled))  # noqa: E731
 
     history, losses, t0 = [], [], time.perf_counter()
+    score_log.clear()
     for rnd in range(args.rounds):
         # ---- train: every step consumes a GLOBAL batch of world * batch labelled keys; rank r takes its slice
         model.train()
@@ -163,7 +169,7 @@ def main():
     for p in core.parameters():
         h.update(p.detach().float().cpu().numpy().tobytes())
     out = {"rank": rank, "world": world, "mode": args.mode, "sync_bn": bool(args.sync_bn), "selections": history,
-           "labelled": len(labelled), "losses": [round(v, 6) for v in losses], "param_sha256": h.hexdigest(), "seconds": round(dt, 3)}
+           "labelled": len(labelled), "losses": [round(v, 6) for v in losses], "scores": score_log, "param_sha256": h.hexdigest(), "seconds": round(dt, 3)}
     dump = os.environ.get("DASS_ROUND_DUMP")
     if dump:
         with open(os.path.join(dump, "rank%d.json" % rank), "w") as f:
