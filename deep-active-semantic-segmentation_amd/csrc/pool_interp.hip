@@ -49,6 +49,27 @@ __global__ void copy_channels_kernel(const T *__restrict__ src, long lds, T *__r
     }
 }
 
+// dst = sum of up to 8 row tensors (each with its own pixel stride): the gradients of a tensor with several consumers, added in
+// ONE pass (autograd would run n - 1 two-operand adds over the whole tensor)
+struct SumPack {
+    const void *src[8];
+    long ld[8];
+    int n;
+};
+template <typename T> __global__ void sum_n_kernel(SumPack p, T *__restrict__ dst, long ldd, long M, int C) {
+    const int cv = C >> 2;
+    const long total = M * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / cv;
+        const int c = (int)(i - m * cv) << 2;
+        f32x4 v = ld4<T>(reinterpret_cast<const T *>(p.src[0]) + m * p.ld[0] + c);
+#pragma unroll
+        for (int j = 1; j < 8; ++j)
+            if (j < p.n) v += ld4<T>(reinterpret_cast<const T *>(p.src[j]) + m * p.ld[j] + c);
+        st4<T>(dst + m * ldd + c, v);
+    }
+}
+
 template <typename T>
 __global__ void maxpool_fwd_kernel(const T *__restrict__ x, T *__restrict__ y, uint8_t *__restrict__ idx, int N,
                                    int H, int W, int C, int OH, int OW) {
@@ -350,6 +371,23 @@ extern "C" int dass_add_channels(const void *src, int64_t lds, void *dst, int64_
     DASS_DISPATCH(dtype,
                   hipLaunchKernelGGL((copy_channels_kernel<float, true>), dim3(grid), dim3(256), 0, st, (const float *)src, lds, (float *)dst, ldd, M, C),
                   hipLaunchKernelGGL((copy_channels_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, st, (const bf16_t *)src, lds, (bf16_t *)dst, ldd, M, C))
+}
+
+/* dst[m][c] = sum_j src_j[m][c], 2 <= n <= 8 sources given as n pointers and n pixel strides (host arrays) */
+extern "C" int dass_sum_channels(const void *const *srcs, const int64_t *lds, int n, void *dst, int64_t ldd, int64_t M, int C, int dtype,
+                                 void *stream) {
+    if (!srcs || !lds || n < 1 || n > 8 || !dst || M <= 0 || C <= 0 || C % 4 || ldd % 4) return DASS_ERR_ARG;
+    SumPack p;
+    p.n = n;
+    for (int j = 0; j < 8; ++j) {
+        p.src[j] = j < n ? srcs[j] : nullptr;
+        p.ld[j] = j < n ? lds[j] : 0;
+        if (j < n && (!srcs[j] || lds[j] % 4)) return DASS_ERR_ARG;
+    }
+    const int grid = dass_grid_1d(M * (C / 4), 256);
+    hipStream_t st = (hipStream_t)stream;
+    DASS_DISPATCH(dtype, hipLaunchKernelGGL(sum_n_kernel<float>, dim3(grid), dim3(256), 0, st, p, (float *)dst, ldd, M, C),
+                  hipLaunchKernelGGL(sum_n_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, p, (bf16_t *)dst, ldd, M, C))
 }
 
 extern "C" int dass_maxpool3x3s2_fwd(const void *x, void *y, uint8_t *idx, int N, int H, int W, int C, int OH, int OW,

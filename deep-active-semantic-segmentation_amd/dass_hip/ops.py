@@ -135,6 +135,7 @@ def _x3_train_layer(taps, red_channels):
 
 _SELECT = (int(os.environ.get("DASS_X3_SELECT_TAPS", "9")), int(os.environ.get("DASS_X3_SELECT_C", "256")))  # measured optimum
 _X3_MIN_ROWS = 256  # output rows below which a conv stays on the classic kernel
+_FANOUT = os.environ.get("DASS_FANOUT", "1") == "1"  # gradients of multi-consumer tensors summed by one library pass (0: autograd's adds)
 _SKIP_DY32 = os.environ.get("DASS_SKIP_DY32", "1") == "1"  # BN backward writes only the split rows of dy when nothing reads its f32 form
 
 
@@ -339,6 +340,8 @@ def x3_operand(t, xs, ld, m, c, nc_scale=None, rows_per_image=1):
     """x3 rows of activation `t` (xs = its NHWC row view): taken from the side buffer the producing pass attached to the
     tensor (`t._dass_x3`, valid while the tensor is unmodified) or converted now by dass_split3_rows"""
     if nc_scale is None:
+        if hasattr(t, "__dict__"):
+            t = t.__dict__.get("_dass_alias_of", t)  # (aliases handed out by fanout() share the rows of their base tensor)
         hit = t.__dict__.get("_dass_x3") if hasattr(t, "__dict__") else None
         if hit is not None and hit[0] == (t.data_ptr(), t._version, m, c, x3_parts()):
             return hit[1]
@@ -355,6 +358,8 @@ def attach_x3(t, buf, m, c):
 
 def attached_x3(t, m, c):
     """the split rows a producer attached to `t` (None when absent or stale)"""
+    if hasattr(t, "__dict__"):
+        t = t.__dict__.get("_dass_alias_of", t)
     hit = t.__dict__.get("_dass_x3") if hasattr(t, "__dict__") else None
     return hit[1] if hit is not None and hit[0] == (t.data_ptr(), t._version, m, c, x3_parts()) else None
 
@@ -1303,7 +1308,8 @@ def conv_bn_act(x, conv, bn=None, act=ACT_NONE, residual=None, nc_scale=None, ex
     if spec.fork:
         # the alias of x handed back for the identity branch is a new tensor object over the same memory: let it keep the split
         # rows (and with them the bound of max |x|) the producer attached to x
-        hit = x.__dict__.get("_dass_x3") if hasattr(x, "__dict__") else None
+        src = x.__dict__.get("_dass_alias_of", x) if hasattr(x, "__dict__") else x
+        hit = src.__dict__.get("_dass_x3") if hasattr(src, "__dict__") else None
         alias = res[1]
         if hit is not None and hit[0][:2] == (x.data_ptr(), x._version) and alias.data_ptr() == x.data_ptr():
             alias.__dict__["_dass_x3"] = ((alias.data_ptr(), alias._version) + tuple(hit[0][2:]), hit[1])
@@ -1366,6 +1372,51 @@ class _Add(torch.autograd.Function):
 
 def add(a, b):
     return _Add.apply(a, b)
+
+
+# ----------------------------------------------------------------------------- one tensor, several consumers
+class _Fanout(torch.autograd.Function):
+    """x -> n aliases of x, one per consumer (aspp.py:76-80: five branches read the backbone output; resnet.py:36-44: conv1 and
+    the downsample conv read the block input; decoder.py:41: the low-level features feed the decoder AND layer 2).  Forward is
+    free; backward adds the n gradients in ONE dass_sum_channels pass instead of autograd's n - 1 at::add launches."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = n
+        ctx.shape, ctx.dt = x.shape, x.dtype
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g for g in grads if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        rws = [rows(_cast_act(g)) for g in gs]
+        n, c, h, w = rws[0][0].shape
+        if c % 4 or any(ld % 4 for _, ld in rws) or len(gs) > 8:
+            out = gs[0]
+            for g in gs[1:]:
+                out = out + g
+            return out, None
+        dst = new_act(n, c, h, w, rws[0][0].dtype, rws[0][0].device)
+        ptrs = (ctypes.c_void_p * len(rws))(*[t.data_ptr() for t, _ in rws])
+        lds = (ctypes.c_int64 * len(rws))(*[ld for _, ld in rws])
+        check(lib.dass_sum_channels(ptrs, lds, len(rws), _p(dst), c, n * h * w, c, _dt(dst), _stream()), "dass_sum_channels")
+        return dst, None
+
+
+def fanout(x, n):
+    """n aliases of x for n consumers (gradients summed by one library pass); a no-op list when autograd is not recording.
+    Split rows attached to x, or by the first consumer that converts it, are shared by all aliases."""
+    if n <= 1 or not _FANOUT or not (torch.is_grad_enabled() and x.requires_grad):
+        return [x] * n
+    outs = _Fanout.apply(x, n)
+    base = x.__dict__.get("_dass_alias_of", x)  # (an alias of an alias points at the first tensor: one lookup finds its rows)
+    for o in outs:
+        o.__dict__["_dass_alias_of"] = base
+    return list(outs)
 
 
 # ----------------------------------------------------------------------------- concat (aspp.py:83)

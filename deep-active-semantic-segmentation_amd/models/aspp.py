@@ -64,11 +64,12 @@ class ASPP(nn.Module):
         """dropout_mask: optional explicit [N,256] multipliers (reproducible stochastic passes);
         apply_dropout=False returns the pre-dropout activation (used by the hoisted MC-dropout tail)."""
         h, w = x.shape[2], x.shape[3]
-        x1 = self.aspp1(x)
-        x2 = self.aspp2(x)
-        x3 = self.aspp3(x)
-        x4 = self.aspp4(x)
-        x5 = ops.global_avgpool(x)
+        xa, xb, xc, xd, xe = ops.fanout(x, 5)  # five consumers: their gradients are added in one pass
+        x1 = self.aspp1(xa)
+        x2 = self.aspp2(xb)
+        x3 = self.aspp3(xc)
+        x4 = self.aspp4(xd)
+        x5 = ops.global_avgpool(xe)
         x5 = ops.conv_bn_act(x5, self.global_average_pool[1], None, ops.ACT_RELU, emit_x3=False)
         x5 = ops.broadcast_bn(x5, self.bn_global_average_pool, h, w)
         cat = ops.concat(x1, x2, x3, x4, x5)

@@ -38,7 +38,9 @@ class InvertedResidual(nn.Module):
     def forward(self, x):
         d = self.dilation  # fixed_padding for k=3: d on every side
         c = self.conv
-        res = x if self.use_res_connect else None
+        res = None
+        if self.use_res_connect:
+            x, res = ops.fanout(x, 2)  # block input read by the expand conv and the skip connection: one gradient sum pass
         if self.expand:
             h = ops.conv_bn_act(x, c[0], c[1], ops.ACT_RELU6, extra_pad=d, emit_x3=False)   # 1x1 over the zero-padded input (feeds the depthwise conv)
             h = ops.conv_bn_act(h, c[3], c[4], ops.ACT_RELU6)                 # depthwise, pad 0
@@ -107,7 +109,8 @@ class MobileNetV2(nn.Module):
     @ops.bn_counter_scope
     def forward(self, x):
         low_level_feat = self._run(self.low_level_features, x, True)
-        x = self._run(self.high_level_features, low_level_feat, False)
+        low_level_feat, hi_in = ops.fanout(low_level_feat, 2)   # consumers: the decoder and the high-level features
+        x = self._run(self.high_level_features, hi_in, False)
         if self.mc_dropout:
             mask = dropout_mask_for(self.dropout, low_level_feat.shape[0], low_level_feat.shape[1], low_level_feat.device)
             if mask is not None:

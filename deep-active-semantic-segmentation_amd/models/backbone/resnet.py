@@ -28,8 +28,9 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         if self.downsample:
-            out = ops.conv_bn_act(x, self.conv1, self.bn1, ops.ACT_RELU, consumer=self.conv2)
-            residual = ops.conv_bn_act(x, self.downsample[0], self.downsample[1], ops.ACT_NONE)
+            xa, xb = ops.fanout(x, 2)
+            out = ops.conv_bn_act(xa, self.conv1, self.bn1, ops.ACT_RELU, consumer=self.conv2)
+            residual = ops.conv_bn_act(xb, self.downsample[0], self.downsample[1], ops.ACT_NONE)
         else:
             # identity block: conv1 hands x back for the skip connection, so that the skip gradient is added inside
             # conv1's input-gradient launch (no separate accumulation pass over the block input)
@@ -74,7 +75,7 @@ class ResNet(nn.Module):
         x = ops.conv_bn_act(input, self.conv1, self.bn1, ops.ACT_RELU, image_input=True, emit_x3=False)  # consumer: the max-pool
         x = ops.maxpool3x3s2(x)
         x = self.layer1(x)
-        low_level_feat = x
+        x, low_level_feat = ops.fanout(x, 2)   # consumers: layer 2 and the decoder
         x = self.layer2(x)
         x = self.layer3(x)
         x = self.layer4(x)

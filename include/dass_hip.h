@@ -260,6 +260,10 @@ int dass_nhwc_to_nchw(const void *x, int64_t ldx, float *y, int N, int C, int H,
 int dass_copy_channels(const void *src, int64_t lds, void *dst, int64_t ldd, int64_t M, int C, int dtype, void *stream);
 /* dst[m,c] += src[m,c] */
 int dass_add_channels(const void *src, int64_t lds, void *dst, int64_t ldd, int64_t M, int C, int dtype, void *stream);
+/* dst = the sum of n (1..8) row tensors, one pass: the gradients of an activation with several consumers (autograd's own
+ * accumulation would be n - 1 two-operand at::add launches); srcs / lds: host arrays of n device pointers / pixel strides */
+int dass_sum_channels(const void *const *srcs, const int64_t *lds, int n, void *dst, int64_t ldd, int64_t M, int C, int dtype,
+                      void *stream);
 /* nn.MaxPool2d(3, 2, 1) (resnet.py:68): idx = winning tap 0..8 (uint8), first max wins */
 int dass_maxpool3x3s2_fwd(const void *x, void *y, uint8_t *idx, int N, int H, int W, int C, int OH, int OW, int dtype, void *stream);
 int dass_maxpool3x3s2_bwd(const void *dy, const uint8_t *idx, void *dx, int N, int H, int W, int C, int OH, int OW, int dtype, void *stream);

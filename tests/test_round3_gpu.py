@@ -289,3 +289,30 @@ def test_fused_inference_chain_with_ragged_channel_slab(k):
         assert (y.double() - want).abs().max().item() <= 1e-4 * want.abs().max().item()
     finally:
         ops.set_f32_mma(keep)
+
+
+# ------------------------------------------------------------------------------------------- multi-consumer tensors
+@pytest.mark.parametrize("n", [2, 5, 8])
+def test_fanout_sums_consumer_gradients_in_one_pass(n):
+    """ops.fanout: n aliases of one activation (aspp.py:76-80, resnet.py:36-44); the gradient of the source is the sum of
+    the consumers' gradients, bit-equal to a left-to-right f32 sum, and aliases of aliases still find the rows attached to
+    the first tensor"""
+    ops, O, S = _setup()
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(3, 64, 9, 7, generator=g).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    outs = ops.fanout(x, n)
+    assert len(outs) == n and all(o.data_ptr() == x.data_ptr() for o in outs)
+    inner = ops.fanout(outs[0], 2)
+    assert all(o.__dict__["_dass_alias_of"] is x for o in inner)
+    xs, ld = ops.rows(x.detach())
+    m = 3 * 9 * 7
+    ops.attach_x3(x, ops.split3_rows(xs, ld, m, 64), m, 64)
+    assert ops.attached_x3(inner[1], m, 64) is ops.attached_x3(x, m, 64) is not None
+    gs = [torch.randn(3, 64, 9, 7, generator=g).cuda().contiguous(memory_format=torch.channels_last) for _ in range(n)]
+    torch.autograd.backward(outs, gs)
+    want = gs[0].clone()
+    for t in gs[1:]:
+        want = want + t
+    assert torch.equal(x.grad, want)
+    with torch.no_grad():
+        assert all(o is x for o in ops.fanout(x, 3))   # nothing to sum when autograd is not recording
