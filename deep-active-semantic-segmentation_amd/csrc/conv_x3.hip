@@ -51,7 +51,31 @@ struct X3P {
     const int *cc_limit;            // per-image mode: channel slabs of image g that hold anything (the others are skipped)
     int OHs, OWs, o_mul, oy_add, ox_add, ustride;
     unsigned long long tap_allow;
+    // filled by launch_x3 (host-side divisions the kernel's per-workgroup setup would otherwise repeat):
+    unsigned mg_ohw, mg_ows;  // magic multipliers of the divisions by OHs * OWs and by OWs (x3_fastdiv)
+    int sh_ohw, sh_ows;
+    int sk_q, sk_r;           // stream-K region: U = sk_q * sk_part + sk_r units; workgroup w owns [w q + min(w, r), ...) (q + 1 units while w < r)
+    int dp_rounds;            // dp_tiles / sk_wgs
+    int whole;                // 1: one whole tile per workgroup, nothing else (no stream-K region arithmetic at all)
 };
+
+// n / d for 0 <= n < 2^31 with the host's magic pair (x3_set_magic): mul = ceil(2^(31 + l) / d), l = ceil(log2 d), shift = l - 1
+// (Granlund-Montgomery: 2^(31+l) <= mul d <= 2^(31+l) + 2^l makes the product's high part exact); d = 1 travels as shift < 0
+__device__ __forceinline__ int x3_fastdiv(int n, unsigned mul, int shift) {
+    return shift < 0 ? n : (int)(__umulhi((unsigned)n, mul) >> shift);
+}
+static inline void x3_set_magic(int d, unsigned &mul, int &shift) {
+    if (d <= 1) {
+        mul = 0u;
+        shift = -1;
+        return;
+    }
+    int l = 0;
+    while ((1ll << l) < d) ++l;
+    mul = (unsigned)(((1ull << (31 + l)) + (unsigned long long)d - 1ull) / (unsigned long long)d);
+    shift = l - 1;
+}
+__device__ __forceinline__ int x3_sk_bound(const X3P &p, int w) { return w * p.sk_q + (w < p.sk_r ? w : p.sk_r); }
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
@@ -95,11 +119,11 @@ template <> struct Terms<3> { static constexpr int N = 6; static constexpr int P
 template <> struct Terms<2> { static constexpr int N = 3; static constexpr int PA[3] = {0, 1, 0}; static constexpr int PB[3] = {1, 0, 0}; };
 
 // fused epilogue of ONE 4-channel group of output pixel m (tile-independent: used by the main kernel and the fix-up pass)
-__device__ __forceinline__ void x3_store_out(const X3P &p, f32x4 v, int m, int k, int ohw, bool vec_ok, float y3_scale, float &vmax) {
+__device__ __forceinline__ void x3_store_out(const X3P &p, f32x4 v, int m, int k, int ohw, bool vec_ok, float y3_scale, float &vmax, bool phase) {
     float *y = reinterpret_cast<float *>(p.y);
     const float *res = reinterpret_cast<const float *>(p.res);
     long mo = m;  // output pixel index; differs from m only for a phase sub-grid
-    if (p.o_mul != 1) {
+    if (phase) {
         const int n = m / ohw, rem = m - n * ohw;
         const int ohs = rem / p.OWs;
         mo = ((long)n * p.OH + ohs * p.o_mul + p.oy_add) * p.OW + (rem - ohs * p.OWs) * p.o_mul + p.ox_add;
@@ -110,7 +134,13 @@ __device__ __forceinline__ void x3_store_out(const X3P &p, f32x4 v, int m, int k
         if (res) v += *reinterpret_cast<const f32x4 *>(res + mo * p.ldr + k);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+#if defined(X3_EXP) && X3_EXP == 10
+        if (y && v[0] == 12345.678f) *reinterpret_cast<f32x4 *>(y + mo * p.ldy + k) = v;
+#elif defined(X3_EXP) && X3_EXP == 11
+        if (y) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(y + mo * p.ldy + k));
+#else
         if (y) *reinterpret_cast<f32x4 *>(y + mo * p.ldy + k) = v;
+#endif
         if (p.y3) x3_store4r(p.y3, mo, p.cc_out, k, v, p.y3_parts, y3_scale);
 #pragma unroll
         for (int e = 0; e < 4; ++e) vmax = fmaxf(vmax, fabsf(v[e]));
@@ -150,7 +180,10 @@ __device__ __forceinline__ void x3_amax_commit(unsigned *slot, float vmax) {
 // M16: the products run on v_mfma_f32_16x16x32_bf16 (one 32-k slab per instruction) instead of v_mfma_f32_32x32x16_bf16: the
 // same FLOPs per cycle, but the chip holds a ~10 % higher clock under that shape (tools/mfma_shape_probe.py: 2.17 vs 1.97 GHz
 // with two LDS-fed waves per SIMD on all CUs; MI355X_MICROARCH.md measures 1.12-1.14 x).
-template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE, bool M16, int NP = 3>
+// SIMPLE: one whole tile per workgroup, no phase sub-grid, no per-image groups (what the host's `p.whole` launches of plain
+// convolutions are): the generality below costs ~1000 instructions of hoisted loop invariants and SGPR spills in front of the
+// first barrier (2-3 us per workgroup, tools/x3_exp.py stamps) -- more than the whole slab loop of a short reduction.
+template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE, bool M16, int NP = 3, bool SIMPLE = false>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(const X3P p) {
     constexpr int NW = WARPS_M * WARPS_N;
     constexpr int SB = NP * 64, PG = NP * 1024;  // bytes of one row-slab / of the NP 1-KiB pieces of one 16-row rowgroup
@@ -161,18 +194,28 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     static_assert((AG + BG) % NW == 0, "rowgroups must divide over the waves");
     static_assert(MT >= 1 && NT >= 1 && NSTAGE >= 2 && NSTAGE <= 4, "tile");
     constexpr int A_BYTES = AG * PG, B_BYTES = BG * PG, STAGE = A_BYTES + B_BYTES;
-    constexpr int G = RG * NP;  // DMA instructions per wave and slab
+#ifndef X3_EXP
+#define X3_EXP 0  // timing experiments (results wrong), tools/x3_exp.py
+#endif
+    constexpr int XE = X3_EXP;
+    constexpr bool XE_NO_RDB = XE == 1 || XE == 2 || XE == 3 || XE == 6 || XE == 7, XE_NO_RDA = XE == 2 || XE == 6 || XE == 7;
+    constexpr bool XE_NO_DMAB = XE == 3 || XE == 5 || XE == 6 || XE == 7, XE_NO_DMAA = XE == 4 || XE == 5 || XE == 6 || XE == 7;
+    constexpr int G = (XE_NO_DMAA && XE_NO_DMAB) ? 0 : (XE_NO_DMAA || XE_NO_DMAB) ? (RG / 2) * NP : RG * NP;  // DMA instructions per wave and slab
     static_assert(G * (NSTAGE - 2) <= 63, "vmcnt range");
     constexpr int RING = NSTAGE * STAGE;
     constexpr int EPI = NW * 32 * ((NT >= 2 ? 64 : 32) + 4) * 4;  // the epilogue's accumulator patches reuse the ring (two-part 64 x 64 ring is smaller)
     constexpr int SMEM = RING > EPI ? RING : EPI;
     // ONE shared object (a second one beside a DMA-filled array makes hipcc drain vmcnt before every ds_read)
-    __shared__ __attribute__((aligned(16))) char smem[SMEM + 64 * 4];
+    __shared__ __attribute__((aligned(16))) char smem[SMEM + 64 * 4 + 16];
     unsigned *tap_delta = reinterpret_cast<unsigned *>(smem + SMEM);
+    unsigned *tap_any = tap_delta + 64;  // [2]: the taps that touch the tile at all (OR over the workgroup's rows)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WARPS_N, wn = wave - wm * WARPS_N;
+    unsigned long long xt0 = 0, xt1 = 0, xt2 = 0, xt3 = 0, xt4 = 0, xa = 0, xb = 0, xc = 0;
+    if (XE == 12) xt0 = wall_clock64();
+    if (XE == 12 && p.R > 0) xa = wall_clock64();
 
     const v4i rsa = make_srd(p.x3, p.x3_bytes), rsb = make_srd(p.w3, p.w3_bytes);
     const unsigned smem_base = (unsigned)(size_t)smem;  // LDS byte address of the ring
@@ -186,7 +229,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     const unsigned chunk_off = (unsigned)(((lane & 3) ^ ((M16 ? 0 - (r16 >> 2) : (r16 >> 2)) & 3)) * 16);
     const int ntaps = p.R * p.S;
     const int ohw = p.OHs * p.OWs;
-    const bool phase = p.o_mul != 1;
+    const bool phase = SIMPLE ? false : p.o_mul != 1;
     auto tap_ey = [&](int r) -> int { return phase ? (p.oy_add - p.pad + r * p.dil) / p.ustride : r * p.dil; };
     auto tap_ex = [&](int s) -> int { return phase ? (p.ox_add - p.pad + s * p.dil) / p.ustride : s * p.dil; };
     if (tid < ntaps) {
@@ -208,37 +251,56 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     const int a16 = (wm * MT16) * PG + l16, b16 = A_BYTES + (wn * NT16) * PG + l16;
 
     // ---- this workgroup's range of (tile, slab) units
+    // (all of it 32-bit and division-free on the common path: this setup runs once per workgroup and tile, and on short
+    // reductions it used to cost more than the slab loop -- tools/x3_exp.py stamps)
     const int wgid = xcd_remap(blockIdx.x, gridDim.x);
-    const long S_tile = (long)p.CC * ntaps;
-    const long U = ((long)p.mtiles * p.ntiles - p.dp_tiles) * S_tile;  // units of the stream-K region
-    const long u_begin = wgid < p.sk_part ? U * wgid / p.sk_part : U, u_end = wgid < p.sk_part ? U * (wgid + 1) / p.sk_part : U;
-    const int dp_rounds = p.dp_tiles / p.sk_wgs;
+    const int S_tile = p.CC * ntaps;
+    int u = 0, u_end = 0;  // units [u, u_end) of the stream-K region (U < 2^31: checked by the host)
+    if (SIMPLE || p.whole) {
+        u_end = 1;  // one pass through the loop below
+    } else if (wgid < p.sk_part) {
+        u = x3_sk_bound(p, wgid);
+        u_end = u + p.sk_q + (wgid < p.sk_r ? 1 : 0);
+    }
+    const int dp_rounds = SIMPLE ? 0 : p.dp_rounds;
     int seg_idx = 0;  // stream-K segments done so far
-    long u = u_begin;
-    for (int round = 0; round < dp_rounds || u < u_end; ++round) {
+    for (int round = 0; SIMPLE ? round < 1 : (round < dp_rounds || u < u_end); ++round) {
     int tile, s_lo, s_hi;
-    if (round < dp_rounds) {  // data-parallel part: whole tiles, fused epilogue, no workspace traffic
+    if (SIMPLE || p.whole) {
+        tile = wgid;
+        s_lo = 0;
+        s_hi = S_tile;
+        u = u_end;
+    } else if (round < dp_rounds) {  // data-parallel part: whole tiles, fused epilogue, no workspace traffic
         tile = round * p.sk_wgs + wgid;
         s_lo = 0;
-        s_hi = (int)S_tile;
+        s_hi = S_tile;
     } else {
-        tile = p.dp_tiles + (int)(u / S_tile);
-        s_lo = (int)(u - (long)(tile - p.dp_tiles) * S_tile);
-        s_hi = (int)((u_end - u) < (S_tile - s_lo) ? s_lo + (u_end - u) : S_tile);
+        const int rt = (int)((unsigned)u / (unsigned)S_tile);
+        tile = p.dp_tiles + rt;
+        s_lo = u - rt * S_tile;
+        s_hi = (u_end - u) < (S_tile - s_lo) ? s_lo + (u_end - u) : S_tile;
         u += s_hi - s_lo;
     }
-    const bool complete = s_lo == 0 && s_hi == (int)S_tile;
-    const int sk_seg = round < dp_rounds ? 0 : seg_idx++;
-    const int mt_i = tile / p.ntiles, nt_i = tile - mt_i * p.ntiles;
-    const int grp = mt_i / p.mt_per_group;
-    const int m0 = grp * p.group_rows + (mt_i - grp * p.mt_per_group) * BM, n0 = nt_i * BN;
-    const int m_end = (grp + 1) * p.group_rows < p.M ? (grp + 1) * p.group_rows : p.M;
-    if (p.cc_limit) {  // slabs are channel-slab major: dropping the slabs >= limit truncates the range
+    const bool complete = SIMPLE ? true : (s_lo == 0 && s_hi == S_tile);
+    const int sk_seg = SIMPLE || round < dp_rounds ? 0 : seg_idx++;
+    const int mt_i = p.ntiles == 1 ? tile : (int)((unsigned)tile / (unsigned)p.ntiles), nt_i = tile - mt_i * p.ntiles;
+    const int grp = SIMPLE || p.mt_per_group >= p.mtiles ? 0 : mt_i / p.mt_per_group;
+    const int m0 = SIMPLE ? mt_i * BM : grp * p.group_rows + (mt_i - grp * p.mt_per_group) * BM, n0 = nt_i * BN;
+    const int m_end = SIMPLE ? p.M : ((grp + 1) * p.group_rows < p.M ? (grp + 1) * p.group_rows : p.M);
+    if (!SIMPLE && p.cc_limit) {  // slabs are channel-slab major: dropping the slabs >= limit truncates the range
         const int lim = p.cc_limit[grp] * ntaps;
         s_lo = s_lo < lim ? s_lo : lim;
         s_hi = s_hi < lim ? s_hi : lim;
     }
+    if (tid < 2) tap_any[tid] = 0u;
+    if (XE == 12 && round == 0 && lane == 0) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(p.ws) + (long)wgid * 16;
+        o[8 + wave] = xt0;
+        o[12 + wave] = wall_clock64();
+    }
     __syncthreads();  // the previous segment's epilogue is done with the ring; tap_delta is visible
+    if (XE == 12 && round == 0) xb = wall_clock64();
 
     unsigned rb_off[RG];
     unsigned long long vmask[RG];
@@ -255,35 +317,54 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
             const int m = m0 + q * 16 + r16;
             a_ok[j] = m < m_end;
             const int mm = a_ok[j] ? m : 0;
-            const int n = mm / ohw;
+            const int n = x3_fastdiv(mm, p.mg_ohw, p.sh_ohw);
             const int rem = mm - n * ohw;
-            const int ohs = rem / p.OWs;
+            const int ohs = x3_fastdiv(rem, p.mg_ows, p.sh_ows);
             const int ows = rem - ohs * p.OWs;
             a_by[j] = phase ? ohs : ohs * p.stride - p.pad;
             a_bx[j] = phase ? ows : ows * p.stride - p.pad;
-            rb_off[j] = (unsigned)(((long)n * p.H + a_by[j]) * p.W + a_bx[j]) * p.row_pitch + chunk_off;  // wraps for border rows; only valid taps use it
+            // (mod 2^32 throughout: wraps for border rows; only valid taps use it, and for those the true offset is < 2^32)
+            rb_off[j] = ((unsigned)(n * p.H + a_by[j]) * (unsigned)p.W + (unsigned)a_bx[j]) * p.row_pitch + chunk_off;
         } else {
             int k = n0 + (q - AG) * 16 + r16;
             if (k >= p.K) k = p.K - 1;  // columns >= K are never stored: any finite row will do
-            rb_off[j] = (unsigned)grp * p.w3_group_stride + (unsigned)k * (unsigned)(ntaps * p.CC * SB) + chunk_off;
+            rb_off[j] = (SIMPLE ? 0u : (unsigned)grp * p.w3_group_stride) + (unsigned)k * (unsigned)(ntaps * p.CC * SB) + chunk_off;
         }
     }
 
     // ---- taps that touch this tile at all; per A row the taps that fall inside the image
+    if (XE == 12 && round == 0) xc = wall_clock64();
     unsigned long long tapmask = 0ull;
-    for (int t = 0; t < ntaps; ++t) {
-        if (!((p.tap_allow >> t) & 1ull)) continue;
-        const int r = t / p.S, s = t - r * p.S;
-        const int ey = tap_ey(r), ex = tap_ex(s);
-        bool any = false;
+    if (ntaps == 1 && p.pad == 0 && !phase) {  // 1 x 1, no padding: every row of the tile reads its one tap
 #pragma unroll
-        for (int j = 0; j < RG; ++j) {
-            const int iy = a_by[j] + ey, ix = a_bx[j] + ex;
-            const bool ok = a_ok[j] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            if (ok) vmask[j] |= (1ull << t);
-            any = any || ok;
+        for (int j = 0; j < RG; ++j) vmask[j] = a_ok[j] ? 1ull : 0ull;
+        tapmask = p.tap_allow & 1ull;
+    } else {
+        unsigned long long wave_any = 0ull;  // wave-uniform
+        int t = 0;
+        for (int r = 0; r < p.R; ++r) {
+            const int ey = tap_ey(r);
+            for (int s2 = 0; s2 < p.S; ++s2, ++t) {
+                if (!((p.tap_allow >> t) & 1ull)) continue;
+                const int ex = tap_ex(s2);
+                bool any = false;
+#pragma unroll
+                for (int j = 0; j < RG; ++j) {
+                    const int iy = a_by[j] + ey, ix = a_bx[j] + ex;
+                    const bool ok = a_ok[j] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                    if (ok) vmask[j] |= (1ull << t);
+                    any = any || ok;
+                }
+                if (__ballot(any)) wave_any |= (1ull << t);
+            }
         }
-        if (__syncthreads_or((int)any)) tapmask |= (1ull << t);
+        // ONE barrier for the whole mask (it was one __syncthreads_or per tap)
+        if (lane == 0) {
+            if ((unsigned)wave_any) atomicOr(&tap_any[0], (unsigned)wave_any);
+            if ((unsigned)(wave_any >> 32)) atomicOr(&tap_any[1], (unsigned)(wave_any >> 32));
+        }
+        __syncthreads();
+        tapmask = (unsigned long long)tap_any[0] | ((unsigned long long)tap_any[1] << 32);
     }
 
     // active slabs of [s_lo, s_hi): slab s = cc * ntaps + t (channel slab outer, taps inner)
@@ -292,7 +373,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
         const int cc = sidx / ntaps, t = sidx - cc * ntaps;
         return cc * pc + __builtin_popcountll(tapmask & ((1ull << t) - 1ull));
     };
-    const int total = active_below(s_hi) - active_below(s_lo);
+    const int total = XE == 8 ? 1 : (s_lo == 0 && s_hi == S_tile) ? p.CC * pc : active_below(s_hi) - active_below(s_lo);
 
     f32x16 acc[M16 ? 1 : MT][M16 ? 1 : NT];
     f32x4 acc16[M16 ? MT16 : 1][M16 ? NT16 : 1];
@@ -310,7 +391,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     // ---- slab iterator of the LOADER (the 9 taps of a 3x3 re-read the same neighbourhood back to back, so the re-reads
     // are L2 hits).  The uniform offsets of the NEXT slab to issue are computed one slab ahead (the tap table lives in
     // LDS: its read must not sit in front of a DMA issue).
-    int it_cc = s_lo / ntaps, nx_t = 0;
+    int it_cc = s_lo == 0 ? 0 : s_lo / ntaps, nx_t = 0;
     unsigned long long it_mask = tapmask & ~((1ull << (s_lo - it_cc * ntaps)) - 1ull);
     unsigned nx_a_uni = 0u, nx_b_uni = 0u;
     auto advance = [&]() __attribute__((always_inline)) {
@@ -342,6 +423,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     };
 
     // ---- prologue: NSTAGE - 1 slabs in flight
+    if (XE == 12 && round == 0) xt1 = wall_clock64();
     int issued = 0;
     if (total > 0) advance();
 #pragma unroll
@@ -434,13 +516,14 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
         const unsigned st = smem_base + (unsigned)(stage * STAGE);
         const int q = wave + j * NW;
         if (q < AG) {
+            if (XE_NO_DMAA) return;
             const bool valid = (vm >> nx_t) & 1ull;
             const unsigned voff = valid ? rbo + nx_a_uni : p.zero_off + chunk_off;
             const unsigned dst = __builtin_amdgcn_readfirstlane(st + q * PG);
             dma16(rsa, dst, voff);
             dma16(rsa, dst + 1024, voff + 64);
             if constexpr (NP == 3) dma16(rsa, dst + 2048, voff + 128);
-        } else {
+        } else if (!XE_NO_DMAB) {
             const unsigned voff = rbo + nx_b_uni;
             const unsigned dst = __builtin_amdgcn_readfirstlane(st + A_BYTES + (q - AG) * PG);
             dma16(rsb, dst, voff);
@@ -448,13 +531,16 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
             if constexpr (NP == 3) dma16(rsb, dst + 2048, voff + 128);
         }
     };
+    bool exp_rd = true;
     auto rd_a = [&](const char *st, uint4(&a)[NP][MH], int half) __attribute__((always_inline)) {
+        if (XE_NO_RDA && !exp_rd) return;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
             for (int i2 = 0; i2 < MH; ++i2) a[pl][i2] = *reinterpret_cast<const uint4 *>(st + a16 + (half * MH + i2) * PG + pl * 1024);
     };
     auto rd_b = [&](const char *st, uint4(&b)[NP][NH], int half) __attribute__((always_inline)) {
+        if (XE_NO_RDB && !exp_rd) return;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
@@ -471,7 +557,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
             for (int i2 = 0; i2 < MH; ++i2)
 #pragma unroll
                 for (int j2 = 0; j2 < NH; ++j2)
-                    acc16[decltype(I0)::value + i2][decltype(J0)::value + j2] =
+                    if (XE != 7) acc16[decltype(I0)::value + i2][decltype(J0)::value + j2] =
                         mfma32<NP>(a[TT::PA[term]][i2], b[TT::PB[term]][j2], acc16[decltype(I0)::value + i2][decltype(J0)::value + j2]);
             between(T);
         };
@@ -498,6 +584,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
         else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (XE == 12 && s == 0 && round == 0) xt2 = wall_clock64();
         const char *st = smem + cur * STAGE;
         const bool more = issued < total;  // block-uniform
         // (sched_barriers pin the order: hoisting a fragment read above the MFMAs that still use its registers costs the
@@ -541,6 +628,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
         __builtin_amdgcn_sched_barrier(0);
         quad(a_lo, bs, C0{}, JS, nothing);           // step 2
         __builtin_amdgcn_sched_barrier(0);
+        exp_rd = false;
         cur = cur + 1 == NSTAGE ? 0 : cur + 1;
         nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
     };
@@ -559,6 +647,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     }
     }
     wait_vmcnt<0>();
+    if (XE == 12 && round == 0) xt3 = wall_clock64();
     if constexpr (NP == 2) {
         // two-part operands carry per-tensor power-of-two scales: sums of (x sa)(w sb) -> multiply by 1 / (sa sb), exact.
         // Done on the raw accumulators, so partial stream-K slabs, BN statistics and the epilogue all see true values.
@@ -576,6 +665,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
         }
     }
     __syncthreads();  // all waves out of the main loop: the ring is free for the epilogue
+    if (XE == 9) continue;
 
     if ((p.stat_partial || p.stat_sums) && complete) {
         // BatchNorm batch statistics of the RAW output, one partial row per M-tile (rows >= M are zero: their taps all
@@ -645,7 +735,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     static_assert(NT % PBLK == 0, "column blocks per pass");
     float *patch = reinterpret_cast<float *>(smem) + wave * 32 * PITCH;
     const bool vec_ok = (!y || (p.ldy & 3) == 0) && ((p.K & 3) == 0) && (!res || (p.ldr & 3) == 0);
-    float *slab = complete ? nullptr : p.ws + ((long)wgid * 2 + (sk_seg > 0 ? 1 : 0)) * (BM * BN);
+    float *slab = SIMPLE || complete ? nullptr : p.ws + ((long)wgid * 2 + (sk_seg > 0 ? 1 : 0)) * (BM * BN);
+    const bool plain = y && vec_ok && !p.scale && !p.shift && !res && p.act == DASS_ACT_NONE && !p.y3 && !p.y_amax && !phase && p.ldy < (1l << 22);
+    float *y_tile = y + (long)m0 * p.ldy + n0;
+    const int ldy32 = (int)p.ldy;
     float y3_scale = 1.f, vmax = 0.f;
     if (p.y3 && p.y3_parts == 2)  // the output's scale: from the bound dass_x3_prepare_out left in y3's trailer (same in every workgroup)
         y3_scale = x3_scale_of(*reinterpret_cast<const float *>(p.y3 + ((long)p.M + 1) * p.cc_out * 128 + 4));
@@ -690,13 +783,28 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
                 }
                 const int m = m0 + lr, k = n0 + lc;
                 if (m >= m_end || k >= p.K) continue;
-                x3_store_out(p, v, m, k, ohw, vec_ok, y3_scale, vmax);
+                if (plain) {  // raw f32 rows and nothing else (every train-mode conv and most input gradients): one 16-B store, 32-bit offsets
+                    *reinterpret_cast<f32x4 *>(y_tile + lr * ldy32 + lc) = v;
+                    continue;
+                }
+                x3_store_out(p, v, m, k, ohw, vec_ok, y3_scale, vmax, phase);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
     }
     x3_amax_commit(p.y_amax, vmax);
+    if (XE == 12 && round == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        xt4 = wall_clock64();
+        if (tid == 0) {
+            unsigned long long *o = reinterpret_cast<unsigned long long *>(p.ws) + (long)wgid * 16;
+            o[0] = xt0; o[1] = xt1; o[2] = xt2; o[3] = xt3; o[4] = xt4;
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            o[5] = xa; o[6] = xb; o[7] = xc;
+        }
+    }
     }  // segments
 }
 
@@ -709,7 +817,7 @@ template <int BM, int BN> __global__ __launch_bounds__(256) void conv_x3_fixup_k
     const long S_tile = (long)p.CC * ntaps;
     const long U = ((long)p.mtiles * p.ntiles - p.dp_tiles) * S_tile;
     const int i = blockIdx.x;
-    auto bound = [&](int w) -> long { return U * w / p.sk_part; };
+    auto bound = [&](int w) -> long { return x3_sk_bound(p, w); };  // the main kernel's cut: near-equal ranges, the first sk_r one unit longer
     const long b1 = bound(i + 1);
     const int rtile = (int)(b1 / S_tile);  // tile index inside the stream-K region
     const long t_lo = (long)rtile * S_tile, t_hi = t_lo + S_tile;
@@ -753,7 +861,7 @@ template <int BM, int BN> __global__ __launch_bounds__(256) void conv_x3_fixup_k
         s1 += v;
         s2 += v * v;
         const int m = m0 + lr, k = n0 + c4 * 4;
-        if (m < m_end && k < p.K) x3_store_out(p, v, m, k, ohw, vec_ok, y3_scale, vmax);
+        if (m < m_end && k < p.K) x3_store_out(p, v, m, k, ohw, vec_ok, y3_scale, vmax, p.o_mul != 1);
     }
     x3_amax_commit(p.y_amax, vmax);
     if (p.stat_partial || p.stat_sums) {  // rows >= M of the slabs are exact zeros
@@ -897,6 +1005,24 @@ template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE, int NP = 3> int 
         if (ur / 4 < p.sk_part) p.sk_part = ur / 4 > 0 ? (int)(ur / 4) : 1;
         if (p.dp_tiles == tiles) stream = false;  // the tile count is a whole number of rounds
         else if (s_tile / (ur / p.sk_part > 0 ? ur / p.sk_part : 1) + 2 > 256) return DASS_ERR_UNSUPPORTED;  // cannot happen for S_tile <= 1016
+    }
+    {   // what the kernel's per-workgroup setup needs divided (x3_fastdiv, x3_sk_bound)
+        const long ur = (tiles - p.dp_tiles) * (long)p.CC * p.R * p.S;
+        if (units >= (1l << 31)) return DASS_ERR_UNSUPPORTED;
+        p.sk_q = (int)(ur / p.sk_part);
+        p.sk_r = (int)(ur % p.sk_part);
+        p.dp_rounds = p.dp_tiles / p.sk_wgs;
+        p.whole = (p.dp_tiles == 0 && p.sk_wgs == tiles && p.sk_part == p.sk_wgs) ? 1 : 0;
+        x3_set_magic(p.OHs * p.OWs, p.mg_ohw, p.sh_ohw);
+        x3_set_magic(p.OWs, p.mg_ows, p.sh_ows);
+    }
+    const bool simple = p.whole && p.o_mul == 1 && !p.cc_limit && p.group_rows == p.M;
+    if constexpr (NP == 2 && ((BM == 64 && BN == 64 && NSTAGE == 2) || (BM == 256 && BN == 128))) {  // the production picks
+        if (simple) {
+            hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE, true, NP, true>), dim3(p.sk_wgs), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
+            DASS_LAUNCH_CHECK();
+            return DASS_OK;
+        }
     }
     if (m16 || NP == 2)  // (the two-part format is built for the 16x16x32 shape only)
         hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE, true, NP>), dim3(p.sk_wgs), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
