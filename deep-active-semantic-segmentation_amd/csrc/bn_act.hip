@@ -9,13 +9,6 @@ namespace {
 
 constexpr int SLAB = 128;  // pixel rows per partial-statistics row
 
-// the BN affine exactly as the forward applies it (one fma per element): forward and backward gates must agree bit for bit
-__device__ __forceinline__ f32x4 bn_affine(f32x4 v, f32x4 sc, f32x4 sh) {
-    f32x4 r;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(v[e], sc[e], sh[e]);
-    return r;
-}
 
 // partial[slab][0][k] = sum f0, partial[slab][1][k] = sum f1 over the slab's rows.
 // MODE 0: f0 = x, f1 = x*x ; MODE 1: f0 = dact, f1 = dact*xhat

@@ -57,6 +57,13 @@ struct X3P {
     int sk_q, sk_r;           // stream-K region: U = sk_q * sk_part + sk_r units; workgroup w owns [w q + min(w, r), ...) (q + 1 units while w < r)
     int dp_rounds;            // dp_tiles / sk_wgs
     int whole;                // 1: one whole tile per workgroup, nothing else (no stream-K region arithmetic at all)
+    // dass_conv2d_x3_dgrad_bnstats: this launch's output is the gradient d_out of a conv + BN (+ act) layer whose conv output
+    // is bs_y [M][K]; the epilogue also adds that layer's BN-backward sums (sum dz, sum dz * xhat; dz = d_out * activation gate)
+    // into bs_sums[2][K] f64 and maxes |dz| per channel into the K floats behind them (what dass_bn_bwd_reduce_sums computes)
+    const float *bs_y, *bs_mean, *bs_invstd, *bs_gsc, *bs_gsh;
+    const unsigned char *bs_gates;  // [M][K / 4] gate bits (residual layers), else the gate is re-derived from bs_y * gsc + gsh
+    double *bs_sums;
+    int bs_act;
 };
 
 // n / d for 0 <= n < 2^31 with the host's magic pair (x3_set_magic): mul = ceil(2^(31 + l) / d), l = ceil(log2 d), shift = l - 1
@@ -736,9 +743,14 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     float *patch = reinterpret_cast<float *>(smem) + wave * 32 * PITCH;
     const bool vec_ok = (!y || (p.ldy & 3) == 0) && ((p.K & 3) == 0) && (!res || (p.ldr & 3) == 0);
     float *slab = SIMPLE || complete ? nullptr : p.ws + ((long)wgid * 2 + (sk_seg > 0 ? 1 : 0)) * (BM * BN);
-    const bool plain = y && vec_ok && !p.scale && !p.shift && !res && p.act == DASS_ACT_NONE && !p.y3 && !p.y_amax && !phase && p.ldy < (1l << 22);
+    bool bstat = false;
+    if constexpr (SIMPLE) bstat = p.bs_sums != nullptr;  // (host: only with f32 rows out, 16-B aligned rows, no scale / shift / act)
+    const bool plain = !bstat && y && vec_ok && !p.scale && !p.shift && !res && p.act == DASS_ACT_NONE && !p.y3 && !p.y_amax && !phase && p.ldy < (1l << 22);
     float *y_tile = y + (long)m0 * p.ldy + n0;
     const int ldy32 = (int)p.ldy;
+    f32x4 bs0[NT / PBLK], bs1[NT / PBLK], bsm[NT / PBLK];
+#pragma unroll
+    for (int i = 0; i < NT / PBLK; ++i) bs0[i] = bs1[i] = bsm[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float y3_scale = 1.f, vmax = 0.f;
     if (p.y3 && p.y3_parts == 2)  // the output's scale: from the bound dass_x3_prepare_out left in y3's trailer (same in every workgroup)
         y3_scale = x3_scale_of(*reinterpret_cast<const float *>(p.y3 + ((long)p.M + 1) * p.cc_out * 128 + 4));
@@ -751,6 +763,38 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int ntp = 0; ntp < NT; ntp += PBLK) {
+            // bstat: the loads of this pass (the linked layer's conv output, the forked gradient, the gate bits, the channel
+            // vectors) are issued BEFORE the accumulators bounce through LDS, so that their latency runs under the bounce
+            constexpr int ITS = (32 * C4) / 64;
+            f32x4 pf_y[SIMPLE ? ITS : 1], pf_r[SIMPLE ? ITS : 1];
+            unsigned pf_g[SIMPLE ? ITS : 1];
+            f32x4 ch_mu = {0.f, 0.f, 0.f, 0.f}, ch_is = ch_mu, ch_sc = ch_mu, ch_sh = ch_mu;
+            if constexpr (SIMPLE) {
+                if (bstat) {
+                    const int kc = n0 + wn * TNW + ntp * 32 + (lane & (C4 - 1)) * 4;
+                    if (kc < p.K) {
+                        ch_mu = *reinterpret_cast<const f32x4 *>(p.bs_mean + kc);
+                        ch_is = *reinterpret_cast<const f32x4 *>(p.bs_invstd + kc);
+                        if (!p.bs_gates && p.bs_act != DASS_ACT_NONE) {
+                            ch_sc = *reinterpret_cast<const f32x4 *>(p.bs_gsc + kc);
+                            ch_sh = *reinterpret_cast<const f32x4 *>(p.bs_gsh + kc);
+                        }
+                    }
+#pragma unroll
+                    for (int it = 0; it < ITS; ++it) {
+                        const int idx = it * 64 + lane;
+                        const int row = idx / C4;
+                        const int mm = m0 + wm * TMW + mt * 32 + row;
+                        pf_y[it] = pf_r[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        pf_g[it] = 0xfu;
+                        if (mm < m_end && kc < p.K) {
+                            pf_y[it] = *reinterpret_cast<const f32x4 *>(p.bs_y + (long)mm * p.K + kc);
+                            if (res) pf_r[it] = *reinterpret_cast<const f32x4 *>(res + (long)mm * p.ldr + kc);
+                            if (p.bs_gates) pf_g[it] = p.bs_gates[(long)mm * (p.K >> 2) + (kc >> 2)];
+                        }
+                    }
+                }
+            }
             if constexpr (M16) {  // C/D layout of the 16x16 blocks: col = lane & 15, row = 4 (lane >> 4) + reg
 #pragma unroll
                 for (int ib = 0; ib < 2; ++ib)
@@ -787,6 +831,28 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
                     *reinterpret_cast<f32x4 *>(y_tile + lr * ldy32 + lc) = v;
                     continue;
                 }
+                if constexpr (SIMPLE) {
+                    if (bstat) {  // input gradient + the BN-backward sums of the layer that produced this conv's input
+                        f32x4 g = v + pf_r[it];
+                        *reinterpret_cast<f32x4 *>(y_tile + lr * ldy32 + lc) = g;
+                        const f32x4 yl = pf_y[it];
+                        if (p.bs_gates) {
+                            const unsigned gb = pf_g[it];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) g[e] = ((gb >> e) & 1u) ? g[e] : 0.f;
+                        } else if (p.bs_act != DASS_ACT_NONE) {
+                            const f32x4 o = bn_affine(yl, ch_sc, ch_sh);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) g[e] *= act_grad_from_out(o[e], p.bs_act);
+                        }
+                        const f32x4 xh = (yl - ch_mu) * ch_is;
+                        bs0[ntp / PBLK] += g;
+                        bs1[ntp / PBLK] += g * xh;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bsm[ntp / PBLK][e] = fmaxf(bsm[ntp / PBLK][e], fabsf(g[e]));
+                        continue;
+                    }
+                }
                 x3_store_out(p, v, m, k, ohw, vec_ok, y3_scale, vmax, phase);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -794,6 +860,52 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
         }
     }
     x3_amax_commit(p.y_amax, vmax);
+    if constexpr (SIMPLE) {
+        if (bstat) {
+            // lanes with the same 4-channel column group (lane % C4) hold partial sums over different rows: fold them, then the
+            // WARPS_M waves of a column through LDS, then one f64 atomic per channel and workgroup (as the forward statistics)
+            __syncthreads();  // every wave is done with its epilogue patch
+            float *red = reinterpret_cast<float *>(smem);  // [WARPS_M][3][BN]
+            static_assert(WARPS_M * 3 * BN * 4 <= SMEM, "bn-backward partials must fit the ring");
+#pragma unroll
+            for (int i = 0; i < NT / PBLK; ++i) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a0 = bs0[i][e], a1 = bs1[i][e], a2 = bsm[i][e];
+#pragma unroll
+                    for (int o = C4; o < 64; o <<= 1) {
+                        a0 += __shfl_xor(a0, o, 64);
+                        a1 += __shfl_xor(a1, o, 64);
+                        a2 = fmaxf(a2, __shfl_xor(a2, o, 64));
+                    }
+                    if (lane < C4) {
+                        const int col = wn * TNW + i * PW + lane * 4 + e;
+                        red[(wm * 3 + 0) * BN + col] = a0;
+                        red[(wm * 3 + 1) * BN + col] = a1;
+                        red[(wm * 3 + 2) * BN + col] = a2;
+                    }
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < 3 * BN; i += 64 * NW) {
+                const int which = i / BN, col = i - which * BN;
+                if (n0 + col >= p.K) continue;
+                if (which < 2) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int q2 = 0; q2 < WARPS_M; ++q2) a += red[(q2 * 3 + which) * BN + col];
+                    unsafeAtomicAdd(p.bs_sums + (long)which * p.K + n0 + col, (double)a);
+                } else {
+                    float a = 0.f;
+#pragma unroll
+                    for (int q2 = 0; q2 < WARPS_M; ++q2) a = fmaxf(a, red[(q2 * 3 + 2) * BN + col]);
+                    if (!(a >= 0.f)) a = __uint_as_float(0x7f800000u);  // NaN: an infinite bound
+                    unsigned *slot = reinterpret_cast<unsigned *>(p.bs_sums + 2 * (long)p.K) + n0 + col;
+                    if (__float_as_uint(a) > *reinterpret_cast<volatile unsigned *>(slot)) atomicMax(slot, __float_as_uint(a));
+                }
+            }
+        }
+    }
     if (XE == 12 && round == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         xt4 = wall_clock64();
@@ -977,6 +1089,7 @@ __global__ __launch_bounds__(256) void absmax_rows_kernel(const float *__restric
 }
 
 static int g_cus = 0;
+static int g_bn_fused = 0;  // did the last launch_x3 fuse the BN-backward sums it was asked for? (read back by the entry point)
 static int g_x3_parts = 3;  // operand format of the pre-split kernels: 3 = bf16 triple (bf16x6 engine), 2 = scaled f16 pair (f16x3 engine)  // compute units of the current device (stream-K launches one workgroup per resident slot)
 
 template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE, int NP = 3> int launch_x3(X3P &p, hipStream_t st, int mode, long ws_bytes, bool m16) {
@@ -1017,7 +1130,10 @@ template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE, int NP = 3> int 
         x3_set_magic(p.OWs, p.mg_ows, p.sh_ows);
     }
     const bool simple = p.whole && p.o_mul == 1 && !p.cc_limit && p.group_rows == p.M;
-    if constexpr (NP == 2 && ((BM == 64 && BN == 64 && NSTAGE == 2) || (BM == 256 && BN == 128))) {  // the production picks
+    constexpr bool has_simple = NP == 2 && ((BM == 64 && BN == 64 && NSTAGE == 2) || (BM == 256 && BN == 128));  // the production picks
+    if (p.bs_sums && !(has_simple && simple)) p.bs_sums = nullptr;  // not fused: the caller runs dass_bn_bwd_reduce_sums itself
+    g_bn_fused = p.bs_sums ? 1 : 0;
+    if constexpr (has_simple) {
         if (simple) {
             hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE, true, NP, true>), dim3(p.sk_wgs), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
             DASS_LAUNCH_CHECK();
@@ -1152,7 +1268,7 @@ static int conv_x3_impl(const void *x3, const void *w3, void *y, int64_t ldy, vo
                         const void *residual, int64_t ldr, int N, int H, int W, int C, int OH, int OW, int K, int R, int S, int stride,
                         int pad, int dil, int ustride, int act, float *stat_partial, int *stat_rows, void *workspace,
                         int64_t workspace_bytes, void *stream, bool per_image, const int *cc_limit, double *stat_sums = nullptr,
-                        void *y_amax = nullptr) {
+                        void *y_amax = nullptr, const X3P *bnstat = nullptr, int *bn_fused = nullptr) {
     if (!x3 || !w3 || (!y && !y3)) return DASS_ERR_ARG;
     if (workspace && ((uintptr_t)workspace & 15)) return DASS_ERR_ARG;
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || K <= 0 || R <= 0 || S <= 0) return DASS_ERR_ARG;
@@ -1181,6 +1297,15 @@ static int conv_x3_impl(const void *x3, const void *w3, void *y, int64_t ldy, vo
     // two-part y3: scale from the bound dass_x3_prepare_out wrote into its trailer; the true max |output| goes to trailer[2]
     p.y_amax = (y3 && parts == 2) ? (unsigned *)((char *)y3 + x3_trailer_off((long)N * OH * OW, (K + 31) / 32, 2) + 8) : (unsigned *)y_amax;
     p.ws = (float *)workspace;
+    p.bs_sums = nullptr;
+    p.bs_y = p.bs_mean = p.bs_invstd = p.bs_gsc = p.bs_gsh = nullptr;
+    p.bs_gates = nullptr;
+    p.bs_act = DASS_ACT_NONE;
+    if (bnstat) {  // (dass_conv2d_x3_dgrad_bnstats; launch_x3 drops it again when the launch is not one whole tile per workgroup)
+        p.bs_sums = bnstat->bs_sums; p.bs_y = bnstat->bs_y; p.bs_mean = bnstat->bs_mean; p.bs_invstd = bnstat->bs_invstd;
+        p.bs_gsc = bnstat->bs_gsc; p.bs_gsh = bnstat->bs_gsh; p.bs_gates = bnstat->bs_gates; p.bs_act = bnstat->bs_act;
+    }
+    g_bn_fused = 0;
     p.ldy = ldy;
     p.ldr = ldr;
     p.x3_bytes = (unsigned)xbytes;
@@ -1234,6 +1359,7 @@ static int conv_x3_impl(const void *x3, const void *w3, void *y, int64_t ldy, vo
     }
     const int rc = dispatch_x3(p, st, workspace_bytes);
     if (stat_rows) *stat_rows = p.mtiles;
+    if (bn_fused) *bn_fused = rc == DASS_OK ? g_bn_fused : 0;
     return rc;
 }
 
@@ -1243,6 +1369,32 @@ extern "C" int dass_conv2d_x3(const void *x3, const void *w3, void *y, int64_t l
                               int64_t workspace_bytes, void *y_amax, void *stream) {
     return conv_x3_impl(x3, w3, y, ldy, y3, scale, shift, residual, ldr, N, H, W, C, OH, OW, K, R, S, stride, pad, dil, ustride, act,
                         stat_partial, stat_rows, workspace, workspace_bytes, stream, false, nullptr, nullptr, y_amax);
+}
+
+/* Input-gradient launch of a stride-1 conv (the caller passes the flipped / transposed weight operand and pad' = dil (R-1) - pad, as for
+ * dass_conv2d_x3) whose OUTPUT dx [N*OH*OW][K] (+ optional residual = the gradient of a forked identity branch) is the gradient
+ * d_out of the conv + BN (+ act) layer that produced this conv's input.  Besides dx the epilogue adds that layer's BN-backward
+ * sums -- what dass_bn_bwd_reduce_sums would compute in a separate pass over dx and bn_y -- into bn_sums: [2][K] f64 (sum dz, sum
+ * dz * xhat) + K floats (max |dz| per channel, atomic max of bit patterns), all zeroed by the caller.  dz = dx * gate; the gate
+ * comes from bn_gates ([M][K/4] bytes, 4 bits used) when given, else from act'(fma(bn_y, gate_scale, gate_shift)).
+ * *fused = 1 when the sums were produced; 0 when this launch's schedule cannot (stream-K / unsupported tile): dx is still
+ * complete and the caller runs dass_bn_bwd_reduce_sums.  Replaces one read of dx and of bn_y per BN layer of the backward
+ * pass (the reduce half of torch's batch_norm_backward, models/sync_batchnorm/batchnorm.py:62-71 + autograd). */
+extern "C" int dass_conv2d_x3_dgrad_bnstats(const void *x3, const void *w3, void *y, int64_t ldy, const void *residual, int64_t ldr, int N, int H,
+                                            int W, int C, int OH, int OW, int K, int R, int S, int pad, int dil, const float *bn_y,
+                                            const float *bn_mean, const float *bn_invstd, const float *gate_scale, const float *gate_shift,
+                                            const void *bn_gates, int64_t gates_bytes, int bn_act, double *bn_sums, int *fused,
+                                            void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!y || !bn_y || !bn_mean || !bn_invstd || !bn_sums || !fused || (K & 3) || ldy != K || (residual && (ldr & 3))) return DASS_ERR_ARG;
+    if (((uintptr_t)bn_y & 15) || ((uintptr_t)y & 15) || ((uintptr_t)bn_sums & 7)) return DASS_ERR_ARG;
+    if (bn_gates ? gates_bytes < (int64_t)N * OH * OW * (K / 4) : (bn_act != DASS_ACT_NONE && (!gate_scale || !gate_shift))) return DASS_ERR_ARG;
+    X3P bs;
+    bs.bs_y = bn_y; bs.bs_mean = bn_mean; bs.bs_invstd = bn_invstd; bs.bs_gsc = gate_scale; bs.bs_gsh = gate_shift;
+    bs.bs_gates = (const unsigned char *)bn_gates; bs.bs_sums = bn_sums; bs.bs_act = bn_act;
+    *fused = 0;
+    const int rc = conv_x3_impl(x3, w3, y, ldy, nullptr, nullptr, nullptr, residual, ldr, N, H, W, C, OH, OW, K, R, S, 1, pad, dil, 1, DASS_ACT_NONE,
+                                nullptr, nullptr, workspace, workspace_bytes, stream, false, nullptr, nullptr, nullptr, &bs, fused);
+    return rc;
 }
 
 /* plain conv + batch statistics added into [2][K] f64 accumulators (zeroed by the caller): see dass_bn_apply_train */

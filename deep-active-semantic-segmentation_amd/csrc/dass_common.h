@@ -152,6 +152,14 @@ __device__ __forceinline__ float act_grad_from_out(float out, int act) {
     return 1.f;
 }
 
+// the BN affine exactly as the forward applies it (one fma per element): forward and backward gates must agree bit for bit
+__device__ __forceinline__ f32x4 bn_affine(f32x4 v, f32x4 sc, f32x4 sh) {
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(v[e], sc[e], sh[e]);
+    return r;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -240,6 +240,50 @@ def conv_x3_launch(x3, w3, y, ldy, dims, y3=None, scale=None, shift=None, residu
     return nrows.value
 
 
+class BnBwdLink:
+    """What the input-gradient launch of the NEXT conv needs to add a conv + BN layer's backward sums in its epilogue
+    (dass_conv2d_x3_dgrad_bnstats): attached to the layer's output tensor by the forward, claimed by the single dense conv that
+    consumes it; that conv's backward fills `sums` and remembers which tensor it returned, the layer's own backward takes the
+    sums only if exactly that tensor arrives as its d_out (autograd hands a lone gradient through untouched; a second consumer
+    would make it a sum in a new tensor)."""
+    __slots__ = ("y_raw", "mean", "invstd", "gsc", "gsh", "gates", "act", "m", "k", "claimed", "dead", "sums", "dx_ptr")
+
+    def __init__(self, y_raw, mean, invstd, gsc, gsh, gates, act, m, k):
+        self.y_raw, self.mean, self.invstd, self.gsc, self.gsh, self.gates, self.act, self.m, self.k = y_raw, mean, invstd, gsc, gsh, gates, act, m, k
+        self.claimed = self.dead = False
+        self.sums = None
+        self.dx_ptr = 0
+
+
+_BN_LINK = os.environ.get("DASS_BN_LINK", "1") == "1"  # BN-backward sums ride in the epilogue of the next layer's input-gradient launch
+bn_link_counts = {"asked": 0, "fused": 0, "used": 0}    # launches asked to carry sums / that did / sums a layer's backward took over
+
+
+def set_bn_link(on):
+    global _BN_LINK
+    _BN_LINK = bool(on)
+
+
+def conv_x3_dgrad_bnstats(dy3, w_t, dx, dims, link, residual=None, ldr=0):
+    """dgrad launch (dims = conv_launch dims of the transposed conv, stride 1) that also produces link's BN-backward sums;
+    -> True when fused (link.sums / link.dx_ptr set)"""
+    n, h, w, c, oh, ow, k, r, s, stride, pad, dil = dims
+    assert stride == 1 and k == link.k and n * oh * ow == link.m
+    sums = _bn_sums(k, dx.device)
+    fused = ctypes.c_int(0)
+    ws = _x3_workspace(dy3.device)
+    g = link.gates
+    check(lib.dass_conv2d_x3_dgrad_bnstats(_p(dy3), _p(w_t), _p(dx), k, _p(residual), ldr, n, h, w, c, oh, ow, k, r, s, pad, dil,
+                                           _p(link.y_raw), _p(link.mean), _p(link.invstd), _p(link.gsc if g is None else None),
+                                           _p(link.gsh if g is None else None), _p(g), g.numel() if g is not None else 0, link.act, _p(sums),
+                                           ctypes.byref(fused), _p(ws), ws.numel(), _stream()), "dass_conv2d_x3_dgrad_bnstats")
+    bn_link_counts["asked"] += 1
+    if fused.value:
+        bn_link_counts["fused"] += 1
+        link.sums, link.dx_ptr = sums, dx.data_ptr()
+    return bool(fused.value)
+
+
 _l1_cache = {}
 
 
@@ -925,7 +969,27 @@ class _ConvBnAct(torch.autograd.Function):
                                 nc_scale=nc_scale, rows_per_image=oh * ow, act=spec.act, out3=out3)
             if out3 is not None:
                 attach_x3(out, out3, m, k)
+            if (_BN_LINK and need_grad and sums is not None and nc_scale is None and dt == torch.float32 and ldo == k and k % 4 == 0
+                    and state is not None and sync_bn_world(bn) == 1):
+                # (the gate is re-derived from y_raw unless the layer has a residual, whose gate bits `gates` holds; a residual
+                # layer without stored gates reads `out` in its backward: no link)
+                if res_t is None or gates is not None or spec.act == ACT_NONE:
+                    ctx.out_link = out.__dict__["_dass_bnlink"] = BnBwdLink(y_raw, state.mean, state.invstd, state.scale, state.shift, gates,
+                                                                            spec.act, m, k)
+        in_link = None
+        if need_grad and _BN_LINK and hasattr(x, "__dict__"):
+            in_link = x.__dict__.get("_dass_bnlink")
+            if in_link is not None:
+                if in_link.claimed:  # a second consumer: the gradient will be a sum of two launches' outputs
+                    in_link.dead = True
+                    in_link = None
+                else:
+                    in_link.claimed = True
+                    if (spec.depthwise or image_input or spec.stride != 1 or in_link.k != c or in_link.m != n * h * w or c != c_in
+                            or getattr(spec, "rowtap", False)):
+                        in_link = None
         if need_grad:
+            ctx.in_link = in_link
             ctx.spec = spec
             ctx.x3_on = x3_on
             ctx.x3_dgrad = (x3_on or _x3_train_layer(taps, k)) and n * h * w >= _X3_MIN_ROWS  # the input gradient reduces over k x taps
@@ -999,12 +1063,18 @@ class _ConvBnAct(torch.autograd.Function):
             bsums = None
             if need_red and ctx.has_bn and ctx.train_stats and getattr(ctx, "bn_sums", False) and ctx.sync_world == 1:
                 # (sum dz, sum dz * xhat) as f64 accumulators: the apply launch reads them, no finalize launch
-                bsums = _bn_sums(k, dev)
                 no_out = gate or gates is not None
-                check(lib.dass_bn_bwd_reduce_sums(_p(dout_r), lddo, _p(None if no_out else out), ldo, _p(y_raw), k, _p(mean_v), _p(invstd_v),
-                                                  _p(bn_scale if gate else None), _p(bn_shift if gate else None), _p(nc_scale), m, k,
-                                                  oh * ow, spec.act, _p(bsums), _p(gates), gates.numel() if gates is not None else 0, _dt(out),
-                                                  _stream()), "dass_bn_bwd_reduce_sums")
+                link = getattr(ctx, "out_link", None)
+                if (link is not None and link.sums is not None and not link.dead and link.dx_ptr == dout_r.data_ptr() and lddo == k
+                        and nc_scale is None and (no_out or spec.act == ACT_NONE)):
+                    bsums = link.sums  # already added by the consumer's input-gradient launch (dass_conv2d_x3_dgrad_bnstats)
+                    bn_link_counts["used"] += 1
+                else:
+                    bsums = _bn_sums(k, dev)
+                    check(lib.dass_bn_bwd_reduce_sums(_p(dout_r), lddo, _p(None if no_out else out), ldo, _p(y_raw), k, _p(mean_v), _p(invstd_v),
+                                                      _p(bn_scale if gate else None), _p(bn_shift if gate else None), _p(nc_scale), m, k,
+                                                      oh * ow, spec.act, _p(bsums), _p(gates), gates.numel() if gates is not None else 0,
+                                                      _dt(out), _stream()), "dass_bn_bwd_reduce_sums")
                 pg = torch.empty((2, k), dtype=torch.float32, device=dev)
                 dbeta, dgamma = pg[0], pg[1]
             elif need_red:
@@ -1136,8 +1206,16 @@ class _ConvBnAct(torch.autograd.Function):
                 # dgrad = stride-1 conv over dy with flipped/transposed taps; ustride re-inserts the stride
                 if dg_x3:
                     dy3 = x3_operand(dy, dy, lddy, m, kk)
-                    conv_x3_launch(dy3, w_t, dx, c, (n, oh, ow, kk, h, w, c, r, s, 1, pad_t, spec.dil), ustride=spec.stride,
-                                   residual=add_t, ldr=add_ld or 0)
+                    link = getattr(ctx, "in_link", None)
+                    if (link is not None and not link.dead and spec.stride == 1 and d_fork is None and ctx.x_dtype == dx.dtype
+                            and x3_parts() == 2):
+                        # dx is the d_out of the layer that produced this conv's input: its BN-backward sums ride in this
+                        # launch's epilogue (no separate pass over dx and that layer's conv output)
+                        conv_x3_dgrad_bnstats(dy3, w_t, dx, (n, oh, ow, kk, h, w, c, r, s, 1, pad_t, spec.dil), link, residual=add_t,
+                                              ldr=add_ld or 0)
+                    else:
+                        conv_x3_launch(dy3, w_t, dx, c, (n, oh, ow, kk, h, w, c, r, s, 1, pad_t, spec.dil), ustride=spec.stride,
+                                       residual=add_t, ldr=add_ld or 0)
                 else:
                     check(lib.dass_conv2d_igemm(_p(dy), lddy, _p(w_t), _p(dx), c, None, None, _p(add_t), add_ld or 0, None, n, oh, ow,
                                                 kk, h, w, c, r, s, 1, pad_t, spec.dil, spec.stride, ACT_NONE, _cdt(dx),

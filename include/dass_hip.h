@@ -193,6 +193,21 @@ int dass_conv2d_igemm_sums(const void *x, int64_t ldx, const void *w, void *y, i
 int dass_conv2d_x3_sums(const void *x3, const void *w3, void *y, int64_t ldy, int N, int H, int W, int C, int OH, int OW,
                         int K, int R, int S, int stride, int pad, int dil, double *stat_sums, void *workspace,
                         int64_t workspace_bytes, void *stream);
+/* dass_conv2d_x3_dgrad_bnstats: the input-gradient launch of a stride-1 conv (flipped / transposed weight operand and
+ * pad' = dil (R - 1) - pad, exactly as a dass_conv2d_x3 dgrad call; residual = gradient of a forked identity branch, nullable)
+ * whose output dx [N*OH*OW][K] IS the gradient d_out of the conv + BN (+ act) layer that produced this conv's input.  Its
+ * epilogue also adds THAT layer's BN-backward sums -- what dass_bn_bwd_reduce_sums computes in a pass of its own over dx and
+ * the layer's conv output bn_y [M][K] -- into bn_sums ([2][K] f64 + K floats, zeroed by the caller):  dz = dx * gate, gate from
+ * bn_gates (M * K / 4 bytes, bounds-checked against gates_bytes) or act'(fma(bn_y, gate_scale, gate_shift)).
+ * *fused = 1: sums complete (the layer's backward goes straight to dass_bn_bwd_apply_sums); 0: this launch's schedule cannot
+ * carry them (stream-K cut, tile without the whole-tile kernel) -- dx is complete, the caller runs dass_bn_bwd_reduce_sums.
+ * (The reduce half of F.batch_norm's backward, models/sync_batchnorm/batchnorm.py:62-71 via autograd, without its own read of
+ * the two tensors.) */
+int dass_conv2d_x3_dgrad_bnstats(const void *x3, const void *w3, void *y, int64_t ldy, const void *residual, int64_t ldr,
+                                 int N, int H, int W, int C, int OH, int OW, int K, int R, int S, int pad, int dil,
+                                 const float *bn_y, const float *bn_mean, const float *bn_invstd, const float *gate_scale,
+                                 const float *gate_shift, const void *bn_gates, int64_t gates_bytes, int bn_act,
+                                 double *bn_sums, int *fused, void *workspace, int64_t workspace_bytes, void *stream);
 int dass_channel_sums(const void *x, int64_t ldx, int64_t M, int K, double *sums, int dtype, void *stream);
 int dass_bn_apply_train(const void *x, int64_t ldx, void *out, int64_t ldo, const double *sums, double count,
                         const float *gamma, const float *beta, float *running_mean, float *running_var, float momentum,

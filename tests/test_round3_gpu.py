@@ -316,3 +316,103 @@ def test_fanout_sums_consumer_gradients_in_one_pass(n):
     assert torch.equal(x.grad, want)
     with torch.no_grad():
         assert all(o is x for o in ops.fanout(x, 3))   # nothing to sum when autograd is not recording
+
+
+# ------------------------------------------------------------------------------------------- BN-backward sums in the dgrad epilogue
+@pytest.mark.parametrize("backbone", ["resnet", "mobilenet"])
+def test_bn_backward_sums_fused_into_next_layers_input_gradient(backbone):
+    """dass_conv2d_x3_dgrad_bnstats: the input-gradient launch of layer L+1 adds layer L's BN-backward sums in its epilogue, and
+    L's backward then skips dass_bn_bwd_reduce_sums.  Same train step with the link on and off: the sums differ only in the order
+    of their f32-partial / f64 additions, so every parameter gradient must agree to ~1e-6 of its norm; and the fusion must
+    actually have happened (a silent fall-back to the separate pass would make this test vacuous)."""
+    ops, O, S = _setup()
+    from models.deeplab import DeepLab
+    from utils.loss import SegmentationLosses
+
+    keep = ops.f32_mma()
+    try:
+        ops.set_f32_mma("f16x3")
+        ncls, n, hw = 19, 4, 129
+        om = O.ODeepLab(backbone, 16, ncls)
+        O.fill_state_dict(om, seed=77, randomize_bn_stats=False)
+        x, lab = O.synthetic_batch(n, hw, hw, ncls, first_index=40)
+        m1, m2 = O.dropout_masks(n, 1, seed=5)
+        grads = {}
+        for on in (False, True):
+            ops.set_bn_link(on)
+            pm = DeepLab(backbone=backbone, output_stride=16, num_classes=ncls, sync_bn=False, pretrained=False)
+            pm.load_state_dict(om.state_dict())
+            pm = pm.cuda().train()
+            for key in ops.bn_link_counts:
+                ops.bn_link_counts[key] = 0
+            loss = SegmentationLosses(cuda=True).build_loss("ce")(pm(x.cuda(), dropout_masks=(m1[0].cuda(), m2[0].cuda())), lab.cuda())
+            loss.backward()
+            grads[on] = {k: p.grad.double().cpu() for k, p in pm.named_parameters()}
+            counts = dict(ops.bn_link_counts)
+            print(backbone, on, counts)
+            if on:
+                assert counts["fused"] >= (20 if backbone == "resnet" else 10), counts
+                assert counts["used"] == counts["fused"], counts   # every fused sum reached its layer (no orphan, no double use)
+            else:
+                assert counts == {"asked": 0, "fused": 0, "used": 0}
+        # (floor: aspp.bn_global_average_pool.bias has an exactly-zero true gradient -- a per-channel constant in front of a
+        # train-mode BN -- so what either run returns for it is rounding noise)
+        floor = 1e-3 * float(np.median([v.norm().item() for v in grads[False].values()]))
+        worst = max((grads[True][k] - grads[False][k]).norm().item() / max(grads[False][k].norm().item(), floor) for k in grads[True])
+        print("worst relative gradient difference", worst)
+        assert worst <= 2e-4, worst   # (measured 4e-5: 1e-7 differences in the sums, amplified by the BN layers downstream)
+    finally:
+        ops.set_bn_link(True)
+        ops.set_f32_mma(keep)
+
+
+@pytest.mark.parametrize("case", [(2, 33, 33, 256, 64, 1, True, "relu"), (2, 33, 33, 128, 256, 3, False, "relu6"), (1, 65, 65, 64, 64, 3, True, "gates"),
+                                  (8, 33, 33, 1024, 256, 1, False, "none")])
+def test_dgrad_bnstats_kernel_equals_separate_reduce(case):
+    """dass_conv2d_x3_dgrad_bnstats against dass_conv2d_x3 + dass_bn_bwd_reduce_sums on the same operands: identical dx, sums
+    equal up to the order of the additions, identical per-channel max |dz|"""
+    ops, O, S = _setup()
+    from dass_hip._lib import lib, check
+    import ctypes
+
+    n, h, w, c_out, c_in, ks, with_res, gate_kind = case   # the "conv" is the dgrad form: input dy [.., c_in], output dx [.., c_out]
+    keep = ops.f32_mma()
+    try:
+        ops.set_f32_mma("f16x3")
+        g = torch.Generator().manual_seed(11)
+        m = n * h * w
+        dy = torch.randn(m, c_in, generator=g).cuda()
+        wt = (torch.randn(c_out, ks, ks, c_in, generator=g) * 0.05).cuda()
+        res = torch.randn(m, c_out, generator=g).cuda() if with_res else None
+        y_l = torch.randn(m, c_out, generator=g).cuda()                     # the linked layer's conv output
+        mean = torch.randn(c_out, generator=g).cuda() * 0.1
+        invstd = (torch.rand(c_out, generator=g) + 0.5).cuda()
+        gsc = torch.randn(c_out, generator=g).cuda()
+        gsh = torch.randn(c_out, generator=g).cuda()
+        act = {"relu": ops.ACT_RELU, "relu6": ops.ACT_RELU6, "gates": ops.ACT_RELU, "none": ops.ACT_NONE}[gate_kind]
+        gates = (torch.randint(0, 16, (m, c_out // 4), generator=g, dtype=torch.uint8).cuda() if gate_kind == "gates" else None)
+        dy3 = ops.split3_rows(dy, c_in, m, c_in)
+        w3 = ops.prepare_conv_weight(wt, x3=True)
+        pad = (ks - 1) // 2
+        dims = (n, h, w, c_in, h, w, c_out, ks, ks, 1, pad, 1)
+        dx_ref = torch.empty(m, c_out, device="cuda")
+        ops.conv_x3_launch(dy3, w3, dx_ref, c_out, dims, residual=res, ldr=c_out if with_res else 0)
+        sums_ref = ops._bn_sums(c_out, dx_ref.device)
+        check(lib.dass_bn_bwd_reduce_sums(ops._p(dx_ref), c_out, None, c_out, ops._p(y_l), c_out, ops._p(mean), ops._p(invstd),
+                                          ops._p(gsc if gates is None else None), ops._p(gsh if gates is None else None), None, m, c_out, h * w, act,
+                                          ops._p(sums_ref), ops._p(gates), gates.numel() if gates is not None else 0, ops.F32, ops._stream()), "reduce")
+        link = ops.BnBwdLink(y_l, mean, invstd, gsc, gsh, gates, act, m, c_out)
+        dx = torch.empty(m, c_out, device="cuda")
+        assert ops.conv_x3_dgrad_bnstats(dy3, w3, dx, dims, link, residual=res, ldr=c_out if with_res else 0), "this shape must take the whole-tile kernel"
+        assert torch.equal(dx, dx_ref)
+        a, b = link.sums.cpu(), sums_ref.cpu()
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 1e-5 * scale, ((a - b).abs().max().item(), scale)
+        off = 2 * c_out
+        mx = lambda t: t.storage_offset()  # noqa: E731
+        base_a, base_b = link.sums._base if link.sums._base is not None else link.sums, sums_ref._base if sums_ref._base is not None else sums_ref
+        ma = base_a[mx(link.sums) + off: mx(link.sums) + off + (c_out + 1) // 2].view(torch.float32)[:c_out].cpu()
+        mb = base_b[mx(sums_ref) + off: mx(sums_ref) + off + (c_out + 1) // 2].view(torch.float32)[:c_out].cpu()
+        assert torch.equal(ma, mb)
+    finally:
+        ops.set_f32_mma(keep)

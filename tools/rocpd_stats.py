@@ -10,6 +10,11 @@ if "--after" in sys.argv:
     i = sys.argv.index("--after")
     after = (sys.argv[i + 1], int(sys.argv[i + 2]))
     del sys.argv[i:i + 3]
+by_grid = []
+while "--by-grid" in sys.argv:   # `--by-grid NAME`: launches of kernels matching NAME grouped by grid size (one row per layer shape)
+    i = sys.argv.index("--by-grid")
+    by_grid.append(sys.argv[i + 1])
+    del sys.argv[i:i + 2]
 db = sqlite3.connect(sys.argv[1])
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 cur = db.cursor()
@@ -32,3 +37,11 @@ if len(sys.argv) > 5:
     r = cur.execute("select count(*), avg(end - start), min(end - start), max(end - start) from kernels where %s like ? and grid_x = ?" % name_col,
                     ("%" + sub + "%", gx)).fetchone()
     print("\nlaunches of *%s* with grid_x=%d: n=%d avg %.1f us (min %.1f, max %.1f)" % (sub, gx, r[0], r[1] / 1e3, r[2] / 1e3, r[3] / 1e3))
+
+for sub in by_grid:
+    w2 = (where + " and " if where else " where ") + "%s like ?" % name_col
+    rs = cur.execute("select grid_x, grid_y, grid_z, count(*), avg(end - start), sum(end - start) from kernels%s group by grid_x, grid_y, grid_z order by 6 desc" % w2,
+                     ("%" + sub + "%",)).fetchall()
+    print("\nlaunches of *%s* by grid (threads): x y z | per step | avg us | ms/step" % sub)
+    for gx, gy, gz, n, avg, tot in rs[:40]:
+        print("  %8d %5d %3d | %6.1f | %7.1f | %6.3f" % (gx, gy, gz, n / steps, avg / 1e3, tot / 1e6 / steps))
