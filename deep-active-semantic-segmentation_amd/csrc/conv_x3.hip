@@ -1182,9 +1182,13 @@ static int dispatch_x3(X3P &p, hipStream_t st, long ws_bytes) {
         //  * short reductions: 64 x 64 tiles, three workgroups per CU.
         const long t256 = (long)((p.M + 255) / 256) * ((p.K + 127) / 128);
         const long s_tile = (long)p.CC * p.R * p.S;
-        if (p.K <= 64) pick = 4;
+        // (re-measured after the per-workgroup setup shrank to ~120 instructions, profiles/r03_x3_conv_sweep_f16.txt: whole 64 x 64
+        //  tiles now also win the K <= 64 and the 2-slab layers of layer 1 -- their stream-K form pays the general kernel's setup
+        //  and a fix-up pass -- and 256 x 128 whole tiles win where they give one well-filled round of 120..256 tiles)
+        if (p.K <= 64 || (t256 >= 4 * g_cus && s_tile <= 4)) { pick = 4; if (!mode) mode = 1; }
         else if (t256 >= 4 * g_cus) pick = 1;
         else if (s_tile >= 100) { pick = 1; if (!mode) mode = 2; }
+        else if (g_x3_parts == 2 && t256 >= 120 && t256 <= g_cus && s_tile >= 16) { pick = 1; if (!mode) mode = 1; }
         else { pick = 4; if (!mode) mode = 1; }  // short reductions: segments would be too short to amortise the fix-up
     }
     if (g_x3_parts == 2) {
