@@ -330,7 +330,7 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
     barrier()
     dt = max(tmax(time.perf_counter() - t0), 1e-9)
     res = {"train_ips": b * world * steps / dt, "ms_per_step": dt / max(steps, 1) * 1e3, "final_loss": float(loss.detach())}
-    if rank == 0:
+    if rank == 0 and steps > 0:
         log("[%s] train: %.2f images/s (%.1f ms/step)" % (dtype_name, res["train_ips"], res["ms_per_step"]))
 
     # ------------------------------------------------------------------ MC-dropout pool scoring (T passes)
@@ -365,7 +365,7 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
         barrier()
         dts = max(tmax(time.perf_counter() - t0), 1e-9)
         pool_ips = len(pool_keys) / dts
-        if rank == 0:
+        if rank == 0 and args.only != "coreset":
             log("[%s] mc-dropout T=%d: %.2f pool images/s (%d images)" % (dtype_name, args.mc_steps, pool_ips, len(pool_keys)))
         res["mc"] = {"metric": "mc_dropout_pool_images_per_s", "value": round(pool_ips, 3), "unit": "images/s",
                      "T": args.mc_steps, "pool_images": len(pool_keys),
