@@ -126,7 +126,11 @@ template <> struct Terms<3> { static constexpr int N = 6; static constexpr int P
 template <> struct Terms<2> { static constexpr int N = 3; static constexpr int PA[3] = {0, 1, 0}; static constexpr int PB[3] = {1, 0, 0}; };
 
 // fused epilogue of ONE 4-channel group of output pixel m (tile-independent: used by the main kernel and the fix-up pass)
-__device__ __forceinline__ void x3_store_out(const X3P &p, f32x4 v, int m, int k, int ohw, bool vec_ok, float y3_scale, float &vmax, bool phase) {
+// (pre: the caller already holds this lane's 4 scale / shift values and its residual in sc4 / sh4 / r4 -- loaded once per pass of
+// the epilogue, before the accumulators bounce through LDS -- instead of three dependent loads per 16-byte store)
+__device__ __forceinline__ void x3_store_out(const X3P &p, f32x4 v, int m, int k, int ohw, bool vec_ok, float y3_scale, float &vmax, bool phase,
+                                             bool pre = false, f32x4 sc4 = f32x4{1.f, 1.f, 1.f, 1.f}, f32x4 sh4 = f32x4{0.f, 0.f, 0.f, 0.f},
+                                             f32x4 r4 = f32x4{0.f, 0.f, 0.f, 0.f}) {
     float *y = reinterpret_cast<float *>(p.y);
     const float *res = reinterpret_cast<const float *>(p.res);
     long mo = m;  // output pixel index; differs from m only for a phase sub-grid
@@ -136,18 +140,16 @@ __device__ __forceinline__ void x3_store_out(const X3P &p, f32x4 v, int m, int k
         mo = ((long)n * p.OH + ohs * p.o_mul + p.oy_add) * p.OW + (rem - ohs * p.OWs) * p.o_mul + p.ox_add;
     }
     if (vec_ok) {
-        if (p.scale) v *= *reinterpret_cast<const f32x4 *>(p.scale + k);
-        if (p.shift) v += *reinterpret_cast<const f32x4 *>(p.shift + k);
-        if (res) v += *reinterpret_cast<const f32x4 *>(res + mo * p.ldr + k);
+        if (pre) {
+            v = v * sc4 + sh4 + r4;  // (same operation order as below: multiply, add shift, add residual, each rounded)
+        } else {
+            if (p.scale) v *= *reinterpret_cast<const f32x4 *>(p.scale + k);
+            if (p.shift) v += *reinterpret_cast<const f32x4 *>(p.shift + k);
+            if (res) v += *reinterpret_cast<const f32x4 *>(res + mo * p.ldr + k);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
-#if defined(X3_EXP) && X3_EXP == 10
-        if (y && v[0] == 12345.678f) *reinterpret_cast<f32x4 *>(y + mo * p.ldy + k) = v;
-#elif defined(X3_EXP) && X3_EXP == 11
-        if (y) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(y + mo * p.ldy + k));
-#else
         if (y) *reinterpret_cast<f32x4 *>(y + mo * p.ldy + k) = v;
-#endif
         if (p.y3) x3_store4r(p.y3, mo, p.cc_out, k, v, p.y3_parts, y3_scale);
 #pragma unroll
         for (int e = 0; e < 4; ++e) vmax = fmaxf(vmax, fabsf(v[e]));
@@ -292,10 +294,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     const bool complete = SIMPLE ? true : (s_lo == 0 && s_hi == S_tile);
     const int sk_seg = SIMPLE || round < dp_rounds ? 0 : seg_idx++;
     const int mt_i = p.ntiles == 1 ? tile : (int)((unsigned)tile / (unsigned)p.ntiles), nt_i = tile - mt_i * p.ntiles;
-    const int grp = SIMPLE || p.mt_per_group >= p.mtiles ? 0 : mt_i / p.mt_per_group;
-    const int m0 = SIMPLE ? mt_i * BM : grp * p.group_rows + (mt_i - grp * p.mt_per_group) * BM, n0 = nt_i * BN;
-    const int m_end = SIMPLE ? p.M : ((grp + 1) * p.group_rows < p.M ? (grp + 1) * p.group_rows : p.M);
-    if (!SIMPLE && p.cc_limit) {  // slabs are channel-slab major: dropping the slabs >= limit truncates the range
+    const int grp = p.mt_per_group >= p.mtiles ? 0 : (int)((unsigned)mt_i / (unsigned)p.mt_per_group);
+    const int m0 = grp * p.group_rows + (mt_i - grp * p.mt_per_group) * BM, n0 = nt_i * BN;
+    const int m_end = (grp + 1) * p.group_rows < p.M ? (grp + 1) * p.group_rows : p.M;
+    if (p.cc_limit) {  // slabs are channel-slab major: dropping the slabs >= limit truncates the range
         const int lim = p.cc_limit[grp] * ntaps;
         s_lo = s_lo < lim ? s_lo : lim;
         s_hi = s_hi < lim ? s_hi : lim;
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
         } else {
             int k = n0 + (q - AG) * 16 + r16;
             if (k >= p.K) k = p.K - 1;  // columns >= K are never stored: any finite row will do
-            rb_off[j] = (SIMPLE ? 0u : (unsigned)grp * p.w3_group_stride) + (unsigned)k * (unsigned)(ntaps * p.CC * SB) + chunk_off;
+            rb_off[j] = (unsigned)grp * p.w3_group_stride + (unsigned)k * (unsigned)(ntaps * p.CC * SB) + chunk_off;
         }
     }
 
@@ -769,7 +771,23 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
             f32x4 pf_y[SIMPLE ? ITS : 1], pf_r[SIMPLE ? ITS : 1];
             unsigned pf_g[SIMPLE ? ITS : 1];
             f32x4 ch_mu = {0.f, 0.f, 0.f, 0.f}, ch_is = ch_mu, ch_sc = ch_mu, ch_sh = ch_mu;
+            bool ep_pre = false;
             if constexpr (SIMPLE) {
+                if (!bstat && !plain && vec_ok) {  // fused epilogue (inference: scale / shift / residual / act / split rows out)
+                    ep_pre = true;
+                    const int kc = n0 + wn * TNW + ntp * 32 + (lane & (C4 - 1)) * 4;
+                    ch_sc = f32x4{1.f, 1.f, 1.f, 1.f};
+                    if (kc < p.K) {
+                        if (p.scale) ch_sc = *reinterpret_cast<const f32x4 *>(p.scale + kc);
+                        if (p.shift) ch_sh = *reinterpret_cast<const f32x4 *>(p.shift + kc);
+                    }
+#pragma unroll
+                    for (int it = 0; it < ITS; ++it) {
+                        const int mm = m0 + wm * TMW + mt * 32 + (it * 64 + lane) / C4;
+                        pf_r[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (res && mm < m_end && kc < p.K) pf_r[it] = *reinterpret_cast<const f32x4 *>(res + (long)mm * p.ldr + kc);
+                    }
+                }
                 if (bstat) {
                     const int kc = n0 + wn * TNW + ntp * 32 + (lane & (C4 - 1)) * 4;
                     if (kc < p.K) {
@@ -853,7 +871,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
                         continue;
                     }
                 }
-                x3_store_out(p, v, m, k, ohw, vec_ok, y3_scale, vmax, phase);
+                if constexpr (SIMPLE) x3_store_out(p, v, m, k, ohw, vec_ok, y3_scale, vmax, false, ep_pre, ch_sc, ch_sh, pf_r[it]);
+                else x3_store_out(p, v, m, k, ohw, vec_ok, y3_scale, vmax, phase);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1129,8 +1148,8 @@ template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE, int NP = 3> int 
         x3_set_magic(p.OHs * p.OWs, p.mg_ohw, p.sh_ohw);
         x3_set_magic(p.OWs, p.mg_ows, p.sh_ows);
     }
-    const bool simple = p.whole && p.o_mul == 1 && !p.cc_limit && p.group_rows == p.M;
-    constexpr bool has_simple = NP == 2 && ((BM == 64 && BN == 64 && NSTAGE == 2) || (BM == 256 && BN == 128));  // the production picks
+    const bool simple = p.whole && p.o_mul == 1;  // (per-image groups included: their tile -> rows map is two more multiplies)
+    constexpr bool has_simple = NP == 2 && ((BM == 64 && BN == 64) || (BM == 256 && BN == 128));  // the production picks
     if (p.bs_sums && !(has_simple && simple)) p.bs_sums = nullptr;  // not fused: the caller runs dass_bn_bwd_reduce_sums itself
     g_bn_fused = p.bs_sums ? 1 : 0;
     if constexpr (has_simple) {
@@ -1200,6 +1219,7 @@ static int dispatch_x3(X3P &p, hipStream_t st, long ws_bytes) {
         case 6: return launch_x3<64, 64, 2, 2, 3, 2>(p, st, mode, ws_bytes, true);
         case 7: return launch_x3<128, 128, 4, 2, 2, 2>(p, st, mode, ws_bytes, true);
         case 8: return launch_x3<256, 128, 4, 2, 3, 2>(p, st, mode, ws_bytes, true);  // three stages of 48 KB fit only in the two-part format
+        case 9: return launch_x3<64, 64, 2, 2, 4, 2>(p, st, mode, ws_bytes, true);   // four stages of 16 KB: three slabs in flight per workgroup
         default: return launch_x3<64, 64, 2, 2, 2, 2>(p, st, mode, ws_bytes, true);
         }
     }
