@@ -4,6 +4,7 @@ The reference is single-process nn.DataParallel: every forward it broadcasts all
 gathers logits on device 0.  Here each rank owns a full replica; the only training collective is the
 gradient average below, and the scoring collectives live in active_selection/base.py.
 """
+import os
 import torch
 
 
@@ -160,6 +161,12 @@ class GradientAverager(object):
         if not self.active:
             return
         self.world = dist.get_world_size()
+        from . import ops
+
+        if not os.environ.get("DASS_WGRAD_CHUNK"):
+            # deferred weight gradients would all appear when backward ENDS (one grouped launch): flush them in chunks of 36
+            # layers so that the first buckets' all-reduce runs under the rest of the pass
+            ops.set_wgrad_chunk(36)
         cap, cur, size = bucket_bytes // 4, [], 0
         for p in reversed(self.params):
             cur.append(p)

@@ -1245,7 +1245,8 @@ class _ConvBnAct(torch.autograd.Function):
 # written to `weight.grad` (accumulated if one exists) and the parameter's post-accumulate-grad hooks are fired, exactly what
 # autograd's AccumulateGrad node would have done; the Function itself returns None for the weight.  DASS_WGRAD_DEFER=0 /
 # set_deferred_wgrad(False): per-layer launches inside backward.
-_wg = {"on": os.environ.get("DASS_WGRAD_DEFER", "1") == "1", "queue": [], "armed": False, "pending": set()}
+_wg = {"on": os.environ.get("DASS_WGRAD_DEFER", "1") == "1", "queue": [], "armed": False, "pending": set(),
+       "chunk": int(os.environ.get("DASS_WGRAD_CHUNK", "0"))}
 
 
 def set_deferred_wgrad(on):
@@ -1263,7 +1264,18 @@ def wgrad_pending(p):
     return id(p) in _wg["pending"]
 
 
+def set_wgrad_chunk(n):
+    """> 0: the queue of deferred weight gradients is also flushed whenever it holds n layers (one grouped launch per chunk).
+    With more than one process the gradient all-reduce of the early chunks then overlaps the rest of backward instead of
+    starting when the pass ends (dist.GradientAverager sets 36: three launches per R101 backward); 0: one launch per pass."""
+    _wg["chunk"] = max(0, int(n))
+
+
 def _wgrad_enqueue(weight, x3, dy3, dwk, dims, k, c_in):
+    if _wg["chunk"] and len(_wg["queue"]) >= _wg["chunk"]:
+        # the layers already queued have returned from their backward, and autograd has run their (empty-handed) AccumulateGrad
+        # nodes -- those have the highest priority in the engine's ready queue -- so their hooks may fire for real now
+        _wgrad_flush(final=False)
     _wg["queue"].append((weight, x3, dy3, dwk, dims, k, c_in))
     _wg["pending"].add(id(weight))
     if not _wg["armed"]:
@@ -1271,12 +1283,15 @@ def _wgrad_enqueue(weight, x3, dy3, dwk, dims, k, c_in):
         torch.autograd.Variable._execution_engine.queue_callback(_wgrad_flush)
 
 
-def _wgrad_flush():
-    """runs once at the end of the backward pass that queued work (on the caller's stream)"""
+def _wgrad_flush(final=True):
+    """runs at the end of the backward pass that queued work (autograd's final callback, on the caller's stream), and for every
+    full chunk before that when set_wgrad_chunk() is on"""
     import numpy as np
 
     q = _wg["queue"]
-    _wg["queue"], _wg["armed"] = [], False
+    _wg["queue"] = []
+    if final:
+        _wg["armed"] = False
     if not q:
         return
     dev = q[0][3].device
@@ -1288,7 +1303,8 @@ def _wgrad_flush():
     scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
     check(lib.dass_conv2d_wgrad_x3_group(items.ctypes.data_as(ctypes.c_void_p), len(q), _p(scratch), scratch.numel(), _stream()),
           "dass_conv2d_wgrad_x3_group")
-    _wg["pending"] = set()
+    for item in q:
+        _wg["pending"].discard(id(item[0]))
     with torch.no_grad():
         done = {}
         for weight, x3, dy3, dwk, dims, k, c_in in q:

@@ -299,3 +299,47 @@ def test_deferred_grouped_wgrad_equals_per_layer_launches():
     assert all(v is not None for v in res[True].values())
     worst = max(((res[True][k] - g).norm().item() / max(g.norm().item(), 1e-12), k) for k, g in res[False].items())
     assert worst[0] <= 1e-4, worst   # (BN running statistics moved between the two runs' passes: train-mode batch statistics do not depend on them)
+
+
+def test_chunked_flush_of_deferred_wgrads_fires_every_hook_once():
+    """ops.set_wgrad_chunk(n): the queue of deferred weight gradients is flushed every n layers (what dist.GradientAverager asks
+    for with more than one process, so that the all-reduce of the first buckets runs under the rest of backward).  Same
+    gradients as the single launch at the end, and every parameter's post-accumulate hook counts exactly one REAL call --
+    calls made while `ops.wgrad_pending(p)` are autograd's empty-handed ones and are skipped, as the averager does."""
+    from dass_hip import ops
+    from models.deeplab import DeepLab
+    from oracle import deeplab_cpu as O
+    from utils.loss import SegmentationLosses
+
+    ncls, n, hw = 19, 2, 65
+    x, lab = O.synthetic_batch(n, hw, hw, ncls, first_index=90)
+    m1, m2 = O.dropout_masks(n, 1, seed=6)
+    crit = SegmentationLosses(cuda=True).build_loss("ce")
+    torch.manual_seed(9)
+    pm = DeepLab(backbone="resnet", output_stride=16, num_classes=ncls, sync_bn=False, pretrained=False).cuda().train()
+    calls = {}
+    handles = []
+    for name, p in pm.named_parameters():
+        def hook(q, name=name):
+            if ops.wgrad_pending(q):
+                return
+            assert q.grad is not None, name
+            calls[name] = calls.get(name, 0) + 1
+        handles.append(p.register_post_accumulate_grad_hook(hook))
+    res = {}
+    try:
+        for chunk in (0, 7):
+            ops.set_wgrad_chunk(chunk)
+            pm.zero_grad(set_to_none=True)
+            calls.clear()
+            crit(pm(x.cuda(), dropout_masks=(m1[0].cuda(), m2[0].cuda())), lab.cuda()).backward()
+            res[chunk] = {k: p.grad.detach().double().cpu() for k, p in pm.named_parameters()}
+            wrong = {k: v for k, v in calls.items() if v != 1}
+            missing = [k for k, _ in pm.named_parameters() if k not in calls]
+            assert not wrong and not missing, (chunk, wrong, missing[:5])
+    finally:
+        ops.set_wgrad_chunk(0)
+        for h in handles:
+            h.remove()
+    worst = max(((res[7][k] - g).norm().item() / max(g.norm().item(), 1e-12), k) for k, g in res[0].items())
+    assert worst[0] <= 1e-5, worst

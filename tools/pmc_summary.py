@@ -9,5 +9,5 @@ for d in sys.argv[1:]:
             name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])[:70]
             acc[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
 for (k, c), v in sorted(acc.items()):
-    if "conv" in k:
+    if "conv" in k or "wgrad" in k:
         print("%-72s %-30s %16.0f  (n=%d)" % (k, c, sum(v) / len(v), len(v)))
