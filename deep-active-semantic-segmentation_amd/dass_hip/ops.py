@@ -105,6 +105,22 @@ def mc_sparse():
     return _state.get("mc_sparse", True)
 
 
+_mc_side = {}
+
+
+def mc_side_streams(dev):
+    """the extra HIP streams the independent stochastic passes of DeepLab.mc_dropout_votes are dealt over
+    (DASS_MC_STREAMS = total number of streams, default 2; 1: none)"""
+    n = int(os.environ.get("DASS_MC_STREAMS", "2"))
+    if n <= 1 or torch.cuda.is_current_stream_capturing():
+        return []
+    key = (dev.index if dev.index is not None else torch.cuda.current_device())
+    sts = _mc_side.setdefault(key, [])
+    while len(sts) < n - 1:
+        sts.append(torch.cuda.Stream(device=dev))
+    return sts[:n - 1]
+
+
 def set_deterministic(on):
     """True: conv weight gradients are summed by ONE workgroup per tile in a fixed order (no cross-workgroup f32 atomics):
     bit-reproducible training steps, slower on layers with few output tiles.  Default False (DASS_DETERMINISTIC=1 to start on)."""

@@ -116,13 +116,41 @@ class DeepLab(nn.Module):
             masks = ((draws[0] >= p1).to(torch.float32) * (1.0 / (1.0 - p1)), (draws[1] >= p2).to(torch.float32) * (1.0 / (1.0 - p2)))
         masks = (masks[0].to(dev).float().contiguous(), masks[1].to(dev).float().contiguous())
         packs = self.decoder.head_mc_pack(prep, masks[0][:steps]) if prep is not None else None
-        for t in range(steps):
+
+        def one_pass(t):
             m1, m2 = masks[0][t], masks[1][t]
             if prep is not None:
                 low_res = self.decoder.head_mc_pass(feats, prep, m1, m2, packs[t] if packs is not None else None)
             else:
                 low_res = self.decoder.head(feats, in_scale=torch.cat((m1, ones48), dim=1), mask_as_in_scale=m2)
             ops.upsample_argmax(low_res, hh, ww, votes, t)
+
+        # The T passes are independent of each other.  Their two 3x3 convs are 1056 tiles of 256 x 128 on 256 CUs -- 4.1 rounds --
+        # so every launch ends with most of the chip idle; dealing the passes over DASS_MC_STREAMS (default 2) HIP streams lets another
+        # pass's launch fill that tail.  Pass 0 runs on the caller's stream (it also fills the operand caches the others read).
+        sides = ops.mc_side_streams(dev) if steps > 1 else []
+        one_pass(0)
+        if not sides:
+            for t in range(1, steps):
+                one_pass(t)
+            return votes
+        main = torch.cuda.current_stream(dev)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        for st in sides:
+            st.wait_event(fork)
+        lanes = [None] + sides  # None = the caller's stream
+        for t in range(1, steps):
+            st = lanes[t % len(lanes)]
+            if st is None:
+                one_pass(t)
+            else:
+                with torch.cuda.stream(st):
+                    one_pass(t)
+        for st in sides:
+            join = torch.cuda.Event()
+            join.record(st)
+            main.wait_event(join)
         return votes
 
     def freeze_bn(self):
