@@ -64,12 +64,51 @@ class ActiveSelectionMCDropout(ActiveSelectionBase):
         local, _ = self.local_slice(images)
         scores = []
         dev = next(self.unwrap(model).parameters()).device
-        for sample in self.make_loader(local, True):
-            image_batch = sample['image'].to(dev, non_blocking=True)
-            label_batch = sample['label'].to(dev, non_blocking=True)
-            votes = self._votes(model, image_batch, steps)
-            _, means = ops.vote_entropy(votes, label_batch, self.dataset_num_classes, want_map=False)
-            scores.append(means)
+        core = self.unwrap(model)
+        pre = None
+        if (type(self)._votes is ActiveSelectionMCDropout._votes  # (a subclass that overrides _votes -- fixed masks in the tests -- keeps its hook)
+                and hasattr(core, "mc_prefix") and not getattr(core.backbone, "mc_dropout", False) and not getattr(core, "noisy_features", False)
+                and core._bn_all_eval()):
+            pre = ops.mc_prefix_stream(dev)
+        if pre is None:
+            for sample in self.make_loader(local, True):
+                image_batch = sample['image'].to(dev, non_blocking=True)
+                label_batch = sample['label'].to(dev, non_blocking=True)
+                votes = self._votes(model, image_batch, steps)
+                _, means = ops.vote_entropy(votes, label_batch, self.dataset_num_classes, want_map=False)
+                scores.append(means)
+        else:
+            # Two-deep software pipeline over the batches: the deterministic prefix (backbone + ASPP: ~100 short launches that
+            # leave most CUs idle) of batch i + 1 runs on a second HIP stream under the T stochastic passes of batch i.
+            main = torch.cuda.current_stream(dev)
+
+            def start(sample):
+                image_batch = sample['image'].to(dev, non_blocking=True)
+                label_batch = sample['label'].to(dev, non_blocking=True)
+                ready = torch.cuda.Event()
+                ready.record(main)                      # the batch is on the device
+                pre.wait_event(ready)
+                with torch.cuda.stream(pre):
+                    state = core.mc_prefix(image_batch)
+                    done = torch.cuda.Event()
+                    done.record(pre)
+                for t in (state[0],) + tuple(x for x in (state[1] or ()) if torch.is_tensor(x)):
+                    t.record_stream(main)               # allocated on `pre`, read by the passes on `main`
+                image_batch.record_stream(pre)
+                return state, done, label_batch
+
+            loader = iter(self.make_loader(local, True))
+            nxt = next(loader, None)
+            cur = start(nxt) if nxt is not None else None
+            while cur is not None:
+                nxt = next(loader, None)
+                ahead = start(nxt) if nxt is not None else None
+                state, done, label_batch = cur
+                main.wait_event(done)
+                votes = core.mc_tail(state, steps)
+                _, means = ops.vote_entropy(votes, label_batch, self.dataset_num_classes, want_map=False)
+                scores.append(means)
+                cur = ahead
         local_scores = torch.cat(scores) if scores else torch.zeros((0,), dtype=torch.float32, device=dev)
         return self.gather(local_scores, len(images))
 

@@ -121,6 +121,18 @@ def mc_side_streams(dev):
     return sts[:n - 1]
 
 
+def mc_prefix_stream(dev):
+    """the HIP stream on which active_selection.mc_dropout runs the deterministic prefix of the NEXT batch under the stochastic
+    passes of the current one (DASS_MC_PIPELINE=0: none, batches strictly one after the other)"""
+    if os.environ.get("DASS_MC_PIPELINE", "1") != "1" or torch.cuda.is_current_stream_capturing():
+        return None
+    key = ("prefix", dev.index if dev.index is not None else torch.cuda.current_device())
+    st = _mc_side.get(key)
+    if st is None:
+        st = _mc_side[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
 def set_deterministic(on):
     """True: conv weight gradients are summed by ONE workgroup per tile in a fixed order (no cross-workgroup f32 atomics):
     bit-reproducible training steps, slower on layers with few output tiles.  Default False (DASS_DETERMINISTIC=1 to start on)."""

@@ -101,15 +101,27 @@ class DeepLab(nn.Module):
         the upsample/concat run ONCE; each pass re-runs last_conv with its masks folded into the conv
         loaders (upsample(m*x) == m*upsample(x)) and ends in the fused upsample+argmax kernel.
         masks: optional ([T,N,256], [T,N,256]) multipliers; default: Bernoulli draws like nn.Dropout2d."""
+        return self.mc_tail(self.mc_prefix(input), steps, masks=masks, generator=generator)
+
+    @torch.no_grad()
+    def mc_prefix(self, input):
+        """the deterministic part of mc_dropout_votes, run once per batch: backbone + ASPP + decoder features, and the share
+        of last_conv[0] that no mask touches.  -> state for mc_tail.  (Split out so that a caller scoring many batches can run
+        the prefix of batch i + 1 on another HIP stream while the T passes of batch i run: active_selection/mc_dropout.py)"""
         assert self._bn_all_eval(), "mc_dropout_votes needs eval-mode BN (model.eval() + dropout switched on)"
-        n, _, hh, ww = input.shape
-        dev = input.device
         feats = self.encoder_features(input)
+        # f32 tensors: the unmasked low-level channels' share of last_conv[0] is hoisted out of the T passes as well
+        prep = self.decoder.head_mc_prepare(feats) if feats.dtype == torch.float32 and feats.shape[1] == 304 else None
+        return feats, prep, tuple(input.shape)
+
+    @torch.no_grad()
+    def mc_tail(self, state, steps, masks=None, generator=None):
+        """the `steps` stochastic passes over a mc_prefix state -> uint8 votes [N, steps, H, W]"""
+        feats, prep, (n, _, hh, ww) = state
+        dev = feats.device
         p1, p2 = self.aspp.dropout.p, self.decoder.last_conv[6].p
         votes = torch.empty((n, steps, hh, ww), dtype=torch.uint8, device=dev)
         ones48 = torch.ones((n, 48), dtype=torch.float32, device=dev)
-        # f32 tensors: the unmasked low-level channels' share of last_conv[0] is hoisted out of the T passes as well
-        prep = self.decoder.head_mc_prepare(feats) if feats.dtype == torch.float32 and feats.shape[1] == 304 else None
         if masks is None:
             # all T x 2 Bernoulli draws in one launch sequence (8 tiny kernels per pass otherwise: ~40 us of a 1.4 ms pass)
             draws = torch.rand((2, steps, n, 256), device=dev, generator=generator)

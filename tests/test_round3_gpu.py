@@ -416,3 +416,49 @@ def test_dgrad_bnstats_kernel_equals_separate_reduce(case):
         assert torch.equal(ma, mb)
     finally:
         ops.set_f32_mma(keep)
+
+
+def test_pipelined_image_scores_equal_sequential_scores():
+    """active_selection.mc_dropout._image_scores: the prefix of batch i + 1 on a second HIP stream under the passes of batch i
+    (and the passes themselves dealt over two streams) must give exactly the scores of the strictly sequential run with the same
+    dropout draws -- a missing event or a block recycled across streams would show up as different votes"""
+    ops, O, S = _setup()
+    from active_selection.mc_dropout import ActiveSelectionMCDropout
+    from models.deeplab import DeepLab
+
+    ncls, hw, T = 19, 129, 4
+    torch.manual_seed(21)
+    pm = DeepLab(backbone="resnet", output_stride=16, num_classes=ncls, sync_bn=False, pretrained=False).cuda().eval()
+    pool = {("img_%03d" % i).encode("ascii"): O.synthetic_batch(1, hw, hw, ncls, first_index=300 + i) for i in range(10)}
+    keys = list(pool)
+
+    def factory(images, include_labels, bs=3):
+        for i in range(0, len(images), bs):
+            chunk = images[i:i + bs]
+            yield {"image": torch.cat([pool[k][0] for k in chunk]), "label": torch.cat([pool[k][1] for k in chunk])}
+
+    sel = ActiveSelectionMCDropout(ncls, None, hw, 3, loader_factory=factory)
+    res = {}
+    keep = {k: os.environ.get(k) for k in ("DASS_MC_PIPELINE", "DASS_MC_STREAMS")}
+    try:
+        for mode, (pipe, streams) in {"sequential": ("0", "1"), "pipelined": ("1", "2")}.items():
+            os.environ["DASS_MC_PIPELINE"], os.environ["DASS_MC_STREAMS"] = pipe, streams
+            torch.manual_seed(77)          # the same Bernoulli draws in both runs (torch.rand on the device, per batch)
+            torch.cuda.manual_seed(77)
+            from active_selection.mc_dropout import _turn_on_dropout
+            pm.apply(_turn_on_dropout)
+            for rep in range(3):           # repeated: a cross-stream race need not show on the first try
+                torch.manual_seed(77)
+                torch.cuda.manual_seed(77)
+                got = sel._image_scores(pm, keys, T).cpu()
+                res.setdefault(mode, []).append(got)
+            pm.eval()
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    for a in res["sequential"] + res["pipelined"]:
+        assert torch.equal(a, res["sequential"][0])
+    assert float(res["sequential"][0].max()) > 0.0
