@@ -52,13 +52,31 @@ class ActiveSelectionCoreSet(ActiveSelectionBase):
         dev = next(core.parameters()).device
         rows = []
         model.eval()
+        # The batches are independent and one encoder pass is ~100 short launches that leave most CUs idle: odd batches run on a
+        # second HIP stream, so two passes share the chip (DASS_MC_PIPELINE=0: one stream)
+        side = ops.mc_prefix_stream(dev)
+        main = torch.cuda.current_stream(dev)
+        used_side = False
         with torch.no_grad():
-            for sample in self.make_loader(local, False):
-                batch = sample['image'] if isinstance(sample, dict) else sample
-                feats = core.encoder_features(batch.to(dev))
-                pooled = ops.avgpool_features(feats, k, k // 2)
+            for i, sample in enumerate(self.make_loader(local, False)):
+                batch = (sample['image'] if isinstance(sample, dict) else sample).to(dev)
+                if side is not None and i % 2:
+                    ready = torch.cuda.Event()
+                    ready.record(main)   # the batch is on the device; operand caches filled by batch 0 are complete
+                    side.wait_event(ready)
+                    with torch.cuda.stream(side):
+                        pooled = ops.avgpool_features(core.encoder_features(batch), k, k // 2)
+                    pooled.record_stream(main)
+                    batch.record_stream(side)
+                    used_side = True
+                else:
+                    pooled = ops.avgpool_features(core.encoder_features(batch), k, k // 2)
                 assert pooled.shape[1] == feature_dim, pooled.shape
                 rows.append(pooled)
+            if used_side:
+                done = torch.cuda.Event()
+                done.record(side)
+                main.wait_event(done)
         local_feats = torch.cat(rows) if rows else torch.zeros((0, feature_dim), dtype=torch.float32, device=dev)
         return self.gather(local_feats, len(paths))
 
