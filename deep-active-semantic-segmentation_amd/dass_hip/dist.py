@@ -161,12 +161,8 @@ class GradientAverager(object):
         if not self.active:
             return
         self.world = dist.get_world_size()
-        from . import ops
-
-        if not os.environ.get("DASS_WGRAD_CHUNK"):
-            # deferred weight gradients would all appear when backward ENDS (one grouped launch): flush them in chunks of 36
-            # layers so that the first buckets' all-reduce runs under the rest of the pass
-            ops.set_wgrad_chunk(36)
+        # (deferred weight gradients are flushed in chunks during backward -- ops.set_wgrad_chunk, default 12 layers -- so the first
+        # buckets fill, and their all-reduce starts, long before the pass ends)
         cap, cur, size = bucket_bytes // 4, [], 0
         for p in reversed(self.params):
             cur.append(p)

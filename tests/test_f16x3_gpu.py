@@ -327,19 +327,23 @@ def test_chunked_flush_of_deferred_wgrads_fires_every_hook_once():
             calls[name] = calls.get(name, 0) + 1
         handles.append(p.register_post_accumulate_grad_hook(hook))
     res = {}
+    keep = (ops._wg["chunk"], ops._wg["side"])
     try:
-        for chunk in (0, 7):
-            ops.set_wgrad_chunk(chunk)
-            pm.zero_grad(set_to_none=True)
-            calls.clear()
-            crit(pm(x.cuda(), dropout_masks=(m1[0].cuda(), m2[0].cuda())), lab.cuda()).backward()
-            res[chunk] = {k: p.grad.detach().double().cpu() for k, p in pm.named_parameters()}
-            wrong = {k: v for k, v in calls.items() if v != 1}
-            missing = [k for k, _ in pm.named_parameters() if k not in calls]
-            assert not wrong and not missing, (chunk, wrong, missing[:5])
+        for chunk, side in ((0, False), (7, False), (7, True), (12, True)):   # (12, True) is the default
+            ops.set_wgrad_chunk(chunk, side)
+            for rep in range(2):   # twice: the second pass ACCUMULATES into .grad while side launches may still be running
+                if rep == 0:
+                    pm.zero_grad(set_to_none=True)
+                calls.clear()
+                crit(pm(x.cuda(), dropout_masks=(m1[0].cuda(), m2[0].cuda())), lab.cuda()).backward()
+                wrong = {k: v for k, v in calls.items() if v != 1}
+                missing = [k for k, _ in pm.named_parameters() if k not in calls]
+                assert not wrong and not missing, (chunk, side, rep, wrong, missing[:5])
+            res[(chunk, side)] = {k: p.grad.detach().double().cpu() for k, p in pm.named_parameters()}
     finally:
-        ops.set_wgrad_chunk(0)
+        ops.set_wgrad_chunk(*keep)
         for h in handles:
             h.remove()
-    worst = max(((res[7][k] - g).norm().item() / max(g.norm().item(), 1e-12), k) for k, g in res[0].items())
-    assert worst[0] <= 1e-5, worst
+    for key in res:
+        worst = max(((res[key][k] - g).norm().item() / max(g.norm().item(), 1e-12), k) for k, g in res[(0, False)].items())
+        assert worst[0] <= 1e-4, (key, worst)   # (BN running statistics move between the passes: batch statistics do not depend on them)
