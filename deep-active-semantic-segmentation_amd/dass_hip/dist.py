@@ -161,7 +161,7 @@ class GradientAverager(object):
         if not self.active:
             return
         self.world = dist.get_world_size()
-        # (deferred weight gradients are flushed in chunks during backward -- ops.set_wgrad_chunk, default 12 layers -- so the first
+        # (deferred weight gradients are flushed in chunks during backward -- ops.set_wgrad_chunk, default 16 layers -- so the first
         # buckets fill, and their all-reduce starts, long before the pass ends)
         cap, cur, size = bucket_bytes // 4, [], 0
         for p in reversed(self.params):

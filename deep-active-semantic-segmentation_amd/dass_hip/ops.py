@@ -1274,7 +1274,7 @@ class _ConvBnAct(torch.autograd.Function):
 # autograd's AccumulateGrad node would have done; the Function itself returns None for the weight.  DASS_WGRAD_DEFER=0 /
 # set_deferred_wgrad(False): per-layer launches inside backward.
 _wg = {"on": os.environ.get("DASS_WGRAD_DEFER", "1") == "1", "queue": [], "armed": False, "pending": set(),
-       "chunk": int(os.environ.get("DASS_WGRAD_CHUNK", "12")), "side": os.environ.get("DASS_WGRAD_SIDE", "1") == "1"}
+       "chunk": int(os.environ.get("DASS_WGRAD_CHUNK", "16")), "side": os.environ.get("DASS_WGRAD_SIDE", "1") == "1"}
 
 
 def set_deferred_wgrad(on):
@@ -1293,7 +1293,7 @@ def wgrad_pending(p):
 
 
 def set_wgrad_chunk(n, side=None):
-    """> 0 (default 12, DASS_WGRAD_CHUNK): the queue of deferred weight gradients is also flushed whenever it holds n layers -- one
+    """> 0 (default 16, DASS_WGRAD_CHUNK): the queue of deferred weight gradients is also flushed whenever it holds n layers -- one
     grouped launch per chunk, on a side stream beside the rest of backward (_wgrad_flush) -- and, with more than one process,
     the gradient all-reduce of the early chunks overlaps the rest of the pass instead of starting when it ends.
     0: one launch when the pass ends.  side: also switch the side stream on / off."""
@@ -1338,8 +1338,9 @@ def _wgrad_flush(final=True):
     """Runs at the end of the backward pass that queued work (autograd's final callback, on the caller's stream), and for every
     full chunk before that (set_wgrad_chunk).  A chunk flushed DURING backward is launched on a side HIP stream: the grouped
     launch (long workgroups, bound by load latency at 31 % MFMA busy) then shares the chip with the chain of short
-    input-gradient and BN launches that backward keeps issuing -- measured 32.7 -> 30.8 ms per R101 step with chunks of 12
-    (DASS_WGRAD_SIDE=0: chunks run on the caller's stream).  Its gradients are handed over (.grad, hooks) at the NEXT flush,
+    input-gradient and BN launches that backward keeps issuing -- measured 32.7 -> 30.8 ms per R101 step with chunks of 12-20
+    layers; every launch has a critical path of one 512-slab workgroup (~1.3 ms), so chunks of 8 or fewer make the side stream
+    the bottleneck (41.8 ms).  DASS_WGRAD_SIDE=0: chunks run on the caller's stream.  Its gradients are handed over (.grad, hooks) at the NEXT flush,
     after the caller's stream has waited for the side launch; the final flush hands over everything."""
     import numpy as np
 

@@ -329,7 +329,7 @@ def test_chunked_flush_of_deferred_wgrads_fires_every_hook_once():
     res = {}
     keep = (ops._wg["chunk"], ops._wg["side"])
     try:
-        for chunk, side in ((0, False), (7, False), (7, True), (12, True)):   # (12, True) is the default
+        for chunk, side in ((0, False), (7, False), (7, True), (16, True)):   # (16, True) is the default
             ops.set_wgrad_chunk(chunk, side)
             for rep in range(2):   # twice: the second pass ACCUMULATES into .grad while side launches may still be running
                 if rep == 0:
