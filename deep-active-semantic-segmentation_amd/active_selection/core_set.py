@@ -1,3 +1,4 @@
+import os
 """Core-set (k-center greedy) selection on the HIP path -- mirror of active_selection/core_set.py:12-69.
 
 Feature extraction stops at the 304-channel decoder feature map (the reference also runs last_conv and
@@ -52,15 +53,16 @@ class ActiveSelectionCoreSet(ActiveSelectionBase):
         dev = next(core.parameters()).device
         rows = []
         model.eval()
-        # The batches are independent and one encoder pass is ~100 short launches that leave most CUs idle: odd batches run on a
-        # second HIP stream, so two passes share the chip (DASS_MC_PIPELINE=0: one stream)
-        side = ops.mc_prefix_stream(dev)
+        # The batches are independent and one encoder pass is ~100 short launches that leave most CUs idle: the batches are dealt
+        # over DASS_CORESET_LANES (default 2; 3-4 measured 1040-1320 depending on how the streams map to hardware queues) HIP streams (DASS_MC_PIPELINE=0: one stream)
+        lanes = [None] + ops.extra_streams(dev, int(os.environ.get("DASS_CORESET_LANES", "2")) - 1)
         main = torch.cuda.current_stream(dev)
         used_side = False
         with torch.no_grad():
             for i, sample in enumerate(self.make_loader(local, False)):
                 batch = (sample['image'] if isinstance(sample, dict) else sample).to(dev)
-                if side is not None and i % 2:
+                side = lanes[i % len(lanes)] if i > 0 else None
+                if side is not None:
                     ready = torch.cuda.Event()
                     ready.record(main)   # the batch is on the device; operand caches filled by batch 0 are complete
                     side.wait_event(ready)
@@ -74,9 +76,10 @@ class ActiveSelectionCoreSet(ActiveSelectionBase):
                 assert pooled.shape[1] == feature_dim, pooled.shape
                 rows.append(pooled)
             if used_side:
-                done = torch.cuda.Event()
-                done.record(side)
-                main.wait_event(done)
+                for st in lanes[1:]:
+                    done = torch.cuda.Event()
+                    done.record(st)
+                    main.wait_event(done)
         local_feats = torch.cat(rows) if rows else torch.zeros((0, feature_dim), dtype=torch.float32, device=dev)
         return self.gather(local_feats, len(paths))
 

@@ -121,6 +121,17 @@ def mc_side_streams(dev):
     return sts[:n - 1]
 
 
+def extra_streams(dev, n):
+    """up to n more HIP streams on `dev` for independent batches (core_set._features); none when DASS_MC_PIPELINE=0"""
+    if n <= 0 or os.environ.get("DASS_MC_PIPELINE", "1") != "1" or torch.cuda.is_current_stream_capturing():
+        return []
+    key = ("lanes", dev.index if dev.index is not None else torch.cuda.current_device())
+    sts = _mc_side.setdefault(key, [])
+    while len(sts) < n:
+        sts.append(torch.cuda.Stream(device=dev))
+    return sts[:n]
+
+
 def mc_prefix_stream(dev):
     """the HIP stream on which active_selection.mc_dropout runs the deterministic prefix of the NEXT batch under the stochastic
     passes of the current one (DASS_MC_PIPELINE=0: none, batches strictly one after the other)"""
