@@ -382,7 +382,8 @@ extern "C" int dass_conv2d_wgrad_x3(const void *x3, const void *dy3, float *dw, 
 
 // ---- grouped launch (see wgrad_x3_group_kernel).  items: n x 16 int64 on the HOST
 //   {x3, dy3, dw, N, H, W, C, OH, OW, K, R, S, stride, pad, dil, 0};  dw must be zeroed (tiles are ADDED: big-M problems are still cut
-// into pixel ranges of at most DASS_WX3_GROUP_SLABS 32-pixel slabs, default 512, so no workgroup runs much longer than the
+// into pixel ranges of at most DASS_WX3_GROUP_SLABS 32-pixel slabs, default 96 (512 while one launch ran alone at the end of
+// backward; the chunked launches that now share the chip with the rest of backward want short workgroups: 31.4 -> 30.0 ms per step), so no workgroup runs much longer than the
 // rest).  scratch: device buffer of dass_conv2d_wgrad_x3_group_scratch_bytes(n) for the problem table (written by an
 // asynchronous copy on `stream`: keep it alive until the launches have run, do not reuse it for another call before that).
 extern "C" int64_t dass_conv2d_wgrad_x3_group_scratch_bytes(int n) { return (int64_t)(n > 0 ? n : 1) * (sizeof(WX3P) + 8) + 64; }
@@ -457,7 +458,7 @@ extern "C" int dass_conv2d_wgrad_x3_group(const int64_t *items, int n, void *scr
     if (!items || n <= 0 || !scratch || ((uintptr_t)scratch & 15)) return DASS_ERR_ARG;
     if (scratch_bytes < dass_conv2d_wgrad_x3_group_scratch_bytes(n)) return DASS_ERR_ARG;
     const int parts = dass_get_x3_parts(), SB = parts * 64;
-    static const long cap_slabs = getenv("DASS_WX3_GROUP_SLABS") ? atol(getenv("DASS_WX3_GROUP_SLABS")) : 512;
+    static const long cap_slabs = getenv("DASS_WX3_GROUP_SLABS") ? atol(getenv("DASS_WX3_GROUP_SLABS")) : 96;
     GroupItem *big = new GroupItem[n], *small = new GroupItem[n];
     int nb = 0, ns = 0, rc = DASS_OK;
     for (int i = 0; i < n && rc == DASS_OK; ++i) {
