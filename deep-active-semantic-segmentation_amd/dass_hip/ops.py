@@ -1318,6 +1318,12 @@ def _wgrad_enqueue(weight, x3, dy3, dwk, dims, k, c_in):
         # the layers already queued have returned from their backward, and autograd has run their (empty-handed) AccumulateGrad
         # nodes -- those have the highest priority in the engine's ready queue -- so their hooks may fire for real now
         _wgrad_flush(final=False)
+    task = torch._C._current_graph_task_id() if hasattr(torch._C, "_current_graph_task_id") else None
+    if task is not None and task != _wg.get("task"):
+        # first deferred gradient of a NEW backward pass.  Whatever is still queued belongs to a pass that never reached its
+        # final callback (an exception inside backward): drop it, and arm the callback again for this pass
+        _wg["task"] = task
+        _wg["queue"], _wg["inflight"], _wg["pending"], _wg["armed"] = [], [], set(), False
     _wg["queue"].append((weight, x3, dy3, dwk, dims, k, c_in))
     _wg["pending"].add(id(weight))
     if not _wg["armed"]:

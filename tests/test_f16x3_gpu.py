@@ -347,3 +347,43 @@ def test_chunked_flush_of_deferred_wgrads_fires_every_hook_once():
     for key in res:
         worst = max(((res[key][k] - g).norm().item() / max(g.norm().item(), 1e-12), k) for k, g in res[(0, False)].items())
         assert worst[0] <= 1e-4, (key, worst)   # (BN running statistics move between the passes: batch statistics do not depend on them)
+
+
+def test_deferred_wgrads_survive_a_backward_pass_that_raised():
+    """a backward pass that dies half-way never runs autograd's final callback: its queued weight gradients must not leak into the
+    next pass, and the next pass must arm its own callback (every parameter gets its gradient)"""
+    from dass_hip import ops
+    from models.deeplab import DeepLab
+    from oracle import deeplab_cpu as O
+    from utils.loss import SegmentationLosses
+
+    ncls, n, hw = 19, 2, 65
+    x, lab = O.synthetic_batch(n, hw, hw, ncls, first_index=95)
+    m1, m2 = O.dropout_masks(n, 1, seed=8)
+    crit = SegmentationLosses(cuda=True).build_loss("ce")
+    torch.manual_seed(3)
+    pm = DeepLab(backbone="resnet", output_stride=16, num_classes=ncls, sync_bn=False, pretrained=False).cuda().train()
+
+    def run(poison):
+        pm.zero_grad(set_to_none=True)
+        out = pm(x.cuda(), dropout_masks=(m1[0].cuda(), m2[0].cuda()))
+        if poison:
+            # an op in the middle of the graph whose backward raises (after the decoder / ASPP layers have queued their gradients)
+            def boom(g):
+                raise RuntimeError("injected failure")
+            handle = pm.backbone.layer4[0].bn1.weight.register_hook(boom)   # fires in the middle of the pass
+            try:
+                with pytest.raises(RuntimeError, match="injected failure"):
+                    crit(out, lab.cuda()).backward()
+            finally:
+                handle.remove()
+            return None
+        crit(out, lab.cuda()).backward()
+        return {k: (None if p.grad is None else p.grad.detach().double().cpu()) for k, p in pm.named_parameters()}
+
+    ref = run(False)
+    run(True)
+    got = run(False)
+    assert all(v is not None for v in got.values())
+    worst = max(((got[k] - g).norm().item() / max(g.norm().item(), 1e-12), k) for k, g in ref.items())
+    assert worst[0] <= 1e-4, worst
