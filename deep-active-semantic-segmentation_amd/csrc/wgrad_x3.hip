@@ -48,11 +48,16 @@ __device__ __forceinline__ v4i wmake_srd(const void *base, unsigned bytes) {
 }
 template <int N> __device__ __forceinline__ void wwait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// transposed LDS read issued through asm: the wait is the caller's (lgkmcnt counted by hand below)
-__device__ __forceinline__ v2u tr16(unsigned addr) {
-    v2u v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
-    return v;
+// transposed LDS read (ds_read_b64_tr_b16) through the builtin: the compiler folds the piece offsets into the instruction's
+// offset field, lands the two reads of a 16-byte MFMA operand directly in the halves of its register tuple and places the
+// lgkmcnt waits in front of the first use.  (The asm form this replaces cost a v_add per read and two v_mov_b64 per operand:
+// 662 instructions per 32-pixel slab around 24 MFMAs -- the loop was issue-bound, 31 % MFMA-busy.  The LDS-DMA stays in asm,
+// so the compiler has no reason to drain vmcnt in front of these reads.)
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ v4s tr16(unsigned addr) {
+    typedef __attribute__((address_space(3))) v4s *lds_ptr;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(size_t)addr);
 }
 
 // Tile BMK (out channels) x BNC (in channels); NW waves as WARPS_M x WARPS_N.  LDS stage = 32 pixels:
@@ -99,13 +104,13 @@ __device__ __forceinline__ void wgrad_x3_body(const WX3P &p, int wg, char *smem)
     const int lp = lane >> 2;                               // pixel row of the piece this lane fetches
     const unsigned chunk16 = (unsigned)((lane & 3) * 16);
     // pixel cursors: pixel (pbeg + 16 * half + lp) of the CURRENT slab to issue, advanced by 32 per slab
-    long cur_pix[2];
+    int cur_pix[2];  // (M < 2^31: checked by the host)
     int c_oh[2], c_ow[2];
     unsigned c_off[2];                                      // operand B: byte offset of the tap's input pixel row (x3)
     const int tap_dy = -p.pad + r * p.dil, tap_dx = -p.pad + s2 * p.dil;
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
-        cur_pix[hf] = pbeg + 16 * hf + lp;
+        cur_pix[hf] = (int)pbeg + 16 * hf + lp;
         const long pix = cur_pix[hf] < p.M ? cur_pix[hf] : 0;
         const int n = (int)(pix / ohw);
         const int rem = (int)(pix - (long)n * ohw);
@@ -117,14 +122,19 @@ __device__ __forceinline__ void wgrad_x3_body(const WX3P &p, int wg, char *smem)
     const unsigned adv_row = (unsigned)(p.stride * p.W - p.OW * p.stride) * p.x_pitch;
     const unsigned adv_img = (unsigned)(p.H * p.W - p.OH * p.stride * p.W) * p.x_pitch;
 
+    // 1 x 1, stride 1, no padding (two thirds of the layers): the input pixel IS the output pixel -- no cursor, no bounds
+    const bool same_pix = p.R * p.S == 1 && p.pad == 0 && p.stride == 1 && p.H == p.OH && p.W == p.OW;
+    const int pend32 = (int)pend;
     auto issue_slab = [&](int stage) {
         const unsigned st = smem_base + (unsigned)(stage * STAGE);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-            const bool live = cur_pix[hf] < pend;
+            const bool live = cur_pix[hf] < pend32;
             unsigned src;
             if (loads_a) {
                 src = live ? (unsigned)cur_pix[hf] * p.dy_pitch : p.dy_zero;
+            } else if (same_pix) {
+                src = live ? (unsigned)cur_pix[hf] * p.x_pitch : p.x_zero;
             } else {
                 const int iy = c_oh[hf] * p.stride + tap_dy, ix = c_ow[hf] * p.stride + tap_dx;
                 src = (live && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? c_off[hf] : p.x_zero;
@@ -142,7 +152,7 @@ __device__ __forceinline__ void wgrad_x3_body(const WX3P &p, int wg, char *smem)
             }
             // advance this cursor by 32 pixels
             cur_pix[hf] += 32;
-            if (!loads_a) {
+            if (!loads_a && !same_pix) {
                 c_ow[hf] += 32;
                 c_off[hf] += adv_px;
                 while (c_ow[hf] >= p.OW) {
@@ -180,11 +190,10 @@ __device__ __forceinline__ void wgrad_x3_body(const WX3P &p, int wg, char *smem)
             ++issued;
         }
 
-    // fragments of one 16-pixel k-step: [part][block][pixels 0-3 / 4-7 of this lane's half].  They stay in the registers
-    // the asm reads wrote until the explicit lgkmcnt wait (the compiler does not know these loads: cdna_hip_programming.md
-    // 5.7 form (iii)); the 16-B operands are assembled inside multiply(), after the wait.
-    v2u a0[NP][MT][2], b0[NP][NT][2], a1[NP][MT][2], b1[NP][NT][2];
-    auto load_frags = [&](unsigned abase, unsigned bbase, v2u(&a)[NP][MT][2], v2u(&b)[NP][NT][2]) {
+    // fragments of one 16-pixel k-step: [part][block][pixels 0-3 / 4-7 of this lane's half]; the two 8-byte reads of an MFMA
+    // operand land in the halves of its register tuple (tr16 above), the compiler waits for them in front of their first use.
+    v4s a0[NP][MT][2], b0[NP][NT][2], a1[NP][MT][2], b1[NP][NT][2];
+    auto load_frags = [&](unsigned abase, unsigned bbase, v4s(&a)[NP][MT][2], v4s(&b)[NP][NT][2]) {
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
@@ -199,8 +208,8 @@ __device__ __forceinline__ void wgrad_x3_body(const WX3P &p, int wg, char *smem)
             }
         }
     };
-    auto multiply = [&](const v2u(&a)[NP][MT][2], const v2u(&b)[NP][NT][2]) {
-        auto frag = [](const v2u(&f)[2]) { return make_uint4(f[0][0], f[0][1], f[1][0], f[1][1]); };
+    auto multiply = [&](const v4s(&a)[NP][MT][2], const v4s(&b)[NP][NT][2]) {
+        auto frag = [](const v4s(&f)[2]) { return __builtin_shufflevector(f[0], f[1], 0, 1, 2, 3, 4, 5, 6, 7); };
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int term = 0; term < NTERM; ++term)
@@ -210,7 +219,7 @@ __device__ __forceinline__ void wgrad_x3_body(const WX3P &p, int wg, char *smem)
                 for (int nt = 0; nt < NT; ++nt) {
                     // smallest products first.  NP = 3: (0,2) (2,0) (1,1) (0,1) (1,0) (0,0); NP = 2: (0,1) (1,0) (0,0)
                     constexpr int PA3[6] = {0, 2, 1, 0, 1, 0}, PB3[6] = {2, 0, 1, 1, 0, 0}, PA2[3] = {0, 1, 0}, PB2[3] = {1, 0, 0};
-                    const uint4 av = frag(a[NP == 3 ? PA3[term] : PA2[term % 3]][mt]), bv = frag(b[NP == 3 ? PB3[term] : PB2[term % 3]][nt]);
+                    const v8s av = frag(a[NP == 3 ? PA3[term] : PA2[term % 3]][mt]), bv = frag(b[NP == 3 ? PB3[term] : PB2[term % 3]][nt]);
                     if constexpr (NP == 3)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&av),
                                                                               *reinterpret_cast<const bf16x8 *>(&bv), acc[mt][nt], 0, 0, 0);
@@ -246,12 +255,10 @@ __device__ __forceinline__ void wgrad_x3_body(const WX3P &p, int wg, char *smem)
                 ++issued;
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a0 / b0 have landed (the asm reads are not counted by the compiler)
         __builtin_amdgcn_sched_barrier(0);
         load_frags(a_rd + so + 1024, b_rd + so + 1024, a1, b1);
         __builtin_amdgcn_sched_barrier(0);
         multiply(a0, b0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a1 / b1 have landed
         __builtin_amdgcn_sched_barrier(0);
         cur = cur + 1 == NSTAGE ? 0 : cur + 1;
         nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
