@@ -271,6 +271,24 @@ def test_abi_argument_checks_without_gpu():
     finally:
         assert L.dass_set_x3_parts(parts_before) == 0
     assert L.dass_set_x3_parts(5) == 1 and L.dass_get_x3_parts() == parts_before
+    # round-3 entry points: the input-gradient launch that carries a layer's BN-backward sums, and the n-way channel sum
+    fused = ctypes.c_int(7)
+    n, h, w, c, k = 1, 10, 10, 64, 64
+    dg = lambda **kw: L.dass_conv2d_x3_dgrad_bnstats(  # noqa: E731
+        p, p, kw.get("y", p), kw.get("ldy", k), None, 0, n, h, w, c, h, w, kw.get("K", k), 1, 1, 0, 1, kw.get("bn_y", p), p, p,
+        kw.get("gsc", p), p, kw.get("gates", None), kw.get("gbytes", 0), kw.get("act", 1), kw.get("sums", p), ctypes.byref(fused), None, 0, None)
+    assert dg(bn_y=None) == 1 and dg(sums=None) == 1 and dg(y=None) == 1
+    assert dg(ldy=k + 4) == 1                       # dx rows must be dense: the linked layer's conv output is indexed with K
+    assert dg(K=62) == 1                            # 16-byte groups of 4 channels
+    assert dg(gsc=None) == 1                        # an activation gate without stored bits needs the forward's scale / shift
+    assert dg(gates=p, gbytes=n * h * w * (k // 4) - 1) == 1   # gate-bit buffer shorter than M * K / 4
+    srcs = (ctypes.c_void_p * 2)(p.value, p.value)
+    lds = (ctypes.c_int64 * 2)(64, 64)
+    assert L.dass_sum_channels(None, lds, 2, p, 64, 10, 64, 0, None) == 1
+    assert L.dass_sum_channels(srcs, lds, 9, p, 64, 10, 64, 0, None) == 1      # at most 8 sources
+    assert L.dass_sum_channels(srcs, lds, 2, p, 64, 10, 62, 0, None) == 1      # C % 4
+    lds_bad = (ctypes.c_int64 * 2)(64, 66)
+    assert L.dass_sum_channels(srcs, lds_bad, 2, p, 64, 10, 64, 0, None) == 1  # a source stride that is not a multiple of 4
 
 
 def test_product_fails_loudly_without_gpu_or_library(tmp_path):
