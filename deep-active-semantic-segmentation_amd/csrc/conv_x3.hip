@@ -1236,6 +1236,14 @@ static int dispatch_x3(X3P &p, hipStream_t st, long ws_bytes) {
 
 }  // namespace
 
+/* the magic pair the pre-split conv kernel divides pixel indices with (x3_set_magic / x3_fastdiv above): exported so that the
+ * CPU test suite can check  (n * mul >> 32) >> shift == n / d  over the whole 31-bit range without a GPU */
+extern "C" int dass_x3_magic(int d, unsigned *mul, int *shift) {
+    if (d < 1 || !mul || !shift) return DASS_ERR_ARG;
+    x3_set_magic(d, *mul, *shift);
+    return DASS_OK;
+}
+
 extern "C" int dass_x3_force_tile(int tile) {
     g_x3_force = tile < 0 ? 0 : tile;
     return DASS_OK;

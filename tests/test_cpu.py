@@ -618,3 +618,29 @@ def test_config0_unet_oracle_matches_reference_fixture():
     losses = U.config0_steps(net, steps=3, lr=0.01)
     assert np.abs(np.asarray(losses) - g["losses"]).max() <= 1e-5
     assert losses[2] < losses[0]
+
+
+def test_x3_magic_division_is_exact_over_the_31_bit_range():
+    """the pre-split conv kernel decomposes an output-pixel index with (n * mul >> 32) >> shift instead of two 32-bit divisions
+    per row (csrc/conv_x3.hip x3_fastdiv; dass_x3_magic hands out the host-made pair).  Exact for every 0 <= n < 2^31: checked
+    here on all n near multiples of d, on random n, and at the ends of the range, for the divisors the DeepLab shapes produce
+    and for awkward ones (powers of two and their neighbours, primes, d = 1, d = 2^31 - 1)."""
+    import ctypes
+    from dass_hip import _lib
+
+    L = _lib.lib
+    rng = np.random.default_rng(5)
+    ds = [1, 2, 3, 5, 7, 9, 17, 33, 65, 129, 193, 257, 513, 1089, 4225, 16641, 37249, 66049, 263169, 591361,
+          1 << 10, (1 << 10) + 1, (1 << 20) - 1, 1 << 20, (1 << 20) + 1, 1000003, 1 << 30, (1 << 30) + 1, (1 << 31) - 1]
+    ds += [int(v) for v in rng.integers(2, 1 << 22, 200)]
+    mul, sh = ctypes.c_uint(0), ctypes.c_int(0)
+    assert L.dass_x3_magic(0, ctypes.byref(mul), ctypes.byref(sh)) == 1
+    for d in ds:
+        assert L.dass_x3_magic(d, ctypes.byref(mul), ctypes.byref(sh)) == 0
+        m, s = np.uint64(mul.value), sh.value
+        top = (1 << 31) - 1
+        near = (np.arange(0, 4096, dtype=np.int64) * max(1, top // d // 4096) * d)[:, None] + np.arange(-2, 3, dtype=np.int64)[None, :]
+        n = np.concatenate([near.ravel(), rng.integers(0, top, 20000), np.array([0, 1, d - 1, d, d + 1, top - 1, top], dtype=np.int64)])
+        n = n[(n >= 0) & (n <= top)].astype(np.uint64)
+        q = n if s < 0 else ((n * m) >> np.uint64(32)) >> np.uint64(s)
+        assert np.array_equal(q, n // np.uint64(d)), d
