@@ -11,19 +11,25 @@ A "step" is one pass of the hot path over one synthetic batch: zero_grad -> forw
 from per-image seeds and are resident in HBM before the timed region.  W untimed warm-up steps, then
 EXACTLY K timed steps between barrier + synchronize; the max over ranks is reported by rank 0 as ONE
 JSON line.  The headline (`value`, `dtype`) is the f32 PARITY mode -- the mode every parity test runs in
-(f32 tensors end to end, logits within 1e-3 of the reference, argmax bit-exact).  Its dense convs form every f32
-product exactly from three bf16 parts per operand on the bf16 MFMA pipe (`config.f32_mma` = "bf16x6", six MFMA
-products per f32 product, f32 accumulation; dass_hip/ops.py:set_f32_mma) -- results differ from the plain f32 MFMA
-only by summation order, and the roofline peak is priced accordingly (2500 / 6 TFLOP/s).  The same line carries
+(f32 tensors end to end, logits within 1e-3 of the reference, argmax bit-exact).  Its dense convs run the "f16x3" engine
+(`config.f32_mma`): every operand tensor is scaled by a power of two and split into two f16 parts (23 significant bits), three
+MFMA products per f32 product on the f16 pipe, f32 accumulation (dass_hip/ops.py:set_f32_mma) -- the f32 product to 2^-22, and
+the roofline peak is priced accordingly (2500 / 3 TFLOP/s); `--f32-mma bf16x6` selects the exact three-part bf16 engine.
+`--gpus N` with N > 1 and no torchrun environment starts N ranks itself (before anything touches the GPU) and relays rank 0's
+line; a WORLD_SIZE that contradicts --gpus is an error.  The same line carries
   mc_dropout  : pool-images/s of the T=10 MC-dropout vote-entropy scoring call on the same model over 376 pool images
                 per rank (config D's per-GPU share of the 2975-image pool is 372),
   core_set    : config E -- pooled decoder features of the same pool shard (images/s) and the k-center greedy selection
                 (k = 125, 50 pre-selected) on a [2975, 2736] feature matrix (seconds),
-  roofline    : `frac` = the TIME-WEIGHTED aggregate of every conv launch of one train step (forward, input gradient and
-                weight gradient of all 105 R101 conv layers timed with events on the launch stream: algorithmic FLOPs /
-                summed kernel time / MFMA peak of the engine); `best_launch` = the single best-case launch (decoder 3x3
-                304->256 @129^2) as reported in round 1; `sustained` = the same fractions against the bf16 MFMA rate the chip
-                actually holds under an all-CU MFMA load (profiles/r02_clock_probe.json),
+  roofline    : `frac` / `achieved` = the conv launches of the TIMED train step itself: after the timed region three more steps
+                run with HIP events around every conv / weight-gradient entry point of the C-ABI, recorded on the stream each
+                launch goes to (dass_hip/_lib.py:KernelTimer); achieved = algorithmic conv FLOPs of the step / the SUM of those
+                launch durations (launches on the main and the side stream overlap: summed, as in a rocprofv3 kernel table --
+                profiles/r04_train_summary.md is that table for the same command), `by_kernel` splits it by entry point and tile
+                class, `dominant` is the class with the most time.  `isolated` keeps the former microbenchmark (every layer shape
+                launched back to back on an idle chip: a ceiling, not what the step achieves), `best_launch` the single best-case
+                launch (decoder 3x3 304->256 @129^2), `sustained` the same fractions against the MFMA rate the chip actually holds
+                under an all-CU MFMA load (profiles/r02_clock_probe.json), `train_step_frac` the whole step against the peak,
   cpu_baseline: the CPU oracle (stock PyTorch fp32 restatement, oracle/) timed on this box's host cores on bounded
                 samples (rank 0, N=1 only): (i) train steps, (ii) 10-pass MC-dropout the reference way (T full forwards)
                 and with the deterministic prefix hoisted, (iii) core-set features + sklearn fp64 k-center on the SAME
@@ -256,6 +262,42 @@ def conv_aggregate(args, ops, tdt):
             "gflop": round(3 * gflop, 1), "achieved": round(3 * gflop / ms, 2)}
 
 
+def _tile_tag(name, tag):
+    if not tag:
+        return name.replace("dass_conv2d_", "")
+    bm, bn = tag >> 16, (tag >> 4) & 0xfff
+    form = "whole-tile" if tag & 2 else ("stream-K + fix-up" if tag & 1 else "general")
+    return "%s: conv_x3_kernel<%d,%d> %s" % (name.replace("dass_conv2d_", ""), bm, bn, form)
+
+
+def step_conv_times(train_step, reps=3):
+    """the conv / weight-gradient launches of `reps` real train steps, timed where they run (KernelTimer: HIP events on each
+    launch's own stream) -> per-step totals and a per-(entry point, tile class) table"""
+    from dass_hip._lib import CONV_ENTRY_POINTS, KernelTimer
+
+    with KernelTimer(CONV_ENTRY_POINTS) as kt:
+        train_step()                      # (events on: first step untimed -- event pools, allocator)
+        torch.cuda.synchronize()
+        kt.rows()
+        for _ in range(reps):
+            train_step()
+        torch.cuda.synchronize()
+        rows = kt.rows()
+    by = {}
+    for name, tag, gflop, ms in rows:
+        e = by.setdefault(_tile_tag(name, tag), [0, 0.0, 0.0])
+        e[0] += 1
+        e[1] += gflop
+        e[2] += ms
+    table = [{"kernel": k, "launches_per_step": round(v[0] / reps, 1), "gflop_per_step": round(v[1] / reps, 1),
+              "ms_per_step": round(v[2] / reps, 3), "avg_us": round(1e3 * v[2] / v[0], 1),
+              "tflops": round(v[1] / v[2], 1) if v[2] > 0 else None} for k, v in by.items()]
+    table.sort(key=lambda r: -r["ms_per_step"])
+    gflop = sum(r[2] for r in rows) / reps
+    ms = sum(r[3] for r in rows) / reps
+    return {"gflop": gflop, "ms": ms, "launches": len(rows) / reps, "table": table}
+
+
 def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
     """train leg + MC-dropout leg + dominant-kernel timing in one numerics mode (mma: conv engine for f32 tensors)"""
     from dass_hip import ops
@@ -415,6 +457,10 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
     b = args.batch  # (the scoring legs may have used --mc-batch)
     # ------------------------------------------------------------------ roofline of the dominant kernel
     res["roofline"] = None
+    inst = None
+    if not args.no_roofline and args.backbone != "mobilenet" and steps > 0:
+        model.train()
+        inst = step_conv_times(train_step)   # on EVERY rank: the step holds collectives when N > 1
     if rank == 0 and not args.no_roofline and args.backbone == "mobilenet":
         nbytes, conv_e, bn_e = mobilenet_train_bytes(b, s, args.classes)
         gbs = nbytes / (res["ms_per_step"] * 1e-3) / 1e9
@@ -423,7 +469,7 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
                            "algorithmic_bytes_per_step": nbytes,
                            "note": "f32 tensors; 3 x (in + out) x 4 B per conv layer and pass + 4 BN passes per train-mode BN tensor (SURVEY 8d); "
                                    "per-family kernel times: profiles/r03_train_C_mbv2_summary.md"}
-    elif rank == 0 and not args.no_roofline:
+    elif rank == 0 and inst is not None:
         tdt = torch.bfloat16 if engine == "bf16" else torch.float32
         n_, h_, c_, k_ = b, (s + 3) // 4, 304, 256  # decoder.last_conv.0: 3x3 304->256 @129^2, the largest single layer
         x = torch.randn((n_, h_, h_, c_), device=dev).to(tdt)
@@ -469,8 +515,13 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
         launch = x3_ = None
         del x, w, y
         agg = conv_aggregate(args, ops, tdt)
-        log("[%s] all conv launches of one train step: %.2f ms (fwd %.2f, dgrad %.2f, wgrad %.2f) = %.1f TFLOP/s"
+        log("[%s] isolated: all conv launches of one train step back to back on an idle chip: %.2f ms (fwd %.2f, dgrad %.2f, wgrad %.2f) = %.1f TFLOP/s"
             % (dtype_name, agg["ms_per_step"], agg["fwd_ms"], agg["dgrad_ms"], agg["wgrad_ms"], agg["achieved"]))
+        in_step = inst["gflop"] / inst["ms"]
+        log("[%s] in-step: %d conv launches per train step, %.2f ms of launch time (streams overlap) for %.0f GFLOP = %.1f TFLOP/s"
+            % (dtype_name, inst["launches"], inst["ms"], inst["gflop"], in_step))
+        for r in inst["table"][:6]:
+            log("    %-70s %5.1f x %7.1f us = %6.2f ms  %s TFLOP/s" % (r["kernel"], r["launches_per_step"], r["avg_us"], r["ms_per_step"], r["tflops"]))
         sustained = None
         cfile = os.path.join(ROOT, "profiles", "r02_clock_probe.json")
         if os.path.exists(cfile) and engine != "f32":
@@ -478,16 +529,28 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
             div = {"bf16x6": 6.0, "bf16x3": 3.0, "f16x3": 3.0, "bf16": 1.0}[engine]
             speak = cp["sustained_bf16_mfma_peak_tflops"] / div
             sustained = {"clock_ghz": cp["sustained_clock_ghz_all_cus_lds_fed"], "peak": round(speak, 1),
-                         "frac": round(agg["achieved"] / speak, 4), "best_launch_frac": round(achieved / speak, 4),
+                         "frac": round(in_step / speak, 4), "isolated_frac": round(agg["achieved"] / speak, 4),
+                         "best_launch_frac": round(achieved / speak, 4),
                          "note": "bf16 MFMA rate at the shader clock the chip holds with all 256 CUs in an LDS-fed MFMA loop "
                                  "(tools/clock_probe.py, profiles/r02_clock_probe.json); the nominal peak assumes 2.4 GHz"}
-        res["roofline"] = {"bound": "mfma", "kernel": "every groups=1 conv launch of one train step (105 layers x fwd/dgrad/wgrad), time-weighted",
-                           "achieved": agg["achieved"], "peak": peak, "peak_note": PEAK_NOTE[engine], "unit": "TFLOP/s",
-                           "frac": round(agg["achieved"] / peak, 4), "traffic": traffic,
+        dom = inst["table"][0]
+        res["roofline"] = {"bound": "mfma",
+                           "kernel": "every conv / weight-gradient launch of the timed train step (HIP events on each launch's stream, "
+                                     "3 steps after the timed region; durations of overlapping launches summed)",
+                           "achieved": round(in_step, 2), "peak": peak, "peak_note": PEAK_NOTE[engine], "unit": "TFLOP/s",
+                           "frac": round(in_step / peak, 4), "traffic": traffic,
                            "traffic_note": "HBM bytes of the best_launch shape from the committed rocprofv3 --pmc passes (%s)" % os.path.basename(tfile),
-                           "conv_ms_per_step": agg["ms_per_step"], "conv_gflop_per_step": agg["gflop"],
-                           "conv_ceiling_ms_per_step": round(agg["gflop"] / peak, 3),
-                           "split_ms": {"fwd": agg["fwd_ms"], "dgrad": agg["dgrad_ms"], "wgrad": agg["wgrad_ms"]},
+                           "conv_ms_per_step": round(inst["ms"], 3), "conv_gflop_per_step": round(inst["gflop"], 1),
+                           "conv_launches_per_step": round(inst["launches"], 1),
+                           "conv_ceiling_ms_per_step": round(inst["gflop"] / peak, 3),
+                           "by_kernel": inst["table"],
+                           "dominant": {"kernel": dom["kernel"], "ms_per_step": dom["ms_per_step"], "avg_us": dom["avg_us"],
+                                        "achieved": dom["tflops"], "frac": round(dom["tflops"] / peak, 4) if dom["tflops"] else None},
+                           "isolated": {"note": "every layer shape launched 5x back to back on an idle chip, operands prepared outside the timing: a "
+                                                "ceiling for the kernels, NOT what the step achieves",
+                                        "achieved": agg["achieved"], "frac": round(agg["achieved"] / peak, 4), "conv_ms_per_step": agg["ms_per_step"],
+                                        "conv_gflop_per_step": agg["gflop"],
+                                        "split_ms": {"fwd": agg["fwd_ms"], "dgrad": agg["dgrad_ms"], "wgrad": agg["wgrad_ms"]}},
                            "best_launch": best, "sustained": sustained,
                            "train_step_frac": round(res["train_ips"] * TRAIN_GFLOP_PER_IMAGE / 1e3 / (peak * world), 4)}
     del model, optimizer
@@ -605,6 +668,9 @@ def cpu_baseline(args):
     out = {"value": round(2 * nsteps / dtc, 4), "unit": "images/s", "cores": cores, "cores_available": cores_box,
            "cores_host": os.cpu_count(), "kind": "port",
            "by_threads": {str(t): round(v[0], 4) for t, v in by_threads.items()},
+           "threads_note": "SURVEY 8d asks for os.cpu_count() threads; the box's cgroup grants %d of the host's %s cores, and stock PyTorch's "
+                           "intra-op pool gets SLOWER beyond ~16 threads on these layer sizes (see by_threads), so the leg is timed at 16 and at "
+                           "min(granted, 64) threads and the faster one is `value` / `cores`" % (cores_box, os.cpu_count()),
            "sample": "%d train steps (fwd+CE+bwd+SGD) of batch 2 = %d images, %s %dx%d, stock PyTorch CPU fp32 "
                      "(oracle/deeplab_cpu.py), %.1f s" % (nsteps, 2 * nsteps, args.backbone, s, s, dtc)}
     del oopt
@@ -664,8 +730,34 @@ def cpu_baseline(args):
     return out
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a torchrun environment: start N ranks (one per GPU) through torch.distributed.run as a
+    CHILD process -- this parent has not touched the GPU and never does -- relay its output, exit with its code"""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    log("--gpus %d without WORLD_SIZE: launching %s" % (args.gpus, " ".join(cmd[1:8])))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args))       # (before any GPU call in this process)
+    if world_env is not None and int(world_env) != args.gpus:
+        print("bench.py: --gpus %d contradicts WORLD_SIZE=%s (launch with --nproc-per-node %d, or drop the launcher and let "
+              "`--gpus N` start the ranks)" % (args.gpus, world_env, args.gpus), file=sys.stderr)
+        sys.exit(2)
     env = Env()
     env.rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -262,18 +262,29 @@ __global__ __launch_bounds__(256) void bn_apply_train_kernel(const T *__restrict
     if (out3 && parts == 2) {
         // Two-part x3 output: the per-tensor scale needs a bound of |out| BEFORE any element is written.  Batch statistics give
         // one for free (Samuelson): |x - mean| <= std * sqrt(M - 1) for every sample, so per channel |gamma * xhat + beta| <=
-        // |gamma| * sqrt(M - 1) + |beta|; a residual adds its own bound, ReLU6 caps at 6, a Dropout2d multiplier is <= 4.
+        // |gamma| * sqrt(M - 1) + |beta|; a residual adds its own bound, ReLU6 caps at 6, a Dropout2d mask multiplies by its largest entry.
         // Loose by ~sqrt(M) / (the batch's true max |xhat|, ~5): 2^4 .. 2^6 -- harmless (dass_common.h), and the same in every block.
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o, 64));
-        if ((threadIdx.x & 63) == 0) s_bnd[0][threadIdx.x >> 6] = gmax;
+        // the Dropout2d multipliers' true maximum (1 / (1 - p), any p): [images][K] floats, a few KB from L2 per block
+        float nmax = 0.f;
+        if (nc_scale) {
+            const long nimg = (M + rows_per_image - 1) / rows_per_image;
+            for (long i = threadIdx.x; i < nimg * K; i += blockDim.x) nmax = fmaxf(nmax, fabsf(nc_scale[i]));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) nmax = fmaxf(nmax, __shfl_xor(nmax, o, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            s_bnd[0][threadIdx.x >> 6] = gmax;
+            s_bnd[1][threadIdx.x >> 6] = nmax;
+        }
     }
     __syncthreads();
     if (out3 && parts == 2) {
         const float gm = fmaxf(fmaxf(s_bnd[0][0], s_bnd[0][1]), fmaxf(s_bnd[0][2], s_bnd[0][3]));
         float bound = 1.25f * gm + (res_bound ? *res_bound : 0.f);
         if (act == DASS_ACT_RELU6) bound = fminf(bound, 6.f);
-        if (nc_scale) bound *= 4.f;
+        if (nc_scale) bound *= fmaxf(fmaxf(s_bnd[1][0], s_bnd[1][1]), fmaxf(s_bnd[1][2], s_bnd[1][3]));
         x3s = x3_scale_of(bound);
         if (blockIdx.x == 0) x3_zero_row(out3, M, (K + 31) >> 5, 2, x3_inv_of(x3s), bound);
     } else if (out3 && blockIdx.x == 0) {

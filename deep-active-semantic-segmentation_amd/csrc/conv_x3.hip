@@ -1109,6 +1109,7 @@ __global__ __launch_bounds__(256) void absmax_rows_kernel(const float *__restric
 
 static int g_cus = 0;
 static int g_bn_fused = 0;  // did the last launch_x3 fuse the BN-backward sums it was asked for? (read back by the entry point)
+static int g_last_pick = 0;  // (BM << 16) | (BN << 4) | 2 * whole-tile kernel | stream-K: the schedule of the last launch_x3 (dass_x3_last_pick)
 static int g_x3_parts = 3;  // operand format of the pre-split kernels: 3 = bf16 triple (bf16x6 engine), 2 = scaled f16 pair (f16x3 engine)  // compute units of the current device (stream-K launches one workgroup per resident slot)
 
 template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE, int NP = 3> int launch_x3(X3P &p, hipStream_t st, int mode, long ws_bytes, bool m16) {
@@ -1152,6 +1153,7 @@ template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE, int NP = 3> int 
     constexpr bool has_simple = NP == 2 && ((BM == 64 && BN == 64) || (BM == 256 && BN == 128));  // the production picks
     if (p.bs_sums && !(has_simple && simple)) p.bs_sums = nullptr;  // not fused: the caller runs dass_bn_bwd_reduce_sums itself
     g_bn_fused = p.bs_sums ? 1 : 0;
+    g_last_pick = (BM << 16) | (BN << 4) | ((has_simple && simple) ? 2 : 0) | (stream ? 1 : 0);
     if constexpr (has_simple) {
         if (simple) {
             hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE, true, NP, true>), dim3(p.sk_wgs), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
@@ -1243,6 +1245,10 @@ extern "C" int dass_x3_magic(int d, unsigned *mul, int *shift) {
     x3_set_magic(d, *mul, *shift);
     return DASS_OK;
 }
+
+/* which kernel the LAST pre-split conv launch of this process ran: (BM << 16) | (BN << 4) | 2 (whole-tile specialisation) | 1 (stream-K
+ * schedule + fix-up pass).  Diagnostic only (bench.py attributes in-step launch times to tile classes with it); host state, no stream */
+extern "C" int dass_x3_last_pick(void) { return g_last_pick; }
 
 extern "C" int dass_x3_force_tile(int tile) {
     g_x3_force = tile < 0 ? 0 : tile;

@@ -182,12 +182,16 @@ class GradientAverager(object):
         self.pending = [len(ps) for ps in self.buckets]
         self.next = 0
         self.works = []
+        self.seen = set()
 
     def _hook(self, p):
         from . import ops
 
         if ops.wgrad_pending(p):  # its gradient is still queued for the grouped launch (ops._wgrad_flush calls again when it is set)
             return
+        if id(p) in self.seen:    # counted once per pass: a weight used through the deferred AND the generic path (or a module
+            return                # applied twice) fires this hook more than once
+        self.seen.add(id(p))
         bi = self.where[id(p)]
         self.pending[bi] -= 1
         self._launch_ready()

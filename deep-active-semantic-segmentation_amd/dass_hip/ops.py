@@ -284,14 +284,18 @@ class BnBwdLink:
     (dass_conv2d_x3_dgrad_bnstats): attached to the layer's output tensor by the forward, claimed by the single dense conv that
     consumes it; that conv's backward fills `sums` and remembers which tensor it returned, the layer's own backward takes the
     sums only if exactly that tensor arrives as its d_out (autograd hands a lone gradient through untouched; a second consumer
-    would make it a sum in a new tensor)."""
-    __slots__ = ("y_raw", "mean", "invstd", "gsc", "gsh", "gates", "act", "m", "k", "claimed", "dead", "sums", "dx_ptr")
+    would make it a sum in a new tensor).  The link keeps a STRONG reference to that tensor (`dx`) until the layer's backward
+    has looked at it: autograd's InputBuffer adds a second gradient IN PLACE (`old_var.add_(var)`) when it holds the last
+    reference to the first one -- same address, different contents -- and a live reference here makes that impossible, so a
+    consumer the link cannot see (a `residual=` use, concat, pooling, user code) always shows up as a different pointer."""
+    __slots__ = ("y_raw", "mean", "invstd", "gsc", "gsh", "gates", "act", "m", "k", "claimed", "dead", "sums", "dx_ptr", "dx")
 
     def __init__(self, y_raw, mean, invstd, gsc, gsh, gates, act, m, k):
         self.y_raw, self.mean, self.invstd, self.gsc, self.gsh, self.gates, self.act, self.m, self.k = y_raw, mean, invstd, gsc, gsh, gates, act, m, k
         self.claimed = self.dead = False
         self.sums = None
         self.dx_ptr = 0
+        self.dx = None
 
 
 _BN_LINK = os.environ.get("DASS_BN_LINK", "1") == "1"  # BN-backward sums ride in the epilogue of the next layer's input-gradient launch
@@ -319,7 +323,7 @@ def conv_x3_dgrad_bnstats(dy3, w_t, dx, dims, link, residual=None, ldr=0):
     bn_link_counts["asked"] += 1
     if fused.value:
         bn_link_counts["fused"] += 1
-        link.sums, link.dx_ptr = sums, dx.data_ptr()
+        link.sums, link.dx_ptr, link.dx = sums, dx.data_ptr(), dx
     return bool(fused.value)
 
 
@@ -866,6 +870,9 @@ class _ConvBnAct(torch.autograd.Function):
         res_t = ldr = None
         if residual is not None:
             res_t, ldr = rows(_cast_act(residual))
+            rl = residual.__dict__.get("_dass_bnlink") if hasattr(residual, "__dict__") else None
+            if rl is not None:
+                rl.dead = True  # a consumer the link's launch does not see: the layer's d_out will be a sum
         kpad = _pad_to(k, _epv(dt))
         if kpad != k:  # e.g. the 19-class classifier: keep a zero pad column so rows stay 16-B aligned
             out = zeros_act(n, kpad, oh, ow, dt, dev)[:, :k]
@@ -1104,8 +1111,11 @@ class _ConvBnAct(torch.autograd.Function):
                 # (sum dz, sum dz * xhat) as f64 accumulators: the apply launch reads them, no finalize launch
                 no_out = gate or gates is not None
                 link = getattr(ctx, "out_link", None)
-                if (link is not None and link.sums is not None and not link.dead and link.dx_ptr == dout_r.data_ptr() and lddo == k
-                        and nc_scale is None and (no_out or spec.act == ACT_NONE)):
+                link_ok = (link is not None and link.sums is not None and not link.dead and link.dx_ptr == dout_r.data_ptr() and lddo == k
+                           and nc_scale is None and (no_out or spec.act == ACT_NONE))
+                if link is not None:
+                    link.dx = None  # (held only so that autograd could not accumulate a second gradient into it in place)
+                if link_ok:
                     bsums = link.sums  # already added by the consumer's input-gradient launch (dass_conv2d_x3_dgrad_bnstats)
                     bn_link_counts["used"] += 1
                 else:
@@ -1286,6 +1296,8 @@ class _ConvBnAct(torch.autograd.Function):
 # set_deferred_wgrad(False): per-layer launches inside backward.
 _wg = {"on": os.environ.get("DASS_WGRAD_DEFER", "1") == "1", "queue": [], "armed": False, "pending": set(),
        "chunk": int(os.environ.get("DASS_WGRAD_CHUNK", "16")), "side": os.environ.get("DASS_WGRAD_SIDE", "1") == "1"}
+if not hasattr(torch._C, "_current_graph_task_id"):
+    _wg["on"] = False  # without the graph-task id a failed backward pass could not be told from the next one: per-layer launches
 
 
 def set_deferred_wgrad(on):
@@ -1314,16 +1326,18 @@ def set_wgrad_chunk(n, side=None):
 
 
 def _wgrad_enqueue(weight, x3, dy3, dwk, dims, k, c_in):
+    task = torch._C._current_graph_task_id() if hasattr(torch._C, "_current_graph_task_id") else None
+    if task is not None and task != _wg.get("task"):
+        # first deferred gradient of a NEW backward pass.  Whatever is still queued (or in flight on the side stream) belongs to
+        # a pass that never reached its final callback (an exception inside backward): drop it BEFORE anything is flushed -- a
+        # flush of the stale state would add the failed pass's gradients into .grad after the caller's zero_grad and fire
+        # hooks for it -- and arm the callback again for this pass
+        _wg["task"] = task
+        _wg["queue"], _wg["inflight"], _wg["pending"], _wg["armed"] = [], [], set(), False
     if _wg["chunk"] and len(_wg["queue"]) >= _wg["chunk"]:
         # the layers already queued have returned from their backward, and autograd has run their (empty-handed) AccumulateGrad
         # nodes -- those have the highest priority in the engine's ready queue -- so their hooks may fire for real now
         _wgrad_flush(final=False)
-    task = torch._C._current_graph_task_id() if hasattr(torch._C, "_current_graph_task_id") else None
-    if task is not None and task != _wg.get("task"):
-        # first deferred gradient of a NEW backward pass.  Whatever is still queued belongs to a pass that never reached its
-        # final callback (an exception inside backward): drop it, and arm the callback again for this pass
-        _wg["task"] = task
-        _wg["queue"], _wg["inflight"], _wg["pending"], _wg["armed"] = [], [], set(), False
     _wg["queue"].append((weight, x3, dy3, dwk, dims, k, c_in))
     _wg["pending"].add(id(weight))
     if not _wg["armed"]:

@@ -420,6 +420,10 @@ int64_t dass_w3_pack_bytes(int64_t rows, int C, int N);
  * dass_conv2d_x3 (csrc/conv_x3.hip); mode 0 = auto, 1 = one output tile per workgroup, 2 = stream-K (whole rounds of
  * tiles one per workgroup + the remainder as equal slab ranges), 3 = stream-K slab ranges over all tiles */
 int dass_x3_force_tile(int tile);
+/* Diagnostic: which kernel the last dass_conv2d_x3* launch of this process ran -- (BM << 16) | (BN << 4) | 2 (whole-tile
+ * specialisation) | 1 (stream-K schedule + fix-up pass).  Host state only (no device work); bench.py's in-step roofline uses it
+ * to attribute launch times to tile classes.  No reference counterpart (the reference's convs are ATen calls). */
+int dass_x3_last_pick(void);
 /* Host-only helper: the (multiplier, shift) pair with which dass_conv2d_x3's kernels divide a pixel index n (0 <= n < 2^31)
  * by d = OH*OW or OW:  n / d == (n * mul >> 32) >> shift,  shift < 0 meaning d == 1 (quotient n).  Exported for the CPU tests. */
 int dass_x3_magic(int d, unsigned *mul, int *shift);

@@ -240,6 +240,99 @@ def test_fullsize_conv_values_vs_f64_dot_products(shape, engine):
     assert (gotw - refw).abs().max().item() <= 1e-5 * refw.abs().max().item(), "wgrad"
 
 
+@pytest.mark.parametrize("shape", [(8, 129, 304, 256, 3), (8, 193, 304, 256, 3), (8, 33, 256, 256, 3), (8, 129, 64, 256, 1), (8, 193, 256, 64, 1)])
+@pytest.mark.parametrize("tile", [0, 14, 11])
+def test_fullsize_f16x3_values_vs_f64_dot_products(shape, tile):
+    """The DEFAULT engine at the headline shapes: the two-part pre-split kernels -- the dispatcher's choice (tile 0),
+    the whole-tile 64 x 64 specialisation forced (14: magic-multiplier pixel decomposition, 32-bit epilogue offsets, folded tap
+    barrier, at M = 133 128 and M = 297 992 = 18 628 workgroups) and whole 256 x 128 tiles (11) -- forward, input gradient and the
+    GROUPED weight-gradient launch the train step uses, against f64 dot products over gathered patches computed outside the
+    kernels; 4096 random pixels + every corner / border of every image (last M- and N-tiles included)."""
+    import ctypes
+
+    import numpy as np
+    from dass_hip import ops
+    from dass_hip._lib import check, lib
+
+    n, hw, c, k, ks = shape
+    pad = ks // 2
+    ops.set_f32_mma("f16x3")
+    g = torch.Generator(device="cuda").manual_seed(n * hw + c + ks)
+    x = torch.randn((n, hw, hw, c), device="cuda", generator=g)
+    wt = torch.randn((k, ks, ks, c), device="cuda", generator=g) * (2.0 / (ks * ks * c)) ** 0.5
+    dy = torch.randn((n, hw, hw, k), device="cuda", generator=g) * 1e-3   # gradient-sized
+    dims = (n, hw, hw, c, hw, hw, k, ks, ks, 1, pad, 1)
+    pix = _sample_pixels(n, hw, hw, 4096, seed=hw + ks).cuda()
+    w64 = wt.double()
+    try:
+        lib.dass_x3_force_tile(tile)
+        # ---- forward
+        y = torch.full((n, hw, hw, k), float("nan"), device="cuda")
+        x3 = ops.split3_rows(x, c, n * hw * hw, c)
+        ops.conv_x3_launch(x3, ops.prepare_conv_weight(wt, x3=True), y, k, dims)
+        pick_f = lib.dass_x3_last_pick()
+        ref = _patches_f64(x, pix, ks, pad, 1) @ w64.reshape(k, -1).t()
+        got = y[pix[:, 0], pix[:, 1], pix[:, 2]].double()
+        assert torch.isfinite(y).all()
+        assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item(), ("fwd", (got - ref).abs().max().item(), ref.abs().max().item())
+        if tile == 14:
+            assert pick_f >> 16 == 64 and (pick_f >> 4) & 0xfff == 64 and pick_f & 2, hex(pick_f)   # the whole-tile kernel really ran
+        # ---- input gradient
+        dx = torch.full((n, hw, hw, c), float("nan"), device="cuda")
+        w_t = ops.prepare_conv_weight(wt.permute(3, 1, 2, 0).flip(1, 2).contiguous(), x3=True)
+        dy3 = ops.split3_rows(dy, k, n * hw * hw, k)
+        ops.conv_x3_launch(dy3, w_t, dx, c, (n, hw, hw, k, hw, hw, c, ks, ks, 1, pad, 1))
+        wflip = w64.flip(1, 2).permute(1, 2, 0, 3).reshape(ks * ks * k, c)
+        refd = _patches_f64(dy, pix, ks, pad, 1) @ wflip
+        gotd = dx[pix[:, 0], pix[:, 1], pix[:, 2]].double()
+        assert torch.isfinite(dx).all()
+        assert (gotd - refd).abs().max().item() <= 2e-5 * refd.abs().max().item(), "dgrad"
+    finally:
+        lib.dass_x3_force_tile(0)
+    if tile != 0:
+        return  # (the weight-gradient launch has its own tile classes: once per shape)
+    # ---- grouped weight gradient (one problem), 8 output channels over the K tiles, all taps and input channels
+    ksel = torch.tensor(sorted({0, 31, min(64, k - 1), k // 2 - 1, k // 2, k - 3, k - 2, k - 1}), device="cuda")
+    dw = torch.zeros((k, ks, ks, c), device="cuda")
+    items = np.zeros((1, 16), dtype=np.int64)
+    items[0, :3] = (x3.data_ptr(), dy3.data_ptr(), dw.data_ptr())
+    items[0, 3:15] = dims
+    scratch = torch.empty((lib.dass_conv2d_wgrad_x3_group_scratch_bytes(1) + 128,), dtype=torch.uint8, device="cuda")
+    check(lib.dass_conv2d_wgrad_x3_group(items.ctypes.data_as(ctypes.c_void_p), 1, ops._p(scratch), scratch.numel(), ops._stream()), "group")
+    xp = torch.zeros((n, hw + 2 * pad, hw + 2 * pad, c), dtype=torch.float64, device="cuda")
+    xp[:, pad:hw + pad, pad:hw + pad] = x.double()
+    dys = dy[..., ksel].double().reshape(-1, ksel.numel())
+    refw = torch.stack([torch.stack([dys.t() @ xp[:, r:r + hw, s2:s2 + hw].reshape(-1, c) for s2 in range(ks)], 1) for r in range(ks)], 1)
+    gotw = dw[ksel].double()
+    assert torch.isfinite(dw).all()
+    assert (gotw - refw).abs().max().item() <= 1e-5 * refw.abs().max().item(), ("wgrad", (gotw - refw).abs().max().item(), refw.abs().max().item())
+
+
+def test_config_b_r101_769_logits_vs_oracle():
+    """BASELINE config B (R101 os16, 769 x 769) against the CPU oracle DIRECTLY (one image costs seconds on the box's
+    host cores, no need to argue it through properties): eval logits of one image within 1e-3 (relative to a logit scale of 50,
+    as in the 513 test), argmax identical outside near-ties.  Default engine (f16x3)."""
+    pm, O = _r101(seed=7)
+    om = O.ODeepLab("resnet101", 16, 19)
+    O.fill_state_dict(om, seed=7)
+    om.eval()
+    x, _ = O.synthetic_batch(1, 769, 769, 19, first_index=31)
+    torch.set_num_threads(min(16, torch.get_num_threads() or 16))
+    with torch.no_grad():
+        ref = om(x).float()
+        got = pm(x.cuda()).float().cpu()
+    assert got.shape == ref.shape == (1, 19, 769, 769)
+    scale = ref.abs().max().item()
+    err = (got - ref).abs().max().item()
+    top = ref.topk(2, dim=1)[0]
+    margin = 1e-3 * max(1.0, scale / 50)
+    safe = (top[:, 0] - top[:, 1]) > margin
+    flips = int((got.argmax(1) != ref.argmax(1)).sum())
+    print("config B 769^2 vs oracle: max |dlogit| %.2e on a logit scale of %.1f, argmax flips %d, near-ties %d" % (err, scale, flips, int((~safe).sum())))
+    assert err <= margin, (err, scale)
+    assert torch.equal(got.argmax(1)[safe], ref.argmax(1)[safe])
+
+
 def test_config_b_r101_769_forward_and_mc_dropout():
     """BASELINE config B's size (R101 os16, 769 x 769): forward through both parity engine paths (classic kernels under
     autograd bookkeeping off = the pre-split inference engine, and with it switched off) agree to the parity tolerance with

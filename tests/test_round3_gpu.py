@@ -366,6 +366,58 @@ def test_bn_backward_sums_fused_into_next_layers_input_gradient(backbone):
         ops.set_f32_mma(keep)
 
 
+@pytest.mark.parametrize("second", ["torch_sum", "residual"])
+def test_bn_link_with_a_consumer_it_cannot_see(second):
+    """layer L's output feeds the dense conv that claims L's link AND a consumer the link knows nothing about
+    (plain torch arithmetic / the `residual=` argument of a later layer).  Autograd then hands L a SUM of two gradients -- in place
+    into the first one's storage when it held the last reference to it (InputBuffer::add), i.e. same address, different contents.
+    The sums the claiming launch computed from its own dx alone must NOT be used: gradients with the link on == link off, and the
+    fused sums stay unused for L."""
+    ops, O, S = _setup()
+    keep = ops.f32_mma()
+    try:
+        ops.set_f32_mma("f16x3")
+        torch.manual_seed(3)
+        n, c, hw = 2, 64, 33
+        conv1, bn1 = torch.nn.Conv2d(c, 64, 1, bias=False).cuda(), torch.nn.BatchNorm2d(64).cuda()
+        conv2, bn2 = torch.nn.Conv2d(64, 64, 3, padding=1, bias=False).cuda(), torch.nn.BatchNorm2d(64).cuda()
+        conv3, bn3 = torch.nn.Conv2d(64, 64, 1, bias=False).cuda(), torch.nn.BatchNorm2d(64).cuda()
+        for bn in (bn1, bn2, bn3):
+            bn.train()
+            with torch.no_grad():
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.uniform_(-0.2, 0.2)
+        x = torch.randn(n, c, hw, hw, device="cuda").contiguous(memory_format=torch.channels_last)
+        t = torch.randn(n, 64, hw, hw, device="cuda").contiguous(memory_format=torch.channels_last)
+        params = [conv1.weight, bn1.weight, bn1.bias, conv2.weight, bn2.weight, bn2.bias]
+        grads = {}
+        for on in (False, True):
+            ops.set_bn_link(on)
+            for key in ops.bn_link_counts:
+                ops.bn_link_counts[key] = 0
+            for p in params + [conv3.weight, bn3.weight, bn3.bias]:
+                p.grad = None
+            xin = x.clone().requires_grad_(True)
+            o1 = ops.conv_bn_act(xin, conv1, bn1, act=ops.ACT_RELU)                 # layer L: attaches its link to o1
+            o2 = ops.conv_bn_act(o1, conv2, bn2, act=ops.ACT_RELU)                  # the dense consumer that claims it
+            if second == "torch_sum":
+                loss = (o2 * t).sum() + (o1 * t).sum() * 0.5                        # + a consumer the link cannot see
+            else:
+                o3 = ops.conv_bn_act(o2, conv3, bn3, act=ops.ACT_RELU, residual=o1)  # ... or o1 again as a later layer's residual
+                loss = (o3 * t).sum()
+            loss.backward()
+            grads[on] = [p.grad.double().cpu().clone() for p in params] + [xin.grad.double().cpu().clone()]
+            counts = dict(ops.bn_link_counts)
+            print(second, on, counts)
+            if on and second == "torch_sum":
+                assert counts["fused"] >= 1 and counts["used"] == 0, counts   # computed, and rightly thrown away
+        for a, b in zip(grads[True], grads[False]):
+            assert (a - b).norm().item() <= 1e-5 * max(b.norm().item(), 1e-12), ((a - b).norm().item(), b.norm().item())
+    finally:
+        ops.set_bn_link(True)
+        ops.set_f32_mma(keep)
+
+
 @pytest.mark.parametrize("case", [(2, 33, 33, 256, 64, 1, True, "relu"), (2, 33, 33, 128, 256, 3, False, "relu6"), (1, 65, 65, 64, 64, 3, True, "gates"),
                                   (8, 33, 33, 1024, 256, 1, False, "none")])
 def test_dgrad_bnstats_kernel_equals_separate_reduce(case):
