@@ -271,31 +271,51 @@ def _tile_tag(name, tag):
 
 
 def step_conv_times(train_step, reps=3):
-    """the conv / weight-gradient launches of `reps` real train steps, timed where they run (KernelTimer: HIP events on each
-    launch's own stream) -> per-step totals and a per-(entry point, tile class) table"""
-    from dass_hip._lib import CONV_ENTRY_POINTS, KernelTimer
+    """`reps` real train steps with the library's launch profile open (dass_hip/_lib.py:KernelTimer -> csrc/prof.hip): every kernel
+    carries a start / stop HIP event pair bound to its own dispatch on its own stream -> per-step totals of the conv / weight-
+    gradient entry points (GFLOP, ms), a per-(entry point, tile class) table, the train-mode BN passes (GB, ms) and the kernel
+    table of the step (what `rocprofv3 --kernel-trace --stats` lists for the same command, profiles/r04_train_summary.md)"""
+    import re
 
-    with KernelTimer(CONV_ENTRY_POINTS) as kt:
-        train_step()                      # (events on: first step untimed -- event pools, allocator)
+    from dass_hip._lib import BN_ENTRY_POINTS, KernelTimer
+
+    with KernelTimer() as kt:
+        train_step()                      # (first profiled step untimed: event pool, allocator)
         torch.cuda.synchronize()
-        kt.rows()
+        kt.restart()
         for _ in range(reps):
             train_step()
         torch.cuda.synchronize()
-        rows = kt.rows()
-    by = {}
-    for name, tag, gflop, ms in rows:
-        e = by.setdefault(_tile_tag(name, tag), [0, 0.0, 0.0])
+        kernels, calls = kt.results()
+    by, bn = {}, {}
+    for name, tag, work, ms, knames in calls:
+        d = bn if name in BN_ENTRY_POINTS else by
+        e = d.setdefault(name.replace("dass_", "") if name in BN_ENTRY_POINTS else _tile_tag(name, tag), [0, 0.0, 0.0])
         e[0] += 1
-        e[1] += gflop
+        e[1] += work
         e[2] += ms
     table = [{"kernel": k, "launches_per_step": round(v[0] / reps, 1), "gflop_per_step": round(v[1] / reps, 1),
               "ms_per_step": round(v[2] / reps, 3), "avg_us": round(1e3 * v[2] / v[0], 1),
               "tflops": round(v[1] / v[2], 1) if v[2] > 0 else None} for k, v in by.items()]
     table.sort(key=lambda r: -r["ms_per_step"])
-    gflop = sum(r[2] for r in rows) / reps
-    ms = sum(r[3] for r in rows) / reps
-    return {"gflop": gflop, "ms": ms, "launches": len(rows) / reps, "table": table}
+    bn_table = [{"pass": k, "launches_per_step": round(v[0] / reps, 1), "gb_per_step": round(v[1] / reps, 3), "ms_per_step": round(v[2] / reps, 3),
+                 "tb_per_s": round(v[1] / v[2], 3) if v[2] > 0 else None, "frac_of_8_tb_per_s": round(v[1] / v[2] / 8.0, 4) if v[2] > 0 else None}
+                for k, v in bn.items()]
+    bn_table.sort(key=lambda r: -r["ms_per_step"])
+    conv = [c for c in calls if c[0] not in BN_ENTRY_POINTS]
+    kt_by = {}
+    for kname, ms, grid, stream in kernels:
+        short = re.sub(r"\(anonymous namespace\)::", "", kname)
+        short = re.sub(r"^void ", "", short).split("(")[0]
+        e = kt_by.setdefault(short, [0, 0.0])
+        e[0] += 1
+        e[1] += ms
+    ktable = [{"kernel": k, "launches_per_step": round(v[0] / reps, 1), "ms_per_step": round(v[1] / reps, 3), "avg_us": round(1e3 * v[1] / v[0], 1)}
+              for k, v in sorted(kt_by.items(), key=lambda kv: -kv[1][1])]
+    return {"gflop": sum(c[2] for c in conv) / reps, "ms": sum(c[3] for c in conv) / reps, "launches": len(conv) / reps, "table": table,
+            "bn": bn_table, "bn_ms": sum(r["ms_per_step"] for r in bn_table), "bn_gb": sum(r["gb_per_step"] for r in bn_table),
+            "kernels": ktable[:16], "kernel_ms": sum(k[1] for k in kernels) / reps, "kernel_launches": len(kernels) / reps,
+            "streams": len({k[3] for k in kernels})}
 
 
 def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
@@ -522,6 +542,10 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
             % (dtype_name, inst["launches"], inst["ms"], inst["gflop"], in_step))
         for r in inst["table"][:6]:
             log("    %-70s %5.1f x %7.1f us = %6.2f ms  %s TFLOP/s" % (r["kernel"], r["launches_per_step"], r["avg_us"], r["ms_per_step"], r["tflops"]))
+        log("[%s] in-step: %d kernels of the library per step on %d streams, %.2f ms of kernel time; train-mode BN passes %.2f ms for %.2f GB = %.2f TB/s"
+            % (dtype_name, inst["kernel_launches"], inst["streams"], inst["kernel_ms"], inst["bn_ms"], inst["bn_gb"], inst["bn_gb"] / max(inst["bn_ms"], 1e-9)))
+        for r in inst["bn"]:
+            log("    %-30s %5.1f launches, %6.3f GB, %6.2f ms = %s TB/s" % (r["pass"], r["launches_per_step"], r["gb_per_step"], r["ms_per_step"], r["tb_per_s"]))
         sustained = None
         cfile = os.path.join(ROOT, "profiles", "r02_clock_probe.json")
         if os.path.exists(cfile) and engine != "f32":
@@ -535,8 +559,9 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
                                  "(tools/clock_probe.py, profiles/r02_clock_probe.json); the nominal peak assumes 2.4 GHz"}
         dom = inst["table"][0]
         res["roofline"] = {"bound": "mfma",
-                           "kernel": "every conv / weight-gradient launch of the timed train step (HIP events on each launch's stream, "
-                                     "3 steps after the timed region; durations of overlapping launches summed)",
+                           "kernel": "every conv / weight-gradient kernel of the train step itself (3 steps after the timed region with a start / stop "
+                                     "HIP event pair bound to each dispatch on its own stream, csrc/prof.hip; durations of overlapping launches summed, "
+                                     "as in the rocprofv3 kernel table profiles/r04_train_summary.md)",
                            "achieved": round(in_step, 2), "peak": peak, "peak_note": PEAK_NOTE[engine], "unit": "TFLOP/s",
                            "frac": round(in_step / peak, 4), "traffic": traffic,
                            "traffic_note": "HBM bytes of the best_launch shape from the committed rocprofv3 --pmc passes (%s)" % os.path.basename(tfile),
@@ -544,6 +569,13 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
                            "conv_launches_per_step": round(inst["launches"], 1),
                            "conv_ceiling_ms_per_step": round(inst["gflop"] / peak, 3),
                            "by_kernel": inst["table"],
+                           "bn_passes": {"note": "train-mode BN apply / backward passes of the same steps: ALGORITHMIC bytes (every [M][K] tensor a call "
+                                                 "reads or writes, 4 B per element; gate bits 1 B per 4) / kernel time, against HBM3E 8 TB/s; counter "
+                                                 "bytes: profiles/r04_pmc_bn.txt",
+                                         "ms_per_step": round(inst["bn_ms"], 3), "gb_per_step": round(inst["bn_gb"], 3),
+                                         "tb_per_s": round(inst["bn_gb"] / max(inst["bn_ms"], 1e-9), 3), "passes": inst["bn"]},
+                           "step_kernels": {"kernel_ms_per_step": round(inst["kernel_ms"], 3), "launches_per_step": round(inst["kernel_launches"], 1),
+                                            "streams": inst["streams"], "top": inst["kernels"]},
                            "dominant": {"kernel": dom["kernel"], "ms_per_step": dom["ms_per_step"], "avg_us": dom["avg_us"],
                                         "achieved": dom["tflops"], "frac": round(dom["tflops"] / peak, 4) if dom["tflops"] else None},
                            "isolated": {"note": "every layer shape launched 5x back to back on an idle chip, operands prepared outside the timing: a "

@@ -504,11 +504,11 @@ extern "C" int dass_channel_stats(const void *x, int64_t ldx, int64_t M, int K, 
     dim3 grid((unsigned)dass_stat_rows(M), (unsigned)((K + 63) / 64));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DASS_F32)
-        hipLaunchKernelGGL((colstat_kernel<float, 0>), grid, dim3(256), 0, st, (const float *)x, ldx, nullptr, 0,
-                           nullptr, 0, nullptr, nullptr, nullptr, M, K, 1, 0, partial);
+        DASS_LAUNCH((colstat_kernel<float, 0>), grid, dim3(256), 0, st, (const float *)x, ldx, nullptr, 0,
+                           nullptr, 0, nullptr, nullptr, nullptr, M, K, 1, 0, partial, nullptr, nullptr, nullptr, nullptr);
     else if (dtype == DASS_BF16)
-        hipLaunchKernelGGL((colstat_kernel<bf16_t, 0>), grid, dim3(256), 0, st, (const bf16_t *)x, ldx, nullptr, 0,
-                           nullptr, 0, nullptr, nullptr, nullptr, M, K, 1, 0, partial);
+        DASS_LAUNCH((colstat_kernel<bf16_t, 0>), grid, dim3(256), 0, st, (const bf16_t *)x, ldx, nullptr, 0,
+                           nullptr, 0, nullptr, nullptr, nullptr, M, K, 1, 0, partial, nullptr, nullptr, nullptr, nullptr);
     else
         return DASS_ERR_UNSUPPORTED;
     DASS_LAUNCH_CHECK();
@@ -519,7 +519,7 @@ extern "C" int dass_bn_finalize(const float *partial, int rows, int K, double co
                                 const float *beta, float *running_mean, float *running_var, float momentum,
                                 float eps, float *mean, float *invstd, float *scale, float *shift, void *stream) {
     if (!partial || rows <= 0 || K <= 0 || count <= 0 || !mean || !invstd || !scale || !shift) return DASS_ERR_ARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((K + FIN_CH - 1) / FIN_CH), dim3(1024), 0, (hipStream_t)stream, partial, rows, K,
+    DASS_LAUNCH(bn_finalize_kernel, dim3((K + FIN_CH - 1) / FIN_CH), dim3(1024), 0, (hipStream_t)stream, partial, rows, K,
                        count, rep, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -529,7 +529,7 @@ extern "C" int dass_bn_rows_fwd(const float *x, int N, int K, double rep, const 
                                 float *running_var, float momentum, float eps, float *mean, float *invstd, float *scale, float *shift,
                                 void *stream) {
     if (!x || N <= 0 || K <= 0 || rep <= 0 || !mean || !invstd || !scale || !shift) return DASS_ERR_ARG;
-    hipLaunchKernelGGL(bn_rows_fwd_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, N, K, rep, gamma, beta,
+    DASS_LAUNCH(bn_rows_fwd_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, N, K, rep, gamma, beta,
                        running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -538,7 +538,7 @@ extern "C" int dass_bn_rows_fwd(const float *x, int N, int K, double rep, const 
 extern "C" int dass_bn_rows_bwd(const float *g, const float *x, const float *mean, const float *invstd, const float *gamma, int N, int K,
                                 int train, float *dx, float *dgamma, float *dbeta, void *stream) {
     if (!g || !x || !mean || !invstd || !dx || !dgamma || !dbeta || N <= 0 || K <= 0) return DASS_ERR_ARG;
-    hipLaunchKernelGGL(bn_rows_bwd_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, x, mean, invstd, gamma, N, K,
+    DASS_LAUNCH(bn_rows_bwd_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, x, mean, invstd, gamma, N, K,
                        train, dx, dgamma, dbeta);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -548,7 +548,7 @@ extern "C" int dass_bn_eval_scale_shift(const float *gamma, const float *beta, c
                                         const float *running_var, float eps, int K, float *mean, float *invstd,
                                         float *scale, float *shift, void *stream) {
     if (!running_mean || !running_var || K <= 0 || !mean || !invstd || !scale || !shift) return DASS_ERR_ARG;
-    hipLaunchKernelGGL(bn_eval_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+    DASS_LAUNCH(bn_eval_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta,
                        running_mean, running_var, eps, K, mean, invstd, scale, shift);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -563,11 +563,11 @@ extern "C" int dass_scale_shift_act(const void *x, int64_t ldx, void *out, int64
     const int grid = dass_grid_1d(M * (K / 4), 256);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DASS_F32)
-        hipLaunchKernelGGL(scale_shift_act_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, ldx,
+        DASS_LAUNCH(scale_shift_act_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, ldx,
                            (float *)out, ldo, scale, shift, (const float *)residual, ldr, nc_scale, M, K,
                            rows_per_image, act, (char *)out3);
     else if (dtype == DASS_BF16)
-        hipLaunchKernelGGL(scale_shift_act_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)x, ldx,
+        DASS_LAUNCH(scale_shift_act_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)x, ldx,
                            (bf16_t *)out, ldo, scale, shift, (const bf16_t *)residual, ldr, nc_scale, M, K,
                            rows_per_image, act, (char *)nullptr);
     else
@@ -586,13 +586,13 @@ extern "C" int dass_bn_bwd_reduce(const void *dout, int64_t lddo, const void *ou
     dim3 grid((unsigned)dass_stat_rows(M), (unsigned)((K + 63) / 64));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DASS_F32)
-        hipLaunchKernelGGL((colstat_kernel<float, 1>), grid, dim3(256), 0, st, (const float *)x, ldx,
+        DASS_LAUNCH((colstat_kernel<float, 1>), grid, dim3(256), 0, st, (const float *)x, ldx,
                            (const float *)dout, lddo, (const float *)out, ldo, mean, invstd, nc_scale, M, K,
-                           rows_per_image, act, partial);
+                           rows_per_image, act, partial, nullptr, nullptr, nullptr, nullptr);
     else if (dtype == DASS_BF16)
-        hipLaunchKernelGGL((colstat_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t *)x, ldx,
+        DASS_LAUNCH((colstat_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t *)x, ldx,
                            (const bf16_t *)dout, lddo, (const bf16_t *)out, ldo, mean, invstd, nc_scale, M, K,
-                           rows_per_image, act, partial);
+                           rows_per_image, act, partial, nullptr, nullptr, nullptr, nullptr);
     else
         return DASS_ERR_UNSUPPORTED;
     DASS_LAUNCH_CHECK();
@@ -607,8 +607,8 @@ extern "C" int dass_bn_bwd_reduce_gate(const void *dout, int64_t lddo, const voi
         return DASS_ERR_ARG;
     if (dtype != DASS_F32) return DASS_ERR_UNSUPPORTED;  // a bf16 `out` is rounded: its gate is not the f32 pre-activation's
     dim3 grid((unsigned)dass_stat_rows(M), (unsigned)((K + 63) / 64));
-    hipLaunchKernelGGL((colstat_kernel<float, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const float *)x, ldx, (const float *)dout, lddo,
-                       (const float *)nullptr, 0, mean, invstd, nc_scale, M, K, rows_per_image, act, partial, gate_scale, gate_shift);
+    DASS_LAUNCH((colstat_kernel<float, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const float *)x, ldx, (const float *)dout, lddo,
+                       (const float *)nullptr, 0, mean, invstd, nc_scale, M, K, rows_per_image, act, partial, gate_scale, gate_shift, nullptr, nullptr);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
@@ -625,9 +625,9 @@ extern "C" int dass_bn_bwd_apply_gate(const void *dout, int64_t lddo, const void
     if (dtype != DASS_F32) return DASS_ERR_UNSUPPORTED;
     const int grid = dass_grid_1d(M * (K / 4), 256);
     const float inv_count = train ? (float)(1.0 / count) : 0.f;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float *)dout, lddo, (const float *)nullptr, 0,
+    DASS_LAUNCH(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float *)dout, lddo, (const float *)nullptr, 0,
                        (const float *)x, ldx, mean, invstd, gamma, dbeta, dgamma, nc_scale, (float *)dx, lddx, (float *)nullptr, 0, M, K,
-                       rows_per_image, inv_count, train, act, gate_scale, gate_shift, (char *)dx3);
+                       rows_per_image, inv_count, train, act, gate_scale, gate_shift, (char *)dx3, nullptr, nullptr, nullptr, nullptr, 3);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
@@ -635,7 +635,7 @@ extern "C" int dass_bn_bwd_apply_gate(const void *dout, int64_t lddo, const void
 extern "C" int dass_bn_bwd_finalize(const float *partial, int rows, int K, float *dbeta, float *dgamma,
                                     void *stream) {
     if (!partial || rows <= 0 || K <= 0) return DASS_ERR_ARG;
-    hipLaunchKernelGGL(bwd_finalize_kernel, dim3((K + FIN_CH - 1) / FIN_CH), dim3(1024), 0, (hipStream_t)stream, partial, rows, K,
+    DASS_LAUNCH(bwd_finalize_kernel, dim3((K + FIN_CH - 1) / FIN_CH), dim3(1024), 0, (hipStream_t)stream, partial, rows, K,
                        dbeta, dgamma);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -656,15 +656,15 @@ extern "C" int dass_bn_bwd_apply(const void *dout, int64_t lddo, const void *out
     const float inv_count = train ? (float)(1.0 / count) : 0.f;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DASS_F32)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)dout, lddo,
+        DASS_LAUNCH(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)dout, lddo,
                            (const float *)out, ldo, (const float *)x, ldx, mean, invstd, gamma, dbeta, dgamma,
                            nc_scale, (float *)dx, lddx, (float *)dres, lddr, M, K, rows_per_image, inv_count, train,
-                           act, (const float *)nullptr, (const float *)nullptr, (char *)dx3);
+                           act, (const float *)nullptr, (const float *)nullptr, (char *)dx3, nullptr, nullptr, nullptr, nullptr, 3);
     else if (dtype == DASS_BF16)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)dout, lddo,
+        DASS_LAUNCH(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)dout, lddo,
                            (const bf16_t *)out, ldo, (const bf16_t *)x, ldx, mean, invstd, gamma, dbeta, dgamma,
                            nc_scale, (bf16_t *)dx, lddx, (bf16_t *)dres, lddr, M, K, rows_per_image, inv_count, train,
-                           act);
+                           act, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 3);
     else
         return DASS_ERR_UNSUPPORTED;
     DASS_LAUNCH_CHECK();
@@ -676,7 +676,7 @@ extern "C" int dass_colsum(const void *x, int64_t ldx, int64_t M, int K, float *
     if (!out) return DASS_ERR_ARG;
     const int rc = dass_channel_stats(x, ldx, M, K, partial, dtype, stream);
     if (rc != DASS_OK) return rc;
-    hipLaunchKernelGGL(bwd_finalize_kernel, dim3((K + FIN_CH - 1) / FIN_CH), dim3(1024), 0, (hipStream_t)stream, partial,
+    DASS_LAUNCH(bwd_finalize_kernel, dim3((K + FIN_CH - 1) / FIN_CH), dim3(1024), 0, (hipStream_t)stream, partial,
                        dass_stat_rows(M), K, out, nullptr);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -691,11 +691,11 @@ extern "C" int dass_channel_sums(const void *x, int64_t ldx, int64_t M, int K, d
     dim3 grid((unsigned)dass_stat_rows(M), (unsigned)((K + 63) / 64));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DASS_F32)
-        hipLaunchKernelGGL((colstat_kernel<float, 0>), grid, dim3(256), 0, st, (const float *)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr,
-                           nullptr, M, K, 1, 0, nullptr, nullptr, nullptr, sums);
+        DASS_LAUNCH((colstat_kernel<float, 0>), grid, dim3(256), 0, st, (const float *)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr,
+                           nullptr, M, K, 1, 0, nullptr, nullptr, nullptr, sums, nullptr);
     else if (dtype == DASS_BF16)
-        hipLaunchKernelGGL((colstat_kernel<bf16_t, 0>), grid, dim3(256), 0, st, (const bf16_t *)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr,
-                           nullptr, M, K, 1, 0, nullptr, nullptr, nullptr, sums);
+        DASS_LAUNCH((colstat_kernel<bf16_t, 0>), grid, dim3(256), 0, st, (const bf16_t *)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr,
+                           nullptr, M, K, 1, 0, nullptr, nullptr, nullptr, sums, nullptr);
     else
         return DASS_ERR_UNSUPPORTED;
     DASS_LAUNCH_CHECK();
@@ -718,11 +718,11 @@ extern "C" int dass_bn_apply_train(const void *x, int64_t ldx, void *out, int64_
     const int grid = dass_grid_1d(M * (K / 4), 256);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DASS_F32)
-        hipLaunchKernelGGL(bn_apply_train_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, ldx, (float *)out, ldo, sums, count,
+        DASS_LAUNCH(bn_apply_train_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, ldx, (float *)out, ldo, sums, count,
                            gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, (const float *)residual, ldr,
                            nc_scale, M, K, rows_per_image, act, (char *)out3, (unsigned char *)gates, parts, residual_bound);
     else if (dtype == DASS_BF16)
-        hipLaunchKernelGGL(bn_apply_train_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)x, ldx, (bf16_t *)out, ldo, sums, count,
+        DASS_LAUNCH(bn_apply_train_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)x, ldx, (bf16_t *)out, ldo, sums, count,
                            gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, (const bf16_t *)residual, ldr,
                            nc_scale, M, K, rows_per_image, act, (char *)nullptr, (unsigned char *)gates, 3, (const float *)nullptr);
     else
@@ -743,11 +743,11 @@ extern "C" int dass_bn_bwd_reduce_sums(const void *dout, int64_t lddo, const voi
     dim3 grid((unsigned)dass_stat_rows(M), (unsigned)((K + 63) / 64));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DASS_F32)
-        hipLaunchKernelGGL((colstat_kernel<float, 1>), grid, dim3(256), 0, st, (const float *)x, ldx, (const float *)dout, lddo,
+        DASS_LAUNCH((colstat_kernel<float, 1>), grid, dim3(256), 0, st, (const float *)x, ldx, (const float *)dout, lddo,
                            (const float *)out, ldo, mean, invstd, nc_scale, M, K, rows_per_image, act, nullptr, gate_scale, gate_shift, sums,
                            (const unsigned char *)gates);
     else if (dtype == DASS_BF16)
-        hipLaunchKernelGGL((colstat_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t *)x, ldx, (const bf16_t *)dout, lddo,
+        DASS_LAUNCH((colstat_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t *)x, ldx, (const bf16_t *)dout, lddo,
                            (const bf16_t *)out, ldo, mean, invstd, nc_scale, M, K, rows_per_image, act, nullptr, nullptr, nullptr, sums,
                            (const unsigned char *)gates);
     else
@@ -773,15 +773,15 @@ extern "C" int dass_bn_bwd_apply_sums(const void *dout, int64_t lddo, const void
     const float inv_count = (float)(1.0 / count);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DASS_F32)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)dout, lddo, (const float *)out, ldo,
+        DASS_LAUNCH(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)dout, lddo, (const float *)out, ldo,
                            (const float *)x, ldx, mean, invstd, gamma, (const float *)nullptr, (const float *)nullptr, nc_scale, (float *)dx,
                            lddx, (float *)dres, lddr, M, K, rows_per_image, inv_count, 1, act, gate_scale, gate_shift, (char *)dx3, sums,
                            dbeta_out, dgamma_out, (const unsigned char *)gates, dass_get_x3_parts());
     else if (dtype == DASS_BF16)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)dout, lddo, (const bf16_t *)out, ldo,
+        DASS_LAUNCH(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)dout, lddo, (const bf16_t *)out, ldo,
                            (const bf16_t *)x, ldx, mean, invstd, gamma, (const float *)nullptr, (const float *)nullptr, nc_scale,
                            (bf16_t *)dx, lddx, (bf16_t *)dres, lddr, M, K, rows_per_image, inv_count, 1, act, (const float *)nullptr,
-                           (const float *)nullptr, (char *)nullptr, sums, dbeta_out, dgamma_out, (const unsigned char *)gates);
+                           (const float *)nullptr, (char *)nullptr, sums, dbeta_out, dgamma_out, (const unsigned char *)gates, 3);
     else
         return DASS_ERR_UNSUPPORTED;
     DASS_LAUNCH_CHECK();

@@ -1208,7 +1208,7 @@ template <typename T, int BM, int BN, int WM, int WN, bool WIDE = false, int SPL
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = (p.K + BN - 1) / BN;
     const int grid = p.mtiles * p.ntiles;
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, WIDE, SPLIT, PF>), dim3(grid), dim3(256), 0, st, p);
+    DASS_LAUNCH((conv_igemm_kernel<T, BM, BN, WM, WN, WIDE, SPLIT, PF>), dim3(grid), dim3(256), 0, st, p);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
@@ -1294,7 +1294,7 @@ template <typename T, int BMK, int BNC, bool WIDE = false> int launch_wgrad(Wgra
     p.pix_per_split = (int)pps;
     p.psplit = (int)((p.M + pps - 1) / pps);
     const long grid = base * p.psplit;
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, BMK, BNC, WIDE>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    DASS_LAUNCH((conv_wgrad_kernel<T, BMK, BNC, WIDE>), dim3((unsigned)grid), dim3(256), 0, st, p);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
@@ -1308,7 +1308,7 @@ template <int BMK, int BNC, int SPLIT = 0> int launch_wgrad_bf16(WgradP &p, hipS
     pps = (pps + BP - 1) / BP * BP;
     p.pix_per_split = (int)pps;
     p.psplit = (int)((p.M + pps - 1) / pps);
-    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BMK, BNC, SPLIT>), dim3((unsigned)(base * p.psplit)), dim3(256), 0, st, p);
+    DASS_LAUNCH((conv_wgrad_bf16_kernel<BMK, BNC, SPLIT>), dim3((unsigned)(base * p.psplit)), dim3(256), 0, st, p);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
@@ -1511,12 +1511,12 @@ extern "C" int dass_weight_transform(const float *src, void *dst, int K, int R, 
     const int grid = dass_grid_1d(total, 256);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DASS_F32)
-        hipLaunchKernelGGL(weight_transform_kernel<float>, dim3(grid), dim3(256), 0, st, src, (float *)dst, K, R, S, Csrc, Cdst, mode);
+        DASS_LAUNCH(weight_transform_kernel<float>, dim3(grid), dim3(256), 0, st, src, (float *)dst, K, R, S, Csrc, Cdst, mode);
     else if (dtype == DASS_BF16)
-        hipLaunchKernelGGL(weight_transform_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, src, (bf16_t *)dst, K, R, S, Csrc, Cdst, mode);
+        DASS_LAUNCH(weight_transform_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, src, (bf16_t *)dst, K, R, S, Csrc, Cdst, mode);
     else if (dtype == DASS_F32X6) {
         const long n6 = (long)(mode == 0 ? K : Csrc) * R * S * (((mode == 0 ? Cdst : K) + 31) / 32) * 32;
-        hipLaunchKernelGGL(weight_split3_kernel, dim3(dass_grid_1d(n6, 256)), dim3(256), 0, st, src, (bf16_t *)dst, K, R, S, Csrc, Cdst, mode);
+        DASS_LAUNCH(weight_split3_kernel, dim3(dass_grid_1d(n6, 256)), dim3(256), 0, st, src, (bf16_t *)dst, K, R, S, Csrc, Cdst, mode);
     } else
         return DASS_ERR_UNSUPPORTED;
     DASS_LAUNCH_CHECK();
@@ -1526,7 +1526,7 @@ extern "C" int dass_weight_transform(const float *src, void *dst, int K, int R, 
 extern "C" int dass_weight_split_batch(const void *desc, const int64_t *start, int n, int64_t total, void *stream) {
     if (!desc || !start || n <= 0 || total <= 0) return DASS_ERR_ARG;
     const long grid = total < 256 * 32 ? total : 256 * 32;
-    hipLaunchKernelGGL(weight_split3_batch_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
+    DASS_LAUNCH(weight_split3_batch_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
                        (const long *)desc, (const long *)start, n, (long)total);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -1546,9 +1546,9 @@ extern "C" int dass_weight_split_batch_f16(const void *desc, const int64_t *star
     if (!desc || !start || n <= 0 || total <= 0) return DASS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const long grid = total < 256 * 32 ? total : 256 * 32;
-    hipLaunchKernelGGL(weight_trailer_zero_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const long *)desc, n);
-    hipLaunchKernelGGL(weight_split2_batch_kernel, dim3((unsigned)grid), dim3(256), 0, st, (const long *)desc, (const long *)start, n, (long)total, 1);
-    hipLaunchKernelGGL(weight_split2_batch_kernel, dim3((unsigned)grid), dim3(256), 0, st, (const long *)desc, (const long *)start, n, (long)total, 0);
+    DASS_LAUNCH(weight_trailer_zero_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const long *)desc, n);
+    DASS_LAUNCH(weight_split2_batch_kernel, dim3((unsigned)grid), dim3(256), 0, st, (const long *)desc, (const long *)start, n, (long)total, 1);
+    DASS_LAUNCH(weight_split2_batch_kernel, dim3((unsigned)grid), dim3(256), 0, st, (const long *)desc, (const long *)start, n, (long)total, 0);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }

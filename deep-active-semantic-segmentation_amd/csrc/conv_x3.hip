@@ -1156,20 +1156,20 @@ template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE, int NP = 3> int 
     g_last_pick = (BM << 16) | (BN << 4) | ((has_simple && simple) ? 2 : 0) | (stream ? 1 : 0);
     if constexpr (has_simple) {
         if (simple) {
-            hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE, true, NP, true>), dim3(p.sk_wgs), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
+            DASS_LAUNCH((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE, true, NP, true>), dim3(p.sk_wgs), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
             DASS_LAUNCH_CHECK();
             return DASS_OK;
         }
     }
     if (m16 || NP == 2)  // (the two-part format is built for the 16x16x32 shape only)
-        hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE, true, NP>), dim3(p.sk_wgs), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
+        DASS_LAUNCH((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE, true, NP>), dim3(p.sk_wgs), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
     else if constexpr (NP == 3)
-        hipLaunchKernelGGL((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE, false, 3>), dim3(p.sk_wgs), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
+        DASS_LAUNCH((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE, false, 3>), dim3(p.sk_wgs), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
     DASS_LAUNCH_CHECK();
     if (stream) {
         constexpr int RPP = 256 / (BN / 4);
         const int row_split = p.stat_partial ? 1 : (BM / RPP >= 8 ? 8 : BM / RPP);
-        hipLaunchKernelGGL((conv_x3_fixup_kernel<BM, BN>), dim3(p.sk_part, row_split), dim3(256), 0, st, p);
+        DASS_LAUNCH((conv_x3_fixup_kernel<BM, BN>), dim3(p.sk_part, row_split), dim3(256), 0, st, p);
         DASS_LAUNCH_CHECK();
     }
     return DASS_OK;
@@ -1273,7 +1273,7 @@ extern "C" int dass_absmax_rows(const float *x, int64_t ld, int64_t M, int C, co
                                 void *stream) {
     if (!x || !bound || M <= 0 || C <= 0 || ld < C || (ld & 3) || ((uintptr_t)x & 15)) return DASS_ERR_ARG;
     if (nc_scale && (rows_per_image <= 0 || (C & 3))) return DASS_ERR_ARG;
-    hipLaunchKernelGGL(absmax_rows_kernel, dim3(dass_grid_1d(M * ((C + 3) / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, (long)ld, (long)M, C,
+    DASS_LAUNCH(absmax_rows_kernel, dim3(dass_grid_1d(M * ((C + 3) / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, (long)ld, (long)M, C,
                        nc_scale, (long)(rows_per_image > 0 ? rows_per_image : 1), (unsigned *)bound);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -1292,10 +1292,10 @@ extern "C" int dass_split3_rows(const float *x, int64_t ld, void *out, int64_t M
         if (hipMemsetAsync(tr, 0, 16, st) != hipSuccess) return DASS_ERR_LAUNCH;
         const int rc = dass_absmax_rows(x, ld, M, C, nc_scale, rows_per_image, (float *)(tr + 4), stream);
         if (rc != DASS_OK) return rc;
-        hipLaunchKernelGGL(split3_rows_kernel<2>, dim3(dass_grid_1d((M + 1) * CC * 4, 256)), dim3(256), 0, st, x, (long)ld, (char *)out, (long)M, C,
+        DASS_LAUNCH(split3_rows_kernel<2>, dim3(dass_grid_1d((M + 1) * CC * 4, 256)), dim3(256), 0, st, x, (long)ld, (char *)out, (long)M, C,
                            CC, nc_scale, (long)rows_per_image);
     } else {
-        hipLaunchKernelGGL(split3_rows_kernel<3>, dim3(dass_grid_1d((M + 1) * CC * 4, 256)), dim3(256), 0, st, x, (long)ld, (char *)out, (long)M, C,
+        DASS_LAUNCH(split3_rows_kernel<3>, dim3(dass_grid_1d((M + 1) * CC * 4, 256)), dim3(256), 0, st, x, (long)ld, (char *)out, (long)M, C,
                            CC, nc_scale, (long)rows_per_image);
     }
     DASS_LAUNCH_CHECK();
@@ -1581,7 +1581,7 @@ __global__ __launch_bounds__(256) void w3_pack_per_image_kernel(const unsigned s
 
 extern "C" int dass_dropout_compact(const float *mask, int N, int C, int *order, int *cc_limit, void *stream) {
     if (!mask || !order || !cc_limit || N <= 0 || C <= 0) return DASS_ERR_ARG;
-    hipLaunchKernelGGL(dropout_compact_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, mask, C, (C + 31) / 32, order, cc_limit);
+    DASS_LAUNCH(dropout_compact_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, mask, C, (C + 31) / 32, order, cc_limit);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
@@ -1607,10 +1607,10 @@ static int split_packed_impl(const float *x, int64_t ld, void *out, int64_t M, i
             bound = (const float *)(tr + 4);
             bound_mul = 1.f;
         }
-        hipLaunchKernelGGL(split3_rows_packed_kernel<2>, dim3((unsigned)(images * chunks + 1)), dim3(256), 0, st, x, (long)ld, (char *)out, (long)M,
+        DASS_LAUNCH(split3_rows_packed_kernel<2>, dim3((unsigned)(images * chunks + 1)), dim3(256), 0, st, x, (long)ld, (char *)out, (long)M,
                            C, CC, mask, order, cc_limit, (long)rows_per_image, (int)chunks, bound, bound_mul);
     } else {
-        hipLaunchKernelGGL(split3_rows_packed_kernel<3>, dim3((unsigned)(images * chunks + 1)), dim3(256), 0, st, x, (long)ld, (char *)out, (long)M,
+        DASS_LAUNCH(split3_rows_packed_kernel<3>, dim3((unsigned)(images * chunks + 1)), dim3(256), 0, st, x, (long)ld, (char *)out, (long)M,
                            C, CC, mask, order, cc_limit, (long)rows_per_image, (int)chunks, (const float *)nullptr, 1.f);
     }
     DASS_LAUNCH_CHECK();
@@ -1636,10 +1636,10 @@ extern "C" int dass_w3_pack_per_image(const void *w3, void *out, int64_t rows, i
     if (((uintptr_t)out & 15) || ((uintptr_t)w3 & 1)) return DASS_ERR_ARG;
     const int CC = (C + 31) / 32;
     if (g_x3_parts == 2)
-        hipLaunchKernelGGL(w3_pack_per_image_kernel<2>, dim3(dass_grid_1d((long)N * rows * CC * 4, 256)), dim3(256), 0, (hipStream_t)stream,
+        DASS_LAUNCH(w3_pack_per_image_kernel<2>, dim3(dass_grid_1d((long)N * rows * CC * 4, 256)), dim3(256), 0, (hipStream_t)stream,
                            (const unsigned short *)w3, (unsigned short *)out, (long)rows, CC, N, order, cc_limit);
     else
-        hipLaunchKernelGGL(w3_pack_per_image_kernel<3>, dim3(dass_grid_1d((long)N * rows * CC * 4, 256)), dim3(256), 0, (hipStream_t)stream,
+        DASS_LAUNCH(w3_pack_per_image_kernel<3>, dim3(dass_grid_1d((long)N * rows * CC * 4, 256)), dim3(256), 0, (hipStream_t)stream,
                            (const unsigned short *)w3, (unsigned short *)out, (long)rows, CC, N, order, cc_limit);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -1701,7 +1701,7 @@ __global__ __launch_bounds__(256) void x3_prepare_out_kernel(char *y3, long out_
 /* l1[k] = sum |w[k][...]| over a row of row_len floats (K rows): the weight-side factor of the output bound of a fused two-part conv */
 extern "C" int dass_weight_l1(const float *w, int K, int64_t row_len, float *l1, void *stream) {
     if (!w || !l1 || K <= 0 || row_len <= 0) return DASS_ERR_ARG;
-    hipLaunchKernelGGL(weight_l1_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, w, (long)row_len, l1);
+    DASS_LAUNCH(weight_l1_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, w, (long)row_len, l1);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
@@ -1713,7 +1713,7 @@ extern "C" int dass_x3_prepare_out(void *y3, int64_t out_rows, int K, const floa
                                    int64_t in_rows, int in_C, const float *res_amax, float mask_max, int act, void *stream) {
     if (!y3 || !l1 || !x3_in || out_rows <= 0 || K <= 0 || in_rows <= 0 || in_C <= 0 || !(mask_max > 0.f)) return DASS_ERR_ARG;
     if (g_x3_parts != 2) return DASS_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(x3_prepare_out_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (char *)y3, (long)out_rows, K, l1, scale, shift,
+    DASS_LAUNCH(x3_prepare_out_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (char *)y3, (long)out_rows, K, l1, scale, shift,
                        (const char *)x3_in, x3_trailer_off(in_rows, (in_C + 31) / 32, 2), res_amax, mask_max, act);
     DASS_LAUNCH_CHECK();
     return DASS_OK;

@@ -9,6 +9,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short bf16_t;  // raw storage
 
+// Every kernel of the library is launched through DASS_LAUNCH: the plain hipLaunchKernelGGL, or -- while bench.py holds a profile
+// open (csrc/prof.hip: dass_prof_begin) -- the same launch with a start / stop event pair bound to that dispatch.
+#include <hip/hip_ext.h>
+extern int g_dass_prof_on;
+void dass_prof_slot(const void *fn, long long grid, hipStream_t st, hipEvent_t *e0, hipEvent_t *e1);
+#define DASS_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                              \
+    do {                                                                                                                  \
+        if (__builtin_expect(g_dass_prof_on, 0)) {                                                                        \
+            hipEvent_t pe0_, pe1_;                                                                                        \
+            const dim3 pg_ = (grid);                                                                                      \
+            dass_prof_slot(reinterpret_cast<const void *>(kernel), (long long)pg_.x * pg_.y * pg_.z, (stream), &pe0_, &pe1_); \
+            hipExtLaunchKernelGGL(kernel, pg_, (block), (shmem), (stream), pe0_, pe1_, 0, __VA_ARGS__);                   \
+        } else {                                                                                                          \
+            hipLaunchKernelGGL(kernel, (grid), (block), (shmem), (stream), __VA_ARGS__);                                   \
+        }                                                                                                                 \
+    } while (0)
+
 #define DASS_LAUNCH_CHECK()                               \
     do {                                                  \
         if (hipGetLastError() != hipSuccess) return DASS_ERR_LAUNCH; \

@@ -393,9 +393,9 @@ extern "C" int dass_dwconv3x3_fwd(const void *x, int64_t ldx, const float *w, vo
     const dim3 grid((unsigned)(gx < 1024 ? gx : 1024), (unsigned)(rows_ < 8192 ? rows_ : 8192));  // (ow, channel group) x output rows
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DASS_F32)
-        hipLaunchKernelGGL(dw_fwd_kernel<float>, grid, dim3(256), 0, st, (const float *)x, ldx, w, (float *)y, ldy, N, H, W, C, OH, OW, stride, pad, dil);
+        DASS_LAUNCH(dw_fwd_kernel<float>, grid, dim3(256), 0, st, (const float *)x, ldx, w, (float *)y, ldy, N, H, W, C, OH, OW, stride, pad, dil);
     else if (dtype == DASS_BF16)
-        hipLaunchKernelGGL(dw_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)x, ldx, w, (bf16_t *)y, ldy, N, H, W, C, OH, OW, stride, pad, dil);
+        DASS_LAUNCH(dw_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)x, ldx, w, (bf16_t *)y, ldy, N, H, W, C, OH, OW, stride, pad, dil);
     else
         return DASS_ERR_UNSUPPORTED;
     DASS_LAUNCH_CHECK();
@@ -413,9 +413,9 @@ extern "C" int dass_dwconv3x3_bwd_data(const void *dy, int64_t lddy, const float
     const dim3 grid((unsigned)(gx < 1024 ? gx : 1024), (unsigned)(rows_ < 8192 ? rows_ : 8192));  // (ix, channel group) x input rows
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DASS_F32)
-        hipLaunchKernelGGL(dw_bwd_data_kernel<float>, grid, dim3(256), 0, st, (const float *)dy, lddy, w, (float *)dx, lddx, N, H, W, C, OH, OW, stride, pad, dil);
+        DASS_LAUNCH(dw_bwd_data_kernel<float>, grid, dim3(256), 0, st, (const float *)dy, lddy, w, (float *)dx, lddx, N, H, W, C, OH, OW, stride, pad, dil);
     else if (dtype == DASS_BF16)
-        hipLaunchKernelGGL(dw_bwd_data_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)dy, lddy, w, (bf16_t *)dx, lddx, N, H, W, C, OH, OW, stride, pad, dil);
+        DASS_LAUNCH(dw_bwd_data_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)dy, lddy, w, (bf16_t *)dx, lddx, N, H, W, C, OH, OW, stride, pad, dil);
     else
         return DASS_ERR_UNSUPPORTED;
     DASS_LAUNCH_CHECK();
@@ -440,9 +440,9 @@ extern "C" int dass_dwconv3x3_bwd_weight(const void *x, int64_t ldx, const void 
     slabs = (M + ppb - 1) / ppb;
     dim3 grid(cblocks, (unsigned)slabs);
     if (dtype == DASS_F32)
-        hipLaunchKernelGGL(dw_bwd_weight_kernel<float>, grid, dim3(256), 0, st, (const float *)x, ldx, (const float *)dy, lddy, dw, N, H, W, C, OH, OW, stride, pad, dil, ppb);
+        DASS_LAUNCH(dw_bwd_weight_kernel<float>, grid, dim3(256), 0, st, (const float *)x, ldx, (const float *)dy, lddy, dw, N, H, W, C, OH, OW, stride, pad, dil, ppb);
     else if (dtype == DASS_BF16)
-        hipLaunchKernelGGL(dw_bwd_weight_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)x, ldx, (const bf16_t *)dy, lddy, dw, N, H, W, C, OH, OW, stride, pad, dil, ppb);
+        DASS_LAUNCH(dw_bwd_weight_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)x, ldx, (const bf16_t *)dy, lddy, dw, N, H, W, C, OH, OW, stride, pad, dil, ppb);
     else
         return DASS_ERR_UNSUPPORTED;
     DASS_LAUNCH_CHECK();
@@ -452,9 +452,9 @@ extern "C" int dass_dwconv3x3_bwd_weight(const void *x, int64_t ldx, const void 
 extern "C" int dass_box_sum(const float *maps, float *out, float *tmp, int N, int H, int W, int r, void *stream) {
     if (!maps || !out || !tmp || N <= 0 || r <= 0 || r > H || r > W) return DASS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(box_rows_kernel, dim3(dass_grid_1d((long)N * H * (W - r + 1), 256)), dim3(256), 0, st, maps, tmp, N, H, W, r);
+    DASS_LAUNCH(box_rows_kernel, dim3(dass_grid_1d((long)N * H * (W - r + 1), 256)), dim3(256), 0, st, maps, tmp, N, H, W, r);
     DASS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(box_cols_kernel, dim3(dass_grid_1d((long)N * (H - r + 1) * (W - r + 1), 256)), dim3(256), 0, st, tmp, out, N, H, W, r);
+    DASS_LAUNCH(box_cols_kernel, dim3(dass_grid_1d((long)N * (H - r + 1) * (W - r + 1), 256)), dim3(256), 0, st, tmp, out, N, H, W, r);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
@@ -462,7 +462,7 @@ extern "C" int dass_box_sum(const float *maps, float *out, float *tmp, int N, in
 extern "C" int dass_zero_rect(float *maps, int n, int H, int W, int r0, int r1, int c0, int c1, void *stream) {
     if (!maps || n < 0 || r0 < 0 || c0 < 0 || r1 > H || c1 > W) return DASS_ERR_ARG;
     if (r1 <= r0 || c1 <= c0) return DASS_OK;
-    hipLaunchKernelGGL(zero_rect_kernel, dim3(dass_grid_1d((long)(r1 - r0) * (c1 - c0), 256)), dim3(256), 0,
+    DASS_LAUNCH(zero_rect_kernel, dim3(dass_grid_1d((long)(r1 - r0) * (c1 - c0), 256)), dim3(256), 0,
                        (hipStream_t)stream, maps, (long)n * H * W, W, r0, r1, c0, c1);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -478,16 +478,16 @@ extern "C" int dass_minmax(const float *v, int64_t n, float *partial, float *out
     if (!v || !partial || !out_min_max || n <= 0) return DASS_ERR_ARG;
     const int blocks = dass_minmax_blocks(n);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(minmax_stage1_kernel, dim3(blocks), dim3(256), 0, st, v, (long)n, partial);
+    DASS_LAUNCH(minmax_stage1_kernel, dim3(blocks), dim3(256), 0, st, v, (long)n, partial);
     DASS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(minmax_stage2_kernel, dim3(1), dim3(256), 0, st, partial, blocks, out_min_max);
+    DASS_LAUNCH(minmax_stage2_kernel, dim3(1), dim3(256), 0, st, partial, blocks, out_min_max);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
 
 extern "C" int dass_affine_inplace(float *v, int64_t n, const float *min_max, void *stream) {
     if (!v || !min_max || n <= 0) return DASS_ERR_ARG;
-    hipLaunchKernelGGL(affine_kernel, dim3(dass_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, v, (long)n, min_max);
+    DASS_LAUNCH(affine_kernel, dim3(dass_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, v, (long)n, min_max);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
@@ -497,9 +497,9 @@ extern "C" int dass_square_nms(float *maps, int N, int H, int W, int region, int
     if (!maps || !imax || !iarg || !picks || !count || N <= 0 || H <= 0 || W <= 0 || region <= 0 || max_picks <= 0)
         return DASS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(image_argmax_kernel, dim3(N), dim3(256), 0, st, maps, (long)H * W, imax, iarg);
+    DASS_LAUNCH(image_argmax_kernel, dim3(N), dim3(256), 0, st, maps, (long)H * W, imax, iarg);
     DASS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(square_nms_kernel, dim3(1), dim3(1024), 0, st, maps, N, H, W, region, max_picks, imax, iarg,
+    DASS_LAUNCH(square_nms_kernel, dim3(1), dim3(1024), 0, st, maps, N, H, W, region, max_picks, imax, iarg,
                        picks, count);
     DASS_LAUNCH_CHECK();
     return DASS_OK;

@@ -567,7 +567,7 @@ extern "C" int dass_ce_fwd(const float *logits, const void *target, int target_i
                            int C, int64_t HW, int ignore_index, float *partial, void *stream) {
     if (!logits || !target || !partial || N <= 0 || C <= 0 || HW <= 0) return DASS_ERR_ARG;
     const int grid = dass_ce_blocks((int64_t)N * HW);
-    hipLaunchKernelGGL(ce_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, target_is_float,
+    DASS_LAUNCH(ce_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, target_is_float,
                        weight, N, C, HW, ignore_index, partial);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -575,7 +575,7 @@ extern "C" int dass_ce_fwd(const float *logits, const void *target, int target_i
 
 extern "C" int dass_ce_finalize(const float *partial, int blocks, float *acc, void *stream) {
     if (!partial || !acc || blocks <= 0) return DASS_ERR_ARG;
-    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, blocks, acc);
+    DASS_LAUNCH(ce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, blocks, acc);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
@@ -585,7 +585,7 @@ extern "C" int dass_ce_bwd(const float *logits, const void *target, int target_i
                            float *dlogits, void *stream) {
     if (!logits || !target || !acc || !gscale || !dlogits || N <= 0 || C <= 0 || HW <= 0) return DASS_ERR_ARG;
     const int grid = dass_grid_1d((int64_t)N * HW, 256);
-    hipLaunchKernelGGL(ce_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, target_is_float,
+    DASS_LAUNCH(ce_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, target_is_float,
                        weight, N, C, HW, ignore_index, acc, gscale, dlogits);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -601,13 +601,13 @@ extern "C" int dass_upsample_argmax(const void *x, int64_t ldx, uint8_t *votes, 
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DASS_F32 && (ldx & 3) == 0 && !((uintptr_t)x & 15) && ldx >= ((C + 3) & ~3) && 3.f * sw <= 1.f && OW >= 4)
         // four pixels span 3 sw <= 1 input columns: their corners lie in three consecutive columns
-        hipLaunchKernelGGL(upsample_argmax4_kernel, dim3(dass_grid_1d((long)N * OH * ((OW + 3) / 4), 256)), dim3(256), 0, st,
+        DASS_LAUNCH(upsample_argmax4_kernel, dim3(dass_grid_1d((long)N * OH * ((OW + 3) / 4), 256)), dim3(256), 0, st,
                            (const float *)x, ldx, votes, vote_nstride, N, IH, IW, C, OH, OW, sh, sw);
     else if (dtype == DASS_F32)
-        hipLaunchKernelGGL(upsample_argmax_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, ldx, votes,
+        DASS_LAUNCH(upsample_argmax_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, ldx, votes,
                            vote_nstride, N, IH, IW, C, OH, OW, sh, sw);
     else if (dtype == DASS_BF16)
-        hipLaunchKernelGGL(upsample_argmax_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)x, ldx, votes,
+        DASS_LAUNCH(upsample_argmax_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)x, ldx, votes,
                            vote_nstride, N, IH, IW, C, OH, OW, sh, sw);
     else
         return DASS_ERR_UNSUPPORTED;
@@ -619,7 +619,7 @@ extern "C" int dass_argmax_nchw(const float *logits, uint8_t *votes, int64_t vot
                                 void *stream) {
     if (!logits || !votes || N <= 0 || C <= 0 || C > 255 || HW <= 0) return DASS_ERR_ARG;
     const int grid = dass_grid_1d((long)N * HW, 256);
-    hipLaunchKernelGGL(argmax_nchw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, votes, vote_nstride,
+    DASS_LAUNCH(argmax_nchw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, votes, vote_nstride,
                        N, C, HW, nullptr, 0, 0);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -629,7 +629,7 @@ extern "C" int dass_weak_labels(const float *logits, const float *label, int N, 
                                 uint8_t *out, void *stream) {
     if (!logits || !label || !out || N <= 0 || C <= 0 || C > 255 || HW <= 0) return DASS_ERR_ARG;
     const int grid = dass_grid_1d((long)N * HW, 256);
-    hipLaunchKernelGGL(argmax_nchw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, out, HW, N, C, HW,
+    DASS_LAUNCH(argmax_nchw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, out, HW, N, C, HW,
                        label, num_classes, 1);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -642,10 +642,10 @@ extern "C" int dass_vote_entropy(const uint8_t *votes, const float *label, int N
     if (!votes || !partial || !image_sum || N <= 0 || T <= 0 || HW <= 0 || num_classes <= 0 || num_classes > 255)
         return DASS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(vote_entropy_kernel, dim3(SCORE_BLOCKS, N), dim3(256), 0, st, votes, label, T, HW, num_classes,
+    DASS_LAUNCH(vote_entropy_kernel, dim3(SCORE_BLOCKS, N), dim3(256), 0, st, votes, label, T, HW, num_classes,
                        entropy_map, partial);
     DASS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(image_sum_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, st, partial, N, image_sum);
+    DASS_LAUNCH(image_sum_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, st, partial, N, image_sum);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
@@ -654,10 +654,10 @@ extern "C" int dass_softmax_scores(const float *logits, const float *label, int 
                                    int mode, float *map, float *partial, float *image_sum, void *stream) {
     if (!logits || !partial || !image_sum || N <= 0 || C <= 0 || HW <= 0 || mode < 0 || mode > 2) return DASS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(softmax_scores_kernel, dim3(SCORE_BLOCKS, N), dim3(256), 0, st, logits, label, C, HW,
+    DASS_LAUNCH(softmax_scores_kernel, dim3(SCORE_BLOCKS, N), dim3(256), 0, st, logits, label, C, HW,
                        num_classes, mode, map, partial);
     DASS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(image_sum_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, st, partial, N, image_sum);
+    DASS_LAUNCH(image_sum_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, st, partial, N, image_sum);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
@@ -669,9 +669,9 @@ extern "C" int dass_avgpool_features(const void *x, int64_t ldx, float *out, int
     dim3 grid((C + 63) / 64, PH * PW, N);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DASS_F32)
-        hipLaunchKernelGGL(avgpool_features_kernel<float>, grid, dim3(256), 0, st, (const float *)x, ldx, out, H, W, C, k, s, PH, PW);
+        DASS_LAUNCH(avgpool_features_kernel<float>, grid, dim3(256), 0, st, (const float *)x, ldx, out, H, W, C, k, s, PH, PW);
     else if (dtype == DASS_BF16)
-        hipLaunchKernelGGL(avgpool_features_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)x, ldx, out, H, W, C, k, s, PH, PW);
+        DASS_LAUNCH(avgpool_features_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)x, ldx, out, H, W, C, k, s, PH, PW);
     else
         return DASS_ERR_UNSUPPORTED;
     DASS_LAUNCH_CHECK();
@@ -681,7 +681,7 @@ extern "C" int dass_avgpool_features(const void *x, int64_t ldx, float *out, int
 extern "C" int dass_kcenter_update(const float *feat, int64_t n, int d, const int64_t *center, double *min_dist,
                                    int first, void *stream) {
     if (!feat || !center || !min_dist || n <= 0 || d <= 0) return DASS_ERR_ARG;
-    hipLaunchKernelGGL(kcenter_update_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, feat,
+    DASS_LAUNCH(kcenter_update_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, feat,
                        (long)n, d, (const long *)center, min_dist, first);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -698,9 +698,9 @@ extern "C" int dass_argmax_f64(const double *v, int64_t n, double *partial_val, 
     if (!v || !partial_val || !partial_idx || !out_idx || n <= 0) return DASS_ERR_ARG;
     const int blocks = dass_argmax_blocks(n);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(argmax_stage1_kernel, dim3(blocks), dim3(256), 0, st, v, (long)n, partial_val, (long *)partial_idx);
+    DASS_LAUNCH(argmax_stage1_kernel, dim3(blocks), dim3(256), 0, st, v, (long)n, partial_val, (long *)partial_idx);
     DASS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(argmax_stage2_kernel, dim3(1), dim3(256), 0, st, partial_val, (const long *)partial_idx, blocks,
+    DASS_LAUNCH(argmax_stage2_kernel, dim3(1), dim3(256), 0, st, partial_val, (const long *)partial_idx, blocks,
                        (long *)out_idx, out_val);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -709,7 +709,7 @@ extern "C" int dass_argmax_f64(const double *v, int64_t n, double *partial_val, 
 extern "C" int dass_sgd_step(float *p, const float *g, float *buf, int64_t n, float lr, float momentum,
                              float weight_decay, int first_step, void *stream) {
     if (!p || !g || !buf || n <= 0) return DASS_ERR_ARG;
-    hipLaunchKernelGGL(sgd_kernel, dim3(dass_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, buf, (long)n, lr,
+    DASS_LAUNCH(sgd_kernel, dim3(dass_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, buf, (long)n, lr,
                        momentum, weight_decay, first_step);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -733,7 +733,7 @@ extern "C" int dass_sgd_step_multi(void *const *p, const void *const *g, void *c
             blocks += (numel[base + i] + SGD_BLK - 1) / SGD_BLK;
         }
         pk.first_block[pk.n] = blocks;
-        hipLaunchKernelGGL(sgd_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pk, momentum, weight_decay);
+        DASS_LAUNCH(sgd_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pk, momentum, weight_decay);
         DASS_LAUNCH_CHECK();
     }
     return DASS_OK;
@@ -745,7 +745,7 @@ extern "C" const char *dass_arch(void) { return "gfx950"; }
 extern "C" int dass_pairwise_dist_f64(const float *a, int64_t n, const float *b, int64_t m, int d, double *D, void *stream) {
     if (!a || !b || !D || n <= 0 || m <= 0 || d <= 0) return DASS_ERR_ARG;
     const long pairs = (long)n * m;
-    hipLaunchKernelGGL(pairwise_dist_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, (long)n,
+    DASS_LAUNCH(pairwise_dist_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, (long)n,
                        b, (long)m, d, D);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -754,7 +754,7 @@ extern "C" int dass_pairwise_dist_f64(const float *a, int64_t n, const float *b,
 extern "C" int dass_facility_scores(const double *D, int64_t n, int64_t m, const double *mind, const uint8_t *selected,
                                     double *scores, void *stream) {
     if (!D || !mind || !selected || !scores || n <= 0 || m <= 0) return DASS_ERR_ARG;
-    hipLaunchKernelGGL(facility_scores_kernel, dim3((unsigned)m), dim3(256), 0, (hipStream_t)stream, D, (long)n, (long)m, mind,
+    DASS_LAUNCH(facility_scores_kernel, dim3((unsigned)m), dim3(256), 0, (hipStream_t)stream, D, (long)n, (long)m, mind,
                        selected, scores);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -763,7 +763,7 @@ extern "C" int dass_facility_scores(const double *D, int64_t n, int64_t m, const
 extern "C" int dass_facility_update(const double *D, int64_t n, int64_t m, const int64_t *col, double *mind,
                                     uint8_t *selected, void *stream) {
     if (!D || !col || !mind || !selected || n <= 0 || m <= 0) return DASS_ERR_ARG;
-    hipLaunchKernelGGL(facility_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, D, (long)n,
+    DASS_LAUNCH(facility_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, D, (long)n,
                        (long)m, (const long *)col, mind, selected);
     DASS_LAUNCH_CHECK();
     return DASS_OK;

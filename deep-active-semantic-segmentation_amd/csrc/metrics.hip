@@ -47,7 +47,7 @@ extern "C" int dass_confusion_accumulate(const float *logits, const uint8_t *pre
     if ((!logits && !pred) || !target || !cm || N <= 0 || HW <= 0 || num_class <= 0 || num_class > 64) return DASS_ERR_ARG;
     if (logits && C <= 0) return DASS_ERR_ARG;
     const int grid = dass_grid_1d((long)N * HW, 256);
-    hipLaunchKernelGGL(confusion_kernel, dim3(grid), dim3(256), sizeof(unsigned int) * num_class * num_class,
+    DASS_LAUNCH(confusion_kernel, dim3(grid), dim3(256), sizeof(unsigned int) * num_class * num_class,
                        (hipStream_t)stream, logits, pred, target, N, C, (long)HW, num_class, (unsigned long long *)cm);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -85,7 +85,7 @@ extern "C" int dass_bn_finalize_sums(const float *sums, int K, double count, con
                                      float *running_mean, float *running_var, float momentum, float eps, int clamp_var,
                                      float *mean, float *invstd, float *scale, float *shift, void *stream) {
     if (!sums || K <= 0 || count <= 0 || !mean || !invstd || !scale || !shift) return DASS_ERR_ARG;
-    hipLaunchKernelGGL(bn_finalize_sums_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, K, count,
+    DASS_LAUNCH(bn_finalize_sums_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, K, count,
                        gamma, beta, running_mean, running_var, momentum, eps, clamp_var, mean, invstd, scale, shift);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long *ou
 
 extern "C" int dass_clock_probe(void *out, int blocks, int iters, int use_lds, void *stream) {
     if (!out || blocks <= 0 || iters <= 0) return DASS_ERR_ARG;
-    hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned long long *)out, iters, use_lds);
+    DASS_LAUNCH(clock_probe_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned long long *)out, iters, use_lds);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }

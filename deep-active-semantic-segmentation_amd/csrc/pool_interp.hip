@@ -339,8 +339,8 @@ extern "C" int dass_nchw_to_nhwc(const float *x, void *y, int N, int C, int H, i
     const int grid = dass_grid_1d((long)N * H * W * Cpad, 256);
     hipStream_t st = (hipStream_t)stream;
     DASS_DISPATCH(dtype,
-                  hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid), dim3(256), 0, st, x, (float *)y, N, C, H, W, Cpad),
-                  hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, x, (bf16_t *)y, N, C, H, W, Cpad))
+                  DASS_LAUNCH(nchw_to_nhwc_kernel<float>, dim3(grid), dim3(256), 0, st, x, (float *)y, N, C, H, W, Cpad),
+                  DASS_LAUNCH(nchw_to_nhwc_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, x, (bf16_t *)y, N, C, H, W, Cpad))
 }
 
 extern "C" int dass_nhwc_to_nchw(const void *x, int64_t ldx, float *y, int N, int C, int H, int W, int dtype,
@@ -349,8 +349,8 @@ extern "C" int dass_nhwc_to_nchw(const void *x, int64_t ldx, float *y, int N, in
     const int grid = dass_grid_1d((long)N * H * W * C, 256);
     hipStream_t st = (hipStream_t)stream;
     DASS_DISPATCH(dtype,
-                  hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, ldx, y, N, C, H, W),
-                  hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)x, ldx, y, N, C, H, W))
+                  DASS_LAUNCH(nhwc_to_nchw_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, ldx, y, N, C, H, W),
+                  DASS_LAUNCH(nhwc_to_nchw_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)x, ldx, y, N, C, H, W))
 }
 
 extern "C" int dass_copy_channels(const void *src, int64_t lds, void *dst, int64_t ldd, int64_t M, int C, int dtype,
@@ -359,8 +359,8 @@ extern "C" int dass_copy_channels(const void *src, int64_t lds, void *dst, int64
     const int grid = dass_grid_1d(M * (C / 4), 256);
     hipStream_t st = (hipStream_t)stream;
     DASS_DISPATCH(dtype,
-                  hipLaunchKernelGGL((copy_channels_kernel<float, false>), dim3(grid), dim3(256), 0, st, (const float *)src, lds, (float *)dst, ldd, M, C),
-                  hipLaunchKernelGGL((copy_channels_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, st, (const bf16_t *)src, lds, (bf16_t *)dst, ldd, M, C))
+                  DASS_LAUNCH((copy_channels_kernel<float, false>), dim3(grid), dim3(256), 0, st, (const float *)src, lds, (float *)dst, ldd, M, C),
+                  DASS_LAUNCH((copy_channels_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, st, (const bf16_t *)src, lds, (bf16_t *)dst, ldd, M, C))
 }
 
 extern "C" int dass_add_channels(const void *src, int64_t lds, void *dst, int64_t ldd, int64_t M, int C, int dtype,
@@ -369,8 +369,8 @@ extern "C" int dass_add_channels(const void *src, int64_t lds, void *dst, int64_
     const int grid = dass_grid_1d(M * (C / 4), 256);
     hipStream_t st = (hipStream_t)stream;
     DASS_DISPATCH(dtype,
-                  hipLaunchKernelGGL((copy_channels_kernel<float, true>), dim3(grid), dim3(256), 0, st, (const float *)src, lds, (float *)dst, ldd, M, C),
-                  hipLaunchKernelGGL((copy_channels_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, st, (const bf16_t *)src, lds, (bf16_t *)dst, ldd, M, C))
+                  DASS_LAUNCH((copy_channels_kernel<float, true>), dim3(grid), dim3(256), 0, st, (const float *)src, lds, (float *)dst, ldd, M, C),
+                  DASS_LAUNCH((copy_channels_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, st, (const bf16_t *)src, lds, (bf16_t *)dst, ldd, M, C))
 }
 
 /* dst[m][c] = sum_j src_j[m][c], 2 <= n <= 8 sources given as n pointers and n pixel strides (host arrays) */
@@ -386,8 +386,8 @@ extern "C" int dass_sum_channels(const void *const *srcs, const int64_t *lds, in
     }
     const int grid = dass_grid_1d(M * (C / 4), 256);
     hipStream_t st = (hipStream_t)stream;
-    DASS_DISPATCH(dtype, hipLaunchKernelGGL(sum_n_kernel<float>, dim3(grid), dim3(256), 0, st, p, (float *)dst, ldd, M, C),
-                  hipLaunchKernelGGL(sum_n_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, p, (bf16_t *)dst, ldd, M, C))
+    DASS_DISPATCH(dtype, DASS_LAUNCH(sum_n_kernel<float>, dim3(grid), dim3(256), 0, st, p, (float *)dst, ldd, M, C),
+                  DASS_LAUNCH(sum_n_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, p, (bf16_t *)dst, ldd, M, C))
 }
 
 extern "C" int dass_maxpool3x3s2_fwd(const void *x, void *y, uint8_t *idx, int N, int H, int W, int C, int OH, int OW,
@@ -396,8 +396,8 @@ extern "C" int dass_maxpool3x3s2_fwd(const void *x, void *y, uint8_t *idx, int N
     const int grid = dass_grid_1d((long)N * OH * OW * (C / 4), 256);
     hipStream_t st = (hipStream_t)stream;
     DASS_DISPATCH(dtype,
-                  hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, (float *)y, idx, N, H, W, C, OH, OW),
-                  hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)x, (bf16_t *)y, idx, N, H, W, C, OH, OW))
+                  DASS_LAUNCH(maxpool_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, (float *)y, idx, N, H, W, C, OH, OW),
+                  DASS_LAUNCH(maxpool_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)x, (bf16_t *)y, idx, N, H, W, C, OH, OW))
 }
 
 extern "C" int dass_maxpool3x3s2_bwd(const void *dy, const uint8_t *idx, void *dx, int N, int H, int W, int C, int OH,
@@ -406,8 +406,8 @@ extern "C" int dass_maxpool3x3s2_bwd(const void *dy, const uint8_t *idx, void *d
     const int grid = dass_grid_1d((long)N * H * W * (C / 4), 256);
     hipStream_t st = (hipStream_t)stream;
     DASS_DISPATCH(dtype,
-                  hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)dy, idx, (float *)dx, N, H, W, C, OH, OW),
-                  hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)dy, idx, (bf16_t *)dx, N, H, W, C, OH, OW))
+                  DASS_LAUNCH(maxpool_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)dy, idx, (float *)dx, N, H, W, C, OH, OW),
+                  DASS_LAUNCH(maxpool_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)dy, idx, (bf16_t *)dx, N, H, W, C, OH, OW))
 }
 
 extern "C" int dass_global_avgpool_fwd(const void *x, int64_t ldx, void *y, int N, int64_t HW, int C, int dtype,
@@ -416,8 +416,8 @@ extern "C" int dass_global_avgpool_fwd(const void *x, int64_t ldx, void *y, int 
     dim3 grid((C + 63) / 64, N);
     hipStream_t st = (hipStream_t)stream;
     DASS_DISPATCH(dtype,
-                  hipLaunchKernelGGL((reduce_rows_kernel<float, true>), grid, dim3(256), 0, st, (const float *)x, ldx, (float *)y, N, HW, C),
-                  hipLaunchKernelGGL((reduce_rows_kernel<bf16_t, true>), grid, dim3(256), 0, st, (const bf16_t *)x, ldx, (bf16_t *)y, N, HW, C))
+                  DASS_LAUNCH((reduce_rows_kernel<float, true>), grid, dim3(256), 0, st, (const float *)x, ldx, (float *)y, N, HW, C),
+                  DASS_LAUNCH((reduce_rows_kernel<bf16_t, true>), grid, dim3(256), 0, st, (const bf16_t *)x, ldx, (bf16_t *)y, N, HW, C))
 }
 
 extern "C" int dass_reduce_rows(const void *src, int64_t lds, void *dst, int N, int64_t HW, int C, int dtype,
@@ -426,8 +426,8 @@ extern "C" int dass_reduce_rows(const void *src, int64_t lds, void *dst, int N, 
     dim3 grid((C + 63) / 64, N);
     hipStream_t st = (hipStream_t)stream;
     DASS_DISPATCH(dtype,
-                  hipLaunchKernelGGL((reduce_rows_kernel<float, false>), grid, dim3(256), 0, st, (const float *)src, lds, (float *)dst, N, HW, C),
-                  hipLaunchKernelGGL((reduce_rows_kernel<bf16_t, false>), grid, dim3(256), 0, st, (const bf16_t *)src, lds, (bf16_t *)dst, N, HW, C))
+                  DASS_LAUNCH((reduce_rows_kernel<float, false>), grid, dim3(256), 0, st, (const float *)src, lds, (float *)dst, N, HW, C),
+                  DASS_LAUNCH((reduce_rows_kernel<bf16_t, false>), grid, dim3(256), 0, st, (const bf16_t *)src, lds, (bf16_t *)dst, N, HW, C))
 }
 
 extern "C" int dass_broadcast_rows(const void *src, void *dst, int64_t ldd, int N, int64_t HW, int C, float mult,
@@ -436,8 +436,8 @@ extern "C" int dass_broadcast_rows(const void *src, void *dst, int64_t ldd, int 
     const int grid = dass_grid_1d((long)N * HW * (C / 4), 256);
     hipStream_t st = (hipStream_t)stream;
     DASS_DISPATCH(dtype,
-                  hipLaunchKernelGGL(broadcast_rows_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)src, (float *)dst, ldd, N, HW, C, mult),
-                  hipLaunchKernelGGL(broadcast_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)src, (bf16_t *)dst, ldd, N, HW, C, mult))
+                  DASS_LAUNCH(broadcast_rows_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)src, (float *)dst, ldd, N, HW, C, mult),
+                  DASS_LAUNCH(broadcast_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)src, (bf16_t *)dst, ldd, N, HW, C, mult))
 }
 
 extern "C" int dass_bilinear_fwd(const void *x, int64_t ldx, void *y, int64_t ldy, int N, int IH, int IW, int C,
@@ -448,14 +448,14 @@ extern "C" int dass_bilinear_fwd(const void *x, int64_t ldx, void *y, int64_t ld
     if (out_nchw) {
         const int grid = dass_grid_1d((long)N * OH * OW, 256);
         DASS_DISPATCH(dtype,
-                      hipLaunchKernelGGL(bilinear_fwd_nchw_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, ldx, (float *)y, N, IH, IW, C, OH, OW, sh, sw),
-                      hipLaunchKernelGGL(bilinear_fwd_nchw_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)x, ldx, (float *)y, N, IH, IW, C, OH, OW, sh, sw))
+                      DASS_LAUNCH(bilinear_fwd_nchw_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, ldx, (float *)y, N, IH, IW, C, OH, OW, sh, sw),
+                      DASS_LAUNCH(bilinear_fwd_nchw_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)x, ldx, (float *)y, N, IH, IW, C, OH, OW, sh, sw))
     }
     if (C % 4 || ldx % 4 || ldy % 4) return DASS_ERR_ARG;
     const int grid = dass_grid_1d((long)N * OH * OW * (C / 4), 256);
     DASS_DISPATCH(dtype,
-                  hipLaunchKernelGGL(bilinear_fwd_nhwc_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, ldx, (float *)y, ldy, N, IH, IW, C, OH, OW, sh, sw),
-                  hipLaunchKernelGGL(bilinear_fwd_nhwc_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)x, ldx, (bf16_t *)y, ldy, N, IH, IW, C, OH, OW, sh, sw))
+                  DASS_LAUNCH(bilinear_fwd_nhwc_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, ldx, (float *)y, ldy, N, IH, IW, C, OH, OW, sh, sw),
+                  DASS_LAUNCH(bilinear_fwd_nhwc_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)x, ldx, (bf16_t *)y, ldy, N, IH, IW, C, OH, OW, sh, sw))
 }
 
 extern "C" int dass_bilinear_bwd(const void *dy, int64_t lddy, void *dx, int64_t lddx, int N, int IH, int IW, int C,
@@ -466,12 +466,12 @@ extern "C" int dass_bilinear_bwd(const void *dy, int64_t lddy, void *dx, int64_t
     if (dy_nchw) {
         const int grid = dass_grid_1d((long)N * C * IH * IW, 256);
         DASS_DISPATCH(dtype,
-                      hipLaunchKernelGGL(bilinear_bwd_nchw_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)dy, (float *)dx, lddx, N, IH, IW, C, OH, OW, sh, sw),
-                      hipLaunchKernelGGL(bilinear_bwd_nchw_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const float *)dy, (bf16_t *)dx, lddx, N, IH, IW, C, OH, OW, sh, sw))
+                      DASS_LAUNCH(bilinear_bwd_nchw_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)dy, (float *)dx, lddx, N, IH, IW, C, OH, OW, sh, sw),
+                      DASS_LAUNCH(bilinear_bwd_nchw_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const float *)dy, (bf16_t *)dx, lddx, N, IH, IW, C, OH, OW, sh, sw))
     }
     if (C % 4 || lddx % 4 || lddy % 4) return DASS_ERR_ARG;
     const int grid = dass_grid_1d((long)N * IH * IW * (C / 4), 256);
     DASS_DISPATCH(dtype,
-                  hipLaunchKernelGGL(bilinear_bwd_nhwc_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)dy, lddy, (float *)dx, lddx, N, IH, IW, C, OH, OW, sh, sw),
-                  hipLaunchKernelGGL(bilinear_bwd_nhwc_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)dy, lddy, (bf16_t *)dx, lddx, N, IH, IW, C, OH, OW, sh, sw))
+                  DASS_LAUNCH(bilinear_bwd_nhwc_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)dy, lddy, (float *)dx, lddx, N, IH, IW, C, OH, OW, sh, sw),
+                  DASS_LAUNCH(bilinear_bwd_nhwc_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)dy, lddy, (bf16_t *)dx, lddx, N, IH, IW, C, OH, OW, sh, sw))
 }

@@ -97,10 +97,10 @@ extern "C" int dass_resample_bilinear_u8(const void *src, int H, int W, int src_
     if (!src || !tmp || !dst || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || src_ch < 3) return DASS_ERR_ARG;
     if (!xmin || !xcnt || !xkk || !ymin || !ycnt || !ykk || xksize <= 0 || yksize <= 0) return DASS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(resample_h_kernel, dim3(dass_grid_1d((long)H * OW, 256)), dim3(256), 0, st, (const uint8_t *)src, H, W, src_ch,
+    DASS_LAUNCH(resample_h_kernel, dim3(dass_grid_1d((long)H * OW, 256)), dim3(256), 0, st, (const uint8_t *)src, H, W, src_ch,
                        (uint8_t *)tmp, OW, xmin, xcnt, xkk, xksize);
     DASS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(resample_v_kernel, dim3(dass_grid_1d((long)OH * OW * 3, 256)), dim3(256), 0, st, (const uint8_t *)tmp, H, OW,
+    DASS_LAUNCH(resample_v_kernel, dim3(dass_grid_1d((long)OH * OW * 3, 256)), dim3(256), 0, st, (const uint8_t *)tmp, H, OW,
                        (uint8_t *)dst, OH, ymin, ycnt, ykk, yksize);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -110,7 +110,7 @@ extern "C" int dass_pool_finalize(const void *img, int OH, int OW, const void *r
                                   int oy0, int ox0, int S, int divide255, int f64_chain, float *out_img, float *out_lab, void *stream) {
     if (!img || !out_img || OH <= 0 || OW <= 0 || S <= 0) return DASS_ERR_ARG;
     if (out_lab && (!rec || !yidx || !xidx || rec_ch < 4 || W <= 0)) return DASS_ERR_ARG;
-    hipLaunchKernelGGL(pool_finalize_kernel, dim3(dass_grid_1d((long)S * S, 256)), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)img,
+    DASS_LAUNCH(pool_finalize_kernel, dim3(dass_grid_1d((long)S * S, 256)), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)img,
                        OH, OW, (const uint8_t *)rec, W, rec_ch, yidx, xidx, oy0, ox0, S, divide255, f64_chain, out_img, out_lab);
     DASS_LAUNCH_CHECK();
     return DASS_OK;

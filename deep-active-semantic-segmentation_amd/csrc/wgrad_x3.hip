@@ -339,7 +339,7 @@ template <int BMK, int BNC, int WARPS_M, int WARPS_N, int NSTAGE, int NP = 3> in
     pps = (pps + 31) / 32 * 32;
     p.pix_per_split = (int)pps;
     p.psplit = (int)((p.M + pps - 1) / pps);
-    hipLaunchKernelGGL((wgrad_x3_kernel<BMK, BNC, WARPS_M, WARPS_N, NSTAGE, NP>), dim3((unsigned)(base * p.psplit)), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
+    DASS_LAUNCH((wgrad_x3_kernel<BMK, BNC, WARPS_M, WARPS_N, NSTAGE, NP>), dim3((unsigned)(base * p.psplit)), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
@@ -455,7 +455,7 @@ int launch_group(GroupItem *it, int n, char *scratch, hipStream_t st) {
     if (hipMemcpyAsync(dev_b, host_b, sizeof(int) * (n + 1), hipMemcpyHostToDevice, st) != hipSuccess) return DASS_ERR_LAUNCH;
     if (hipEventRecord(sl.done, st) != hipSuccess) return DASS_ERR_LAUNCH;
     sl.used = true;
-    hipLaunchKernelGGL((wgrad_x3_group_kernel<BMK, BNC, WARPS_M, WARPS_N, NSTAGE, NP>), dim3((unsigned)total), dim3(64 * WARPS_M * WARPS_N), 0, st, dev_p, dev_b, n);
+    DASS_LAUNCH((wgrad_x3_group_kernel<BMK, BNC, WARPS_M, WARPS_N, NSTAGE, NP>), dim3((unsigned)total), dim3(64 * WARPS_M * WARPS_N), 0, st, dev_p, dev_b, n);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }

@@ -80,93 +80,104 @@ def check(rc, name):
 CONV_ENTRY_POINTS = ("dass_conv2d_igemm", "dass_conv2d_igemm_stats", "dass_conv2d_igemm_sums", "dass_conv2d_wgrad", "dass_conv2d_wgrad_acc",
                      "dass_conv2d_rowtap", "dass_conv2d_rowtap_wgrad", "dass_conv2d_x3", "dass_conv2d_x3_sums", "dass_conv2d_x3_dgrad_bnstats",
                      "dass_conv2d_x3_per_image", "dass_conv2d_wgrad_x3", "dass_conv2d_wgrad_x3_group")
+BN_ENTRY_POINTS = ("dass_bn_apply_train", "dass_bn_bwd_apply_sums", "dass_bn_bwd_reduce_sums")
+
+
+def _val(a):
+    return a.value if hasattr(a, "value") else a
+
+
+def _conv_gflop(name, args):
+    """2 x output rows x K x R x S x C of the conv this call computes (input rows for a strided input gradient), from its arguments"""
+    idx = {n: i for i, n in enumerate(ARG_NAMES[name])}
+    if name == "dass_conv2d_wgrad_x3_group":
+        import numpy as np
+
+        n = int(_val(args[idx["n"]]))
+        ptr = ctypes.cast(args[idx["items"]], ctypes.POINTER(ctypes.c_int64 * (16 * n)))
+        it = np.frombuffer(ptr.contents, dtype=np.int64).reshape(n, 16)
+        nn, h, w, c, oh, ow, k, r, s = (it[:, 3 + j].astype(np.float64) for j in range(9))
+        return float((2.0 * nn * oh * ow * k * r * s * c).sum() / 1e9)
+    g = lambda key: float(_val(args[idx[key]]))  # noqa: E731
+    us = g("ustride") if "ustride" in idx else 1.0
+    out_rows = g("N") * (g("H") * g("W") if us > 1 else g("OH") * g("OW"))
+    return 2.0 * out_rows * g("K") * g("R") * g("S") * g("C" if "C" in idx else "Cin") / 1e9
+
+
+def _bn_gbytes(name, args):
+    """ALGORITHMIC bytes of one train-mode BN pass in f32: every [M][K] tensor the call reads or writes once, 4 B per element
+    (two f16 parts of a split-row output: 4 B as well), gate bits 1 B per 4 channels; a null pointer = that tensor is not touched"""
+    idx = {n: i for i, n in enumerate(ARG_NAMES[name])}
+    has = lambda key: key in idx and _val(args[idx[key]]) not in (None, 0)  # noqa: E731
+    e = float(_val(args[idx["M"]])) * float(_val(args[idx["K"]]))
+    tensors = {"dass_bn_apply_train": ("x", "out", "residual", "out3"),
+               "dass_bn_bwd_apply_sums": ("dout", "out", "x", "dx", "dres", "dx3"),
+               "dass_bn_bwd_reduce_sums": ("dout", "out", "x")}[name]
+    b = sum(4.0 * e for t in tensors if has(t))
+    if has("gates"):
+        b += e / 4.0
+    return b / 1e9
 
 
 class KernelTimer(object):
-    """HIP events around every call of the named C-ABI entry points, recorded ON THE STREAM EACH CALL LAUNCHES ON (its last
-    argument) -- torch.cuda.Event would only see torch's current stream, and the chunked weight gradients run on a side stream.
+    """Kernel-exact timing of real steps through the library's own profile (include/dass_hip.h dass_prof_*): while the context is
+    open every kernel launch of libdass_hip carries a start / stop HIP event pair bound to that dispatch, ON THE STREAM IT IS
+    LAUNCHED ON (the chunked weight gradients run on a side stream; torch.cuda.Event would only see torch's current stream).
 
-        with KernelTimer(CONV_ENTRY_POINTS) as kt:
+        with KernelTimer() as kt:
             train_step()
-        rows = kt.rows()   # [(entry point, tag, gflop, ms)] per call, after one device synchronize
+        kernels, calls = kt.results()
+        # kernels: [(kernel name, ms, workgroups, stream)] for EVERY launch, in launch order -- a rocprofv3 kernel trace, live
+        # calls:   [(entry point, tag, work, ms, [kernel names])] per call of a conv / BN entry point: ms = sum of the kernels
+        #          that call enqueued (a phase-decomposed input gradient is up to four, a stream-K conv has its fix-up pass);
+        #          work = GFLOP (conv: 2 x output rows x K x R x S x C from the call's own arguments) or GB (BN passes);
+        #          tag = the pre-split conv kernel's tile class (dass_x3_last_pick)
 
-    A call's duration is stop-event minus start-event on its stream: the kernels that call enqueued (a phase-decomposed input
-    gradient is up to four, a stream-K conv has its fix-up pass), plus whatever the stream waited for in between -- nothing, for
-    launches that are issued back to back.  Launches on two streams overlap in time; their durations are summed, not merged
-    (the same convention as a rocprofv3 kernel table).  gflop = 2 x output rows x K x R x S x C of the conv the call computes
-    (input rows for a strided input gradient), from the call's own arguments.  tag = the pre-split kernel's tile pick of that
-    call (dass_x3_last_pick) where the library reports one."""
+    Launches on two streams overlap in time; durations are summed, not merged (as in a rocprofv3 kernel table)."""
 
-    def __init__(self, names=CONV_ENTRY_POINTS):
-        self.names = [n for n in names if n in PROTOTYPES]
-        self.hip = ctypes.CDLL("libamdhip64.so")
-        self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
-        self.hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-        self.hip.hipEventSynchronize.argtypes = [ctypes.c_void_p]
-        self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
-        self.hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
+    def __init__(self, conv=CONV_ENTRY_POINTS, bn=BN_ENTRY_POINTS):
+        self.work = {n: _conv_gflop for n in conv if n in PROTOTYPES}
+        self.work.update({n: _bn_gbytes for n in bn if n in PROTOTYPES})
         self.calls = []
         self.saved = {}
 
-    def _event(self):
-        ev = ctypes.c_void_p()
-        if self.hip.hipEventCreate(ctypes.byref(ev)) != 0:
-            raise RuntimeError("hipEventCreate failed")
-        return ev
-
-    @staticmethod
-    def _val(a):
-        return a.value if hasattr(a, "value") else a
-
-    def _gflop(self, name, args):
-        idx = {n: i for i, n in enumerate(ARG_NAMES[name])}
-        if name == "dass_conv2d_wgrad_x3_group":
-            import numpy as np
-
-            n = int(self._val(args[idx["n"]]))
-            ptr = ctypes.cast(args[idx["items"]], ctypes.POINTER(ctypes.c_int64 * (16 * n)))
-            it = np.frombuffer(ptr.contents, dtype=np.int64).reshape(n, 16)
-            nn, h, w, c, oh, ow, k, r, s = (it[:, 3 + j].astype(np.float64) for j in range(9))
-            return float((2.0 * nn * oh * ow * k * r * s * c).sum() / 1e9)
-        g = lambda key: float(self._val(args[idx[key]]))  # noqa: E731
-        us = g("ustride") if "ustride" in idx else 1.0
-        out_rows = g("N") * (g("H") * g("W") if us > 1 else g("OH") * g("OW"))
-        return 2.0 * out_rows * g("K") * g("R") * g("S") * g("C" if "C" in idx else "Cin") / 1e9
-
     def _wrap(self, name, fn):
-        pick = getattr(lib, "dass_x3_last_pick", None) if "x3" in name and "wgrad" not in name else None
+        pick = lib.dass_x3_last_pick if ("x3" in name and "wgrad" not in name and "conv2d" in name) else None
+        work = self.work[name]
 
         def timed(*args):
-            stream = self._val(args[-1])
-            e0, e1 = self._event(), self._event()
-            self.hip.hipEventRecord(e0, stream)
+            i0 = lib.dass_prof_count()
             rc = fn(*args)
-            self.hip.hipEventRecord(e1, stream)
-            self.calls.append((name, pick() if pick is not None else 0, self._gflop(name, args), e0, e1))
+            self.calls.append((name, pick() if pick is not None else 0, work(name, args), i0, lib.dass_prof_count()))
             return rc
 
         return timed
 
     def __enter__(self):
-        for n in self.names:
+        check(lib.dass_prof_begin(), "dass_prof_begin")
+        for n in self.work:
             self.saved[n] = getattr(lib, n)
             setattr(lib, n, self._wrap(n, self.saved[n]))
         return self
 
     def __exit__(self, *exc):
+        lib.dass_prof_end()
         for n, fn in self.saved.items():
             setattr(lib, n, fn)
         self.saved = {}
 
-    def rows(self):
-        out = []
-        ms = ctypes.c_float(0.0)
-        for name, tag, gflop, e0, e1 in self.calls:
-            self.hip.hipEventSynchronize(e1)
-            if self.hip.hipEventElapsedTime(ctypes.byref(ms), e0, e1) != 0:
-                raise RuntimeError("hipEventElapsedTime failed")
-            out.append((name, tag, gflop, float(ms.value)))
-            self.hip.hipEventDestroy(e0)
-            self.hip.hipEventDestroy(e1)
+    def restart(self):
+        """forget what was recorded so far (e.g. an untimed first step) and keep recording"""
         self.calls = []
-        return out
+        check(lib.dass_prof_begin(), "dass_prof_begin")
+
+    def results(self):
+        n = lib.dass_prof_count()
+        buf = ctypes.create_string_buffer(512)
+        ms, grid, st = ctypes.c_float(0.0), ctypes.c_int64(0), ctypes.c_void_p()
+        kernels = []
+        for i in range(n):
+            check(lib.dass_prof_get(i, buf, 512, ctypes.byref(ms), ctypes.byref(grid), ctypes.byref(st)), "dass_prof_get")
+            kernels.append((buf.value.decode("ascii", "replace"), float(ms.value), int(grid.value), st.value or 0))
+        calls = [(name, tag, work, sum(k[1] for k in kernels[i0:i1]), [k[0] for k in kernels[i0:i1]]) for name, tag, work, i0, i1 in self.calls]
+        return kernels, calls

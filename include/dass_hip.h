@@ -424,6 +424,17 @@ int dass_x3_force_tile(int tile);
  * specialisation) | 1 (stream-K schedule + fix-up pass).  Host state only (no device work); bench.py's in-step roofline uses it
  * to attribute launch times to tile classes.  No reference counterpart (the reference's convs are ATen calls). */
 int dass_x3_last_pick(void);
+/* Measurement infrastructure (csrc/prof.hip; bench.py's in-step `roofline`, SURVEY.md 8d "measured live inside bench.py with HIP
+ * events ... on the stream the kernel is launched on").  Between dass_prof_begin() and dass_prof_end() EVERY kernel this library
+ * launches carries a start / stop event pair bound to that one dispatch (hipExtLaunchKernelGGL), on the stream of the launch:
+ * dass_prof_get(i) returns launch i's kernel name, its own begin -> end duration in ms (waiting for it to finish), its grid size in
+ * workgroups and its stream -- what a rocprofv3 kernel trace would list.  dass_prof_count(): launches recorded so far (callers
+ * bracket an entry-point call with it to learn which kernels that call enqueued).  Outside a profile the launch path is the
+ * plain one.  No reference counterpart. */
+int dass_prof_begin(void);
+int dass_prof_end(void);
+int dass_prof_count(void);
+int dass_prof_get(int i, char *name, int name_bytes, float *ms, int64_t *grid, void **stream);
 /* Host-only helper: the (multiplier, shift) pair with which dass_conv2d_x3's kernels divide a pixel index n (0 <= n < 2^31)
  * by d = OH*OW or OW:  n / d == (n * mul >> 32) >> shift,  shift < 0 meaning d == 1 (quotient n).  Exported for the CPU tests. */
 int dass_x3_magic(int d, unsigned *mul, int *shift);

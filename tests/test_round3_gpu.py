@@ -514,3 +514,50 @@ def test_pipelined_image_scores_equal_sequential_scores():
     for a in res["sequential"] + res["pipelined"]:
         assert torch.equal(a, res["sequential"][0])
     assert float(res["sequential"][0].max()) > 0.0
+
+
+# ------------------------------------------------------------------------------------------- the library's launch profile (round 4)
+def test_launch_profile_reports_kernel_durations():
+    """include/dass_hip.h dass_prof_*: with a profile open every launch carries its own start / stop event pair; the durations it
+    reports for 20 back-to-back launches of one big conv must add up to the wall time torch's events see around the same 20
+    launches (within 10 %: the plain events also see the inter-launch gaps), results are unchanged, and outside a profile
+    nothing is recorded."""
+    ops, O, S = _setup()
+    from dass_hip._lib import KernelTimer, lib
+
+    keep = ops.f32_mma()
+    try:
+        ops.set_f32_mma("f16x3")
+        n, h, c, k = 8, 129, 304, 256
+        x = torch.randn((n, h, h, c), device="cuda")
+        wt = torch.randn((k, 3, 3, c), device="cuda") * 0.02
+        dims = (n, h, h, c, h, h, k, 3, 3, 1, 1, 1)
+        x3 = ops.split3_rows(x, c, n * h * h, c)
+        wop = ops.prepare_conv_weight(wt, x3=True)
+        y0 = torch.empty((n, h, h, k), device="cuda")
+        ops.conv_x3_launch(x3, wop, y0, k, dims)
+        y1 = torch.empty_like(y0)
+        with KernelTimer() as kt:
+            ops.conv_x3_launch(x3, wop, y1, k, dims)
+            torch.cuda.synchronize()
+            kt.restart()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                ops.conv_x3_launch(x3, wop, y1, k, dims)
+            e1.record()
+            torch.cuda.synchronize()
+            kernels, calls = kt.results()
+        assert torch.equal(y0, y1)
+        wall = e0.elapsed_time(e1)
+        assert len(calls) == 20 and all(c[0] == "dass_conv2d_x3" for c in calls)
+        assert abs(calls[0][2] - 2.0 * n * h * h * k * 9 * c / 1e9) < 1e-3   # GFLOP from the call's own arguments
+        total = sum(c[3] for c in calls)
+        print("profiled kernel time %.3f ms vs %.3f ms wall for 20 launches; kernels per call: %s" % (total, wall, calls[0][4]))
+        assert 0.85 * wall <= total <= 1.02 * wall, (total, wall)
+        assert all("conv_x3" in kn for kn in calls[0][4])
+        before = lib.dass_prof_count()
+        ops.conv_x3_launch(x3, wop, y1, k, dims)     # profile closed: the plain launch path, nothing recorded
+        assert lib.dass_prof_count() == before
+    finally:
+        ops.set_f32_mma(keep)
