@@ -66,22 +66,7 @@ struct X3P {
     int bs_act;
 };
 
-// n / d for 0 <= n < 2^31 with the host's magic pair (x3_set_magic): mul = ceil(2^(31 + l) / d), l = ceil(log2 d), shift = l - 1
-// (Granlund-Montgomery: 2^(31+l) <= mul d <= 2^(31+l) + 2^l makes the product's high part exact); d = 1 travels as shift < 0
-__device__ __forceinline__ int x3_fastdiv(int n, unsigned mul, int shift) {
-    return shift < 0 ? n : (int)(__umulhi((unsigned)n, mul) >> shift);
-}
-static inline void x3_set_magic(int d, unsigned &mul, int &shift) {
-    if (d <= 1) {
-        mul = 0u;
-        shift = -1;
-        return;
-    }
-    int l = 0;
-    while ((1ll << l) < d) ++l;
-    mul = (unsigned)(((1ull << (31 + l)) + (unsigned long long)d - 1ull) / (unsigned long long)d);
-    shift = l - 1;
-}
+// (x3_fastdiv / x3_set_magic: dass_common.h)
 __device__ __forceinline__ int x3_sk_bound(const X3P &p, int w) { return w * p.sk_q + (w < p.sk_r ? w : p.sk_r); }
 
 typedef int v4i __attribute__((ext_vector_type(4)));

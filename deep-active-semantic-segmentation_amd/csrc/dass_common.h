@@ -190,6 +190,24 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// n / d for 0 <= n < 2^31 with a host-made magic pair: mul = ceil(2^(31 + l) / d), l = ceil(log2 d), shift = l - 1
+// (Granlund-Montgomery: 2^(31+l) <= mul d <= 2^(31+l) + 2^l makes the product's high part exact); d = 1 travels as shift < 0.
+// Checked exhaustively against `/` on the CPU (tests/test_cpu.py through dass_x3_magic).
+__device__ __forceinline__ int x3_fastdiv(int n, unsigned mul, int shift) {
+    return shift < 0 ? n : (int)(__umulhi((unsigned)n, mul) >> shift);
+}
+static inline void x3_set_magic(int d, unsigned &mul, int &shift) {
+    if (d <= 1) {
+        mul = 0u;
+        shift = -1;
+        return;
+    }
+    int l = 0;
+    while ((1ll << l) < d) ++l;
+    mul = (unsigned)(((1ull << (31 + l)) + (unsigned long long)d - 1ull) / (unsigned long long)d);
+    shift = l - 1;
+}
+
 static inline int dass_grid_1d(int64_t work_items, int block) {
     int64_t g = (work_items + block - 1) / block;
     const int64_t cap = 256 * 8;  // 256 CUs x 8 blocks: grid-stride the rest

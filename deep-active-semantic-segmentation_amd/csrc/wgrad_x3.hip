@@ -14,6 +14,7 @@
 // Reference site replaced: the weight gradient autograd derives for every dense nn.Conv2d of the DeepLab path.
 #include "dass_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -25,18 +26,40 @@ struct WX3P {
     unsigned dy_tr, x_tr;  // trailers {inv_scale, bound} of the two-part format
     int N, H, W, C, OH, OW, K, R, S, stride, pad, dil;
     int M, KC, CC, ktiles, ctiles, psplit, pix_per_split;
+    unsigned mg_ohw, mg_ow;  // magic multipliers of the divisions by OH * OW and by OW (dass_common.h x3_fastdiv), filled by wx3_finish
+    int sh_ohw, sh_ow;
 };
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void wdma16(v4i rsrc, unsigned lds, unsigned voff) {  // see conv_x3.hip:dma16
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(lds), "s"(rsrc)
+// FOUR LDS-DMA instructions into four CONSECUTIVE 1 KiB pieces with ONE write of M0: the instruction's immediate offset is added
+// to the LDS address (M0 + offset + 16 * lane) as well as to the memory address (base + voffset + soffset + offset), so piece i goes
+// out with offset:1024 i and a per-lane voffset that carries its true source minus 1024 i.  soff: wave-uniform part of the source
+// offset (the 32-channel chunk; + WX3_BIAS, see wgrad_x3_body).  M0 is not restored: nothing the compiler emits for these kernels
+// reads it (gfx9+ LDS instructions do not), and every statement that needs it writes it itself.
+// (Round 3 issued every piece as `save m0; set m0; nop; load; restore m0` -- 40 of the loop's ~280 SALU instructions per slab.)
+__device__ __forceinline__ void wdma16x4(v4i rsrc, unsigned lds, unsigned soff, unsigned v0, unsigned v1, unsigned v2, unsigned v3) {
+    asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %0, %5, %6 offen lds\n\t"
+                 "buffer_load_dwordx4 %1, %5, %6 offen offset:1024 lds\n\t"
+                 "buffer_load_dwordx4 %2, %5, %6 offen offset:2048 lds\n\t"
+                 "buffer_load_dwordx4 %3, %5, %6 offen offset:3072 lds"
+                 :
+                 : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(lds), "s"(rsrc), "s"(soff)
                  : "memory");
 }
+__device__ __forceinline__ void wdma16x6(v4i rsrc, unsigned lds, unsigned soff, unsigned v0, unsigned v1, unsigned v2, unsigned v3, unsigned v4,
+                                         unsigned v5) {  // three-part rows: six pieces per chunk, the last two behind a second M0
+    wdma16x4(rsrc, lds, soff, v0, v1, v2, v3);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %0, %3, %4 offen lds\n\t"
+                 "buffer_load_dwordx4 %1, %3, %4 offen offset:1024 lds"
+                 :
+                 : "v"(v4), "v"(v5), "s"(lds + 4096u), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+constexpr unsigned WX3_BIAS = 8192u;  // the buffer descriptors start this many bytes BELOW the operands, so that `source - 1024 i` never wraps
 __device__ __forceinline__ v4i wmake_srd(const void *base, unsigned bytes) {
     const unsigned long long a = (unsigned long long)base;
     v4i r;
@@ -95,75 +118,72 @@ __device__ __forceinline__ void wgrad_x3_body(const WX3P &p, int wg, char *smem)
     if (pend > p.M) pend = p.M;
     const int total = (int)((pend - pbeg + 31) / 32);       // 32-pixel slabs
 
-    const v4i rsa = wmake_srd(p.dy3, p.dy3_bytes), rsb = wmake_srd(p.x3, p.x3_bytes);
+    const v4i rsa = wmake_srd(p.dy3 - WX3_BIAS, p.dy3_bytes + WX3_BIAS), rsb = wmake_srd(p.x3 - WX3_BIAS, p.x3_bytes + WX3_BIAS);
     const unsigned smem_base = (unsigned)(size_t)smem;
 
-    // ---- loader role of this wave: chunks first_ch .. first_ch + CHW - 1 of operand A (waves below ACH / CHW) or B
+    // ---- loader role of this wave: chunks first_ch .. first_ch + CHW - 1 of operand A (waves below ACH / CHW) or B.  The NP * 2
+    // pieces of one chunk -- (part pl, pixel half hf) at ((ch * NP + pl) * 2 + hf) * 1024 -- are consecutive in LDS: one M0 write
+    // per four of them (wdma16x4).  A chunk beyond the tensor (the last tile of K or C) is CLAMPED to the last real chunk, not
+    // zeroed: the rows / columns it feeds are never stored.
     const bool loads_a = wave * CHW < ACH;                  // wave-uniform
     const int first_ch = loads_a ? wave * CHW : wave * CHW - ACH;
     const int lp = lane >> 2;                               // pixel row of the piece this lane fetches
     const unsigned chunk16 = (unsigned)((lane & 3) * 16);
-    // pixel cursors: pixel (pbeg + 16 * half + lp) of the CURRENT slab to issue, advanced by 32 per slab
-    int cur_pix[2];  // (M < 2^31: checked by the host)
-    int c_oh[2], c_ow[2];
-    unsigned c_off[2];                                      // operand B: byte offset of the tap's input pixel row (x3)
-    const int tap_dy = -p.pad + r * p.dil, tap_dx = -p.pad + s2 * p.dil;
+    unsigned soff[CHW], ldsoff[CHW];
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-        cur_pix[hf] = (int)pbeg + 16 * hf + lp;
-        const long pix = cur_pix[hf] < p.M ? cur_pix[hf] : 0;
-        const int n = (int)(pix / ohw);
-        const int rem = (int)(pix - (long)n * ohw);
-        c_oh[hf] = rem / p.OW;
-        c_ow[hf] = rem - c_oh[hf] * p.OW;
-        c_off[hf] = (unsigned)(((long)n * p.H + (c_oh[hf] * p.stride + tap_dy)) * p.W + (c_ow[hf] * p.stride + tap_dx)) * p.x_pitch;
+    for (int j = 0; j < CHW; ++j) {
+        const int ch = first_ch + j;
+        int gch = (loads_a ? k0 : c0) / 32 + ch;
+        const int lim = (loads_a ? p.KC : p.CC) - 1;
+        gch = gch < lim ? gch : lim;
+        soff[j] = __builtin_amdgcn_readfirstlane((unsigned)(gch * SB) + WX3_BIAS);
+        ldsoff[j] = __builtin_amdgcn_readfirstlane((unsigned)((loads_a ? 0 : A_BYTES) + ch * CHB));
     }
-    const unsigned adv_px = (unsigned)(32 * p.stride) * p.x_pitch;
-    const unsigned adv_row = (unsigned)(p.stride * p.W - p.OW * p.stride) * p.x_pitch;
-    const unsigned adv_img = (unsigned)(p.H * p.W - p.OH * p.stride * p.W) * p.x_pitch;
-
-    // 1 x 1, stride 1, no padding (two thirds of the layers): the input pixel IS the output pixel -- no cursor, no bounds
-    const bool same_pix = p.R * p.S == 1 && p.pad == 0 && p.stride == 1 && p.H == p.OH && p.W == p.OW;
+    // per-lane constant of piece (pl, hf): + pl * 64 + chunk16 (where the 16 bytes sit in the row-slab) - 1024 * (pl * 2 + hf)
+    // (what the instruction's immediate offset adds back); pieces 4, 5 of a three-part chunk sit behind the second M0: - 1024 * (i - 4)
+    auto piece_k = [&](int pl, int hf) -> unsigned {
+        const int i = pl * 2 + hf;
+        return (unsigned)(pl * 64) + chunk16 - (unsigned)(1024 * (i < 4 ? i : i - 4));
+    };
     const int pend32 = (int)pend;
-    auto issue_slab = [&](int stage) {
+    const int pix_lane = (int)pbeg + lp;                    // pixel of (slab 0, half 0); slab s, half hf: + 32 s + 16 hf
+    const unsigned pitch = loads_a ? p.dy_pitch : p.x_pitch, zero_off = loads_a ? p.dy_zero : p.x_zero;
+    const int tap_dy = -p.pad + r * p.dil, tap_dx = -p.pad + s2 * p.dil;
+    // operand B source row of output pixel `pix`: the tap's input pixel (1 x 1 / stride 1 / no padding -- two thirds of the layers --:
+    // the pixel itself), the zero row when that falls outside the image.  Branch-free, by magic division (no cursor state).
+    const bool same_pix = p.R * p.S == 1 && p.pad == 0 && p.stride == 1 && p.H == p.OH && p.W == p.OW;
+    auto src_of = [&](int pix, auto ROLE) __attribute__((always_inline)) -> unsigned {
+        constexpr int role = decltype(ROLE)::value;         // 0: operand A, 1: B with the pixel itself, 2: B through the tap geometry
+        const bool live = pix < pend32;
+        if constexpr (role < 2) {
+            return live ? (unsigned)pix * pitch : zero_off;
+        } else {
+            const int pp2 = live ? pix : 0;
+            const int n = x3_fastdiv(pp2, p.mg_ohw, p.sh_ohw);
+            const int rem = pp2 - n * ohw;
+            const int oh = x3_fastdiv(rem, p.mg_ow, p.sh_ow);
+            const int ow = rem - oh * p.OW;
+            const int iy = oh * p.stride + tap_dy, ix = ow * p.stride + tap_dx;
+            const bool in = live && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            return in ? (unsigned)((n * p.H + iy) * p.W + ix) * pitch : zero_off;
+        }
+    };
+    int next_slab = 0;                                       // slab index the next issue fetches
+    auto issue_slab = [&](int stage, auto ROLE) __attribute__((always_inline)) {
         const unsigned st = smem_base + (unsigned)(stage * STAGE);
+        const int pix = pix_lane + 32 * next_slab;
+        ++next_slab;
+        const unsigned s0 = src_of(pix, ROLE), s1 = src_of(pix + 16, ROLE);
+        const v4i rs = decltype(ROLE)::value == 0 ? rsa : rsb;
+        if constexpr (NP == 2) {
+            const unsigned v0 = s0 + piece_k(0, 0), v1 = s1 + piece_k(0, 1), v2 = s0 + piece_k(1, 0), v3 = s1 + piece_k(1, 1);
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            const bool live = cur_pix[hf] < pend32;
-            unsigned src;
-            if (loads_a) {
-                src = live ? (unsigned)cur_pix[hf] * p.dy_pitch : p.dy_zero;
-            } else if (same_pix) {
-                src = live ? (unsigned)cur_pix[hf] * p.x_pitch : p.x_zero;
-            } else {
-                const int iy = c_oh[hf] * p.stride + tap_dy, ix = c_ow[hf] * p.stride + tap_dx;
-                src = (live && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? c_off[hf] : p.x_zero;
-            }
-            const bool zero = loads_a ? !live : src == p.x_zero;
+            for (int j = 0; j < CHW; ++j) wdma16x4(rs, __builtin_amdgcn_readfirstlane(st + ldsoff[j]), soff[j], v0, v1, v2, v3);
+        } else {
+            const unsigned v0 = s0 + piece_k(0, 0), v1 = s1 + piece_k(0, 1), v2 = s0 + piece_k(1, 0), v3 = s1 + piece_k(1, 1);
+            const unsigned v4 = s0 + piece_k(2, 0), v5 = s1 + piece_k(2, 1);
 #pragma unroll
-            for (int j = 0; j < CHW; ++j) {
-                const int ch = first_ch + j;
-                const int gch = (loads_a ? k0 : c0) / 32 + ch;                 // chunk index in the tensor
-                const bool ch_ok = gch < (loads_a ? p.KC : p.CC);            // beyond the tensor: zeros
-                const unsigned base = (zero || !ch_ok) ? (loads_a ? p.dy_zero : p.x_zero) : src + (unsigned)(gch * SB);
-                const unsigned dst = __builtin_amdgcn_readfirstlane(st + (loads_a ? 0 : A_BYTES) + ((ch * NP) * 2 + hf) * 1024);
-#pragma unroll
-                for (int pl = 0; pl < NP; ++pl) wdma16(loads_a ? rsa : rsb, dst + pl * 2048, base + pl * 64 + chunk16);
-            }
-            // advance this cursor by 32 pixels
-            cur_pix[hf] += 32;
-            if (!loads_a && !same_pix) {
-                c_ow[hf] += 32;
-                c_off[hf] += adv_px;
-                while (c_ow[hf] >= p.OW) {
-                    c_ow[hf] -= p.OW;
-                    c_off[hf] += adv_row;
-                    if (++c_oh[hf] >= p.OH) {
-                        c_oh[hf] = 0;
-                        c_off[hf] += adv_img;
-                    }
-                }
-            }
+            for (int j = 0; j < CHW; ++j) wdma16x6(rs, __builtin_amdgcn_readfirstlane(st + ldsoff[j]), soff[j], v0, v1, v2, v3, v4, v5);
         }
     };
 
@@ -181,14 +201,6 @@ __device__ __forceinline__ void wgrad_x3_body(const WX3P &p, int wg, char *smem)
     const unsigned lane_off = (unsigned)((8 * (g >> 1) + q) * 64 + (16 * (g & 1) + 4 * pp) * 2);
     const unsigned a_rd = smem_base + (unsigned)((wm * (TMW / 32)) * CHB) + lane_off;
     const unsigned b_rd = smem_base + (unsigned)(A_BYTES + (wn * (TNW / 32)) * CHB) + lane_off;
-
-    int issued = 0;
-#pragma unroll
-    for (int sg = 0; sg < NSTAGE - 1; ++sg)
-        if (issued < total) {
-            issue_slab(sg);
-            ++issued;
-        }
 
     // fragments of one 16-pixel k-step: [part][block][pixels 0-3 / 4-7 of this lane's half]; the two 8-byte reads of an MFMA
     // operand land in the halves of its register tuple (tr16 above), the compiler waits for them in front of their first use.
@@ -230,39 +242,66 @@ __device__ __forceinline__ void wgrad_x3_body(const WX3P &p, int wg, char *smem)
         __builtin_amdgcn_s_setprio(0);
     };
 
-    int cur = 0, nxt = NSTAGE - 1;
-    for (int s = 0; s < total; ++s) {
-        const int later = issued - s - 1;
-        if (NSTAGE >= 3 && later >= 1) wwait_vmcnt<(NSTAGE >= 3 ? G : 0)>();
-        else wwait_vmcnt<0>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const unsigned so = (unsigned)(cur * STAGE);
-        // k-step 0 = pixels 0..15 of the slab (pieces hf = 0), k-step 1 = pixels 16..31 (hf = 1, + 1024)
-        if (s > 0) {
-            // slab s-1 / k-step 1 sits in a1 / b1: its reads were issued before the previous multiply and waited for below
+    // The main loop, once per loader role (the role is wave-uniform and fixed: three straight-line copies instead of one loop that
+    // branches on it inside every slab).  One slab: wait for its pieces, barrier, read k-step 0 (pixels 0..15, pieces hf = 0) while --
+    // from the second slab on -- k-step 1 of the PREVIOUS slab (already in a1 / b1) multiplies, then read k-step 1 (hf = 1, + 1024)
+    // under the MFMAs of k-step 0.  The first slab is peeled off the loop: with an `if (s > 0)` inside it the compiler kept two
+    // copies of the 64 accumulator registers and moved one into the other around every multiply (32 v_mov_b64 + MFMA-drain nops
+    // per k-step in the ISA of round 3, and the loader's small arrays lived in scratch memory -- a scratch load with a vmcnt(0)
+    // wait in the middle of every DMA issue: the loop ran 31 % MFMA-busy); a uniform body accumulates in place.
+    auto run = [&](auto ROLE) __attribute__((always_inline)) {
+        int issued = 0;
+#pragma unroll
+        for (int sg = 0; sg < NSTAGE - 1; ++sg)
+            if (issued < total) {
+                issue_slab(sg, ROLE);
+                ++issued;
+            }
+        int cur = 0, nxt = NSTAGE - 1;
+        if (total > 0) {
+            if (NSTAGE >= 3 && issued - 1 >= 1) wwait_vmcnt<(NSTAGE >= 3 ? G : 0)>();
+            else wwait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            load_frags(a_rd, b_rd, a0, b0);
+            if (issued < total) {
+                issue_slab(nxt, ROLE);
+                ++issued;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(a_rd + 1024, b_rd + 1024, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+            nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
+        }
+        for (int s = 1; s < total; ++s) {
+            const int later = issued - s - 1;
+            if (NSTAGE >= 3 && later >= 1) wwait_vmcnt<(NSTAGE >= 3 ? G : 0)>();
+            else wwait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const unsigned so = (unsigned)(cur * STAGE);
             load_frags(a_rd + so, b_rd + so, a0, b0);
             __builtin_amdgcn_sched_barrier(0);
             if (issued < total) {
-                issue_slab(nxt);
+                issue_slab(nxt, ROLE);
                 ++issued;
             }
-            multiply(a1, b1);
-        } else {
-            load_frags(a_rd + so, b_rd + so, a0, b0);
-            if (issued < total) {
-                issue_slab(nxt);
-                ++issued;
-            }
+            multiply(a1, b1);   // slab s-1 / k-step 1
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(a_rd + so + 1024, b_rd + so + 1024, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+            nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
         }
-        __builtin_amdgcn_sched_barrier(0);
-        load_frags(a_rd + so + 1024, b_rd + so + 1024, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        multiply(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        cur = cur + 1 == NSTAGE ? 0 : cur + 1;
-        nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
-    }
+    };
+    if (loads_a) run(std::integral_constant<int, 0>{});
+    else if (same_pix) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 2>{});
     if (total > 0) multiply(a1, b1);
     wwait_vmcnt<0>();
     if constexpr (NP == 2) {  // undo the operands' per-tensor power-of-two scales (exact)
@@ -375,6 +414,8 @@ extern "C" int dass_conv2d_wgrad_x3(const void *x3, const void *dy3, float *dw, 
     p.stride = stride; p.pad = pad; p.dil = dil;
     p.M = N * OH * OW;
     p.KC = KC; p.CC = CC;
+    x3_set_magic(OH * OW, p.mg_ohw, p.sh_ohw);
+    x3_set_magic(OW, p.mg_ow, p.sh_ow);
     static const long target = getenv("DASS_WX3_TARGET") ? atol(getenv("DASS_WX3_TARGET")) : 768;
     static const long min_slabs = getenv("DASS_WX3_MINSLABS") ? atol(getenv("DASS_WX3_MINSLABS")) : 16;
     static const int force = getenv("DASS_WX3_TILE") ? atoi(getenv("DASS_WX3_TILE")) : 0;
@@ -492,6 +533,8 @@ extern "C" int dass_conv2d_wgrad_x3_group(const int64_t *items, int n, void *scr
         p.N = N; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K; p.R = R; p.S = S;
         p.stride = stride; p.pad = pad; p.dil = dil;
         p.M = N * OH * OW; p.KC = KC; p.CC = CC;
+        x3_set_magic(OH * OW, p.mg_ohw, p.sh_ohw);
+        x3_set_magic(OW, p.mg_ow, p.sh_ow);
         const int tile = is_big ? 128 : 64;
         p.ktiles = (K + tile - 1) / tile;
         p.ctiles = (C + tile - 1) / tile;
