@@ -49,6 +49,8 @@ struct X3P {
     int group_rows, mt_per_group;   // per-image mode: M-tiles never straddle an image; group_rows = M otherwise
     unsigned w3_group_stride;       // per-image mode: byte offset between the weight operands of consecutive images
     const int *cc_limit;            // per-image mode: channel slabs of image g that hold anything (the others are skipped)
+    int res_groups;                 // per-image mode, > 0: the residual holds only res_groups images -- image g adds the rows of image g % res_groups
+                                    // (all T stochastic passes of a scoring batch in ONE launch share the batch's deterministic residual)
     int OHs, OWs, o_mul, oy_add, ox_add, ustride;
     unsigned long long tap_allow;
     // filled by launch_x3 (host-side divisions the kernel's per-workgroup setup would otherwise repeat):
@@ -115,7 +117,7 @@ template <> struct Terms<2> { static constexpr int N = 3; static constexpr int P
 // the epilogue, before the accumulators bounce through LDS -- instead of three dependent loads per 16-byte store)
 __device__ __forceinline__ void x3_store_out(const X3P &p, f32x4 v, int m, int k, int ohw, bool vec_ok, float y3_scale, float &vmax, bool phase,
                                              bool pre = false, f32x4 sc4 = f32x4{1.f, 1.f, 1.f, 1.f}, f32x4 sh4 = f32x4{0.f, 0.f, 0.f, 0.f},
-                                             f32x4 r4 = f32x4{0.f, 0.f, 0.f, 0.f}) {
+                                             f32x4 r4 = f32x4{0.f, 0.f, 0.f, 0.f}, long res_shift = 0) {
     float *y = reinterpret_cast<float *>(p.y);
     const float *res = reinterpret_cast<const float *>(p.res);
     long mo = m;  // output pixel index; differs from m only for a phase sub-grid
@@ -130,7 +132,7 @@ __device__ __forceinline__ void x3_store_out(const X3P &p, f32x4 v, int m, int k
         } else {
             if (p.scale) v *= *reinterpret_cast<const f32x4 *>(p.scale + k);
             if (p.shift) v += *reinterpret_cast<const f32x4 *>(p.shift + k);
-            if (res) v += *reinterpret_cast<const f32x4 *>(res + mo * p.ldr + k);
+            if (res) v += *reinterpret_cast<const f32x4 *>(res + (mo + res_shift) * p.ldr + k);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
@@ -143,7 +145,7 @@ __device__ __forceinline__ void x3_store_out(const X3P &p, f32x4 v, int m, int k
         for (int e = 0; e < 4; ++e) {
             if (k + e >= p.K) break;
             float u = v[e] * (p.scale ? p.scale[k + e] : 1.f) + (p.shift ? p.shift[k + e] : 0.f);
-            if (res) u += res[mo * p.ldr + k + e];
+            if (res) u += res[(mo + res_shift) * p.ldr + k + e];
             u = apply_act(u, p.act);
             y[mo * p.ldy + k + e] = u;
             vmax = fmaxf(vmax, fabsf(u));
@@ -729,6 +731,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     static_assert(NT % PBLK == 0, "column blocks per pass");
     float *patch = reinterpret_cast<float *>(smem) + wave * 32 * PITCH;
     const bool vec_ok = (!y || (p.ldy & 3) == 0) && ((p.K & 3) == 0) && (!res || (p.ldr & 3) == 0);
+    const long res_shift = p.res_groups > 0 ? (long)((grp % p.res_groups) - grp) * p.group_rows : 0;  // (rows: the residual of image g % res_groups)
     float *slab = SIMPLE || complete ? nullptr : p.ws + ((long)wgid * 2 + (sk_seg > 0 ? 1 : 0)) * (BM * BN);
     bool bstat = false;
     if constexpr (SIMPLE) bstat = p.bs_sums != nullptr;  // (host: only with f32 rows out, 16-B aligned rows, no scale / shift / act)
@@ -770,7 +773,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
                     for (int it = 0; it < ITS; ++it) {
                         const int mm = m0 + wm * TMW + mt * 32 + (it * 64 + lane) / C4;
                         pf_r[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (res && mm < m_end && kc < p.K) pf_r[it] = *reinterpret_cast<const f32x4 *>(res + (long)mm * p.ldr + kc);
+                        if (res && mm < m_end && kc < p.K) pf_r[it] = *reinterpret_cast<const f32x4 *>(res + ((long)mm + res_shift) * p.ldr + kc);
                     }
                 }
                 if (bstat) {
@@ -792,7 +795,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
                         pf_g[it] = 0xfu;
                         if (mm < m_end && kc < p.K) {
                             pf_y[it] = *reinterpret_cast<const f32x4 *>(p.bs_y + (long)mm * p.K + kc);
-                            if (res) pf_r[it] = *reinterpret_cast<const f32x4 *>(res + (long)mm * p.ldr + kc);
+                            if (res) pf_r[it] = *reinterpret_cast<const f32x4 *>(res + ((long)mm + res_shift) * p.ldr + kc);
                             if (p.bs_gates) pf_g[it] = p.bs_gates[(long)mm * (p.K >> 2) + (kc >> 2)];
                         }
                     }
@@ -856,8 +859,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
                         continue;
                     }
                 }
-                if constexpr (SIMPLE) x3_store_out(p, v, m, k, ohw, vec_ok, y3_scale, vmax, false, ep_pre, ch_sc, ch_sh, pf_r[it]);
-                else x3_store_out(p, v, m, k, ohw, vec_ok, y3_scale, vmax, phase);
+                if constexpr (SIMPLE) x3_store_out(p, v, m, k, ohw, vec_ok, y3_scale, vmax, false, ep_pre, ch_sc, ch_sh, pf_r[it], res_shift);
+                else x3_store_out(p, v, m, k, ohw, vec_ok, y3_scale, vmax, phase, false, f32x4{1.f, 1.f, 1.f, 1.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, res_shift);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -977,7 +980,9 @@ template <int BM, int BN> __global__ __launch_bounds__(256) void conv_x3_fixup_k
         s1 += v;
         s2 += v * v;
         const int m = m0 + lr, k = n0 + c4 * 4;
-        if (m < m_end && k < p.K) x3_store_out(p, v, m, k, ohw, vec_ok, y3_scale, vmax, p.o_mul != 1);
+        if (m < m_end && k < p.K)
+            x3_store_out(p, v, m, k, ohw, vec_ok, y3_scale, vmax, p.o_mul != 1, false, f32x4{1.f, 1.f, 1.f, 1.f}, f32x4{0.f, 0.f, 0.f, 0.f},
+                         f32x4{0.f, 0.f, 0.f, 0.f}, p.res_groups > 0 ? (long)((grp % p.res_groups) - grp) * p.group_rows : 0);
     }
     x3_amax_commit(p.y_amax, vmax);
     if (p.stat_partial || p.stat_sums) {  // rows >= M of the slabs are exact zeros
@@ -1135,7 +1140,8 @@ template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE, int NP = 3> int 
         x3_set_magic(p.OWs, p.mg_ows, p.sh_ows);
     }
     const bool simple = p.whole && p.o_mul == 1;  // (per-image groups included: their tile -> rows map is two more multiplies)
-    constexpr bool has_simple = NP == 2 && ((BM == 64 && BN == 64) || (BM == 256 && BN == 128));  // the production picks
+    // whole-tile forms of the two-part kernel: the production picks + the 128 x 64 tile (wins layer-1 / 2 / 4 shapes, r04 sweep)
+    constexpr bool has_simple = NP == 2 && ((BM == 64 && BN == 64) || (BM == 256 && BN == 128) || (BM == 128 && BN == 64));
     if (p.bs_sums && !(has_simple && simple)) p.bs_sums = nullptr;  // not fused: the caller runs dass_bn_bwd_reduce_sums itself
     g_bn_fused = p.bs_sums ? 1 : 0;
     g_last_pick = (BM << 16) | (BN << 4) | ((has_simple && simple) ? 2 : 0) | (stream ? 1 : 0);
@@ -1291,7 +1297,7 @@ static int conv_x3_impl(const void *x3, const void *w3, void *y, int64_t ldy, vo
                         const void *residual, int64_t ldr, int N, int H, int W, int C, int OH, int OW, int K, int R, int S, int stride,
                         int pad, int dil, int ustride, int act, float *stat_partial, int *stat_rows, void *workspace,
                         int64_t workspace_bytes, void *stream, bool per_image, const int *cc_limit, double *stat_sums = nullptr,
-                        void *y_amax = nullptr, const X3P *bnstat = nullptr, int *bn_fused = nullptr) {
+                        void *y_amax = nullptr, const X3P *bnstat = nullptr, int *bn_fused = nullptr, int res_images = 0) {
     if (!x3 || !w3 || (!y && !y3)) return DASS_ERR_ARG;
     if (workspace && ((uintptr_t)workspace & 15)) return DASS_ERR_ARG;
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || K <= 0 || R <= 0 || S <= 0) return DASS_ERR_ARG;
@@ -1344,6 +1350,7 @@ static int conv_x3_impl(const void *x3, const void *w3, void *y, int64_t ldy, vo
     p.group_rows = per_image ? OH * OW : p.M;
     p.w3_group_stride = per_image ? (unsigned)((long)K * R * S * CC * SB) : 0u;
     p.cc_limit = per_image ? cc_limit : nullptr;
+    p.res_groups = (per_image && residual && res_images > 0 && res_images < N) ? res_images : 0;
     p.OHs = OH; p.OWs = OW; p.o_mul = 1; p.oy_add = 0; p.ox_add = 0;
     p.tap_allow = ~0ull;
     hipStream_t st = (hipStream_t)stream;
@@ -1442,6 +1449,19 @@ extern "C" int dass_conv2d_x3_per_image(const void *x3, const void *w3, const in
                         nullptr, workspace, workspace_bytes, stream, true, cc_limit, nullptr, y_amax);
 }
 
+/* the same with a residual that holds only res_images images: image g of the batch adds the rows of image g % res_images.  This is
+ * how ALL T stochastic passes of a scoring batch run as ONE launch (N = T x batch "images", each with its own packed operand and weight
+ * copy, sharing the batch's deterministic low-level share): T x the tiles of one pass fill the chip for ~40 rounds instead of ending
+ * every pass with a partly filled round and a stream-K fix-up (mc_dropout.py:37-49 runs the T passes one after the other). */
+extern "C" int dass_conv2d_x3_per_image_rep(const void *x3, const void *w3, const int *cc_limit, void *y, int64_t ldy, void *y3,
+                                            const float *scale, const float *shift, const void *residual, int64_t ldr, int res_images, int N,
+                                            int H, int W, int C, int OH, int OW, int K, int R, int S, int stride, int pad, int dil, int act,
+                                            void *workspace, int64_t workspace_bytes, void *y_amax, void *stream) {
+    if (residual && (res_images <= 0 || N % res_images)) return DASS_ERR_ARG;
+    return conv_x3_impl(x3, w3, y, ldy, y3, scale, shift, residual, ldr, N, H, W, C, OH, OW, K, R, S, stride, pad, dil, 1, act, nullptr,
+                        nullptr, workspace, workspace_bytes, stream, true, cc_limit, nullptr, y_amax, nullptr, nullptr, res_images);
+}
+
 namespace {
 
 // mask [N][C] (0 = dropped, else the multiplier) -> order [N][CC * 32]: the surviving channel indices in ascending order,
@@ -1471,7 +1491,7 @@ template <int NP>
 __global__ __launch_bounds__(256) void split3_rows_packed_kernel(const float *__restrict__ x, long ld, char *__restrict__ out, long M, int C,
                                                                  int CC, const float *__restrict__ mask, const int *__restrict__ order,
                                                                  const int *__restrict__ cc_limit, long rows_per_image, int chunks,
-                                                                 const float *__restrict__ bound_src, float bound_mul) {
+                                                                 const float *__restrict__ bound_src, float bound_mul, int src_images) {
     constexpr int SB = NP * 64;
     const int n = blockIdx.x / chunks, chunk = blockIdx.x - n * chunks;
     const int upr = CC * 4, unit = threadIdx.x % upr, rstep = blockDim.x / upr;
@@ -1503,7 +1523,7 @@ __global__ __launch_bounds__(256) void split3_rows_packed_kernel(const float *__
     const long r_lo = chunk * per, r_hi = r_lo + per < rows_per_image ? r_lo + per : rows_per_image;
     for (long r = r_lo + threadIdx.x / upr; r < r_hi; r += rstep) {
         const long m = (long)n * rows_per_image + r;
-        const float *src = x + m * ld;
+        const float *src = x + ((long)(src_images > 0 ? n % src_images : n) * rows_per_image + r) * ld;  // (src_images: x holds fewer images than masks)
         f32x4 v0, v1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1572,7 +1592,7 @@ extern "C" int dass_dropout_compact(const float *mask, int N, int C, int *order,
 }
 
 static int split_packed_impl(const float *x, int64_t ld, void *out, int64_t M, int C, const float *mask, const int *order,
-                             const int *cc_limit, int64_t rows_per_image, const float *bound, float bound_mul, void *stream) {
+                             const int *cc_limit, int64_t rows_per_image, const float *bound, float bound_mul, void *stream, int src_images = 0) {
     if (!x || !out || !mask || !order || !cc_limit || M <= 0 || C <= 0 || ld < C || rows_per_image <= 0) return DASS_ERR_ARG;
     if (((uintptr_t)out & 15) || M % rows_per_image) return DASS_ERR_ARG;
     const int CC = (C + 31) / 32;
@@ -1585,6 +1605,7 @@ static int split_packed_impl(const float *x, int64_t ld, void *out, int64_t M, i
     if (g_x3_parts == 2) {
         if ((ld & 3) || (C & 3) || ((uintptr_t)x & 15)) return DASS_ERR_ARG;
         char *tr = (char *)out + x3_trailer_off(M, CC, 2);
+        if (!bound && src_images > 0) return DASS_ERR_ARG;  // (the replicated form needs the caller's bound)
         if (!bound) {  // no bound supplied: max |x * mask| by one more pass over the tensor
             if (hipMemsetAsync(tr, 0, 16, st) != hipSuccess) return DASS_ERR_LAUNCH;
             const int rc = dass_absmax_rows(x, ld, M, C, mask, rows_per_image, (float *)(tr + 4), stream);
@@ -1593,10 +1614,10 @@ static int split_packed_impl(const float *x, int64_t ld, void *out, int64_t M, i
             bound_mul = 1.f;
         }
         DASS_LAUNCH(split3_rows_packed_kernel<2>, dim3((unsigned)(images * chunks + 1)), dim3(256), 0, st, x, (long)ld, (char *)out, (long)M,
-                           C, CC, mask, order, cc_limit, (long)rows_per_image, (int)chunks, bound, bound_mul);
+                           C, CC, mask, order, cc_limit, (long)rows_per_image, (int)chunks, bound, bound_mul, src_images);
     } else {
         DASS_LAUNCH(split3_rows_packed_kernel<3>, dim3((unsigned)(images * chunks + 1)), dim3(256), 0, st, x, (long)ld, (char *)out, (long)M,
-                           C, CC, mask, order, cc_limit, (long)rows_per_image, (int)chunks, (const float *)nullptr, 1.f);
+                           C, CC, mask, order, cc_limit, (long)rows_per_image, (int)chunks, (const float *)nullptr, 1.f, src_images);
     }
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -1613,6 +1634,15 @@ extern "C" int dass_split3_rows_packed_bound(const float *x, int64_t ld, void *o
                                              const int *cc_limit, int64_t rows_per_image, const float *bound, float bound_mul, void *stream) {
     if (!bound || !(bound_mul > 0.f)) return DASS_ERR_ARG;
     return split_packed_impl(x, ld, out, M, C, mask, order, cc_limit, rows_per_image, bound, bound_mul, stream);
+}
+
+/* the same for M = (images x T) output rows over an x that holds only src_images images: output image v packs source image
+ * v % src_images with ITS OWN mask / order / limit (all T Dropout2d masks of a scoring batch in one launch) */
+extern "C" int dass_split3_rows_packed_rep(const float *x, int64_t ld, void *out, int64_t M, int C, const float *mask, const int *order,
+                                           const int *cc_limit, int64_t rows_per_image, int src_images, const float *bound, float bound_mul,
+                                           void *stream) {
+    if (!bound || !(bound_mul > 0.f) || src_images <= 0 || rows_per_image <= 0 || (M / rows_per_image) % src_images) return DASS_ERR_ARG;
+    return split_packed_impl(x, ld, out, M, C, mask, order, cc_limit, rows_per_image, bound, bound_mul, stream, src_images);
 }
 
 extern "C" int dass_w3_pack_per_image(const void *w3, void *out, int64_t rows, int C, int N, const int *order, const int *cc_limit,

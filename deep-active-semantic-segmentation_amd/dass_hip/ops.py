@@ -387,6 +387,25 @@ def split3_rows_packed(x, ld, m, c, mask, order, lim, rows_per_image, bound=None
     return out
 
 
+def split3_rows_packed_rep(x, ld, m_out, c, mask, order, lim, rows_per_image, src_images, bound, bound_mul=1.0):
+    """split3_rows_packed for m_out = (T x src_images) x rows_per_image output rows over an x of only src_images images: output
+    image v packs source image v % src_images with mask / order / lim row v (all T masks of a scoring batch in one launch)"""
+    out = x3_alloc(m_out, c, x.device)
+    check(lib.dass_split3_rows_packed_rep(_p(x), ld, _p(out), m_out, c, _p(mask), _p(order), _p(lim), rows_per_image, src_images, _p(bound),
+                                          float(bound_mul), _stream()), "dass_split3_rows_packed_rep")
+    return out
+
+
+def conv_x3_per_image_rep_launch(x3, w3n, lim, y, ldy, dims, res_images, y3=None, scale=None, shift=None, residual=None, ldr=0, act=ACT_NONE):
+    """dass_conv2d_x3_per_image_rep: N = T x res_images "images" (own weight copy + slab limit each); the residual holds only
+    res_images images and is shared by the T groups"""
+    n, h, w, c, oh, ow, k, r, s, stride, pad, dil = dims
+    ws = _x3_workspace(x3.device)
+    check(lib.dass_conv2d_x3_per_image_rep(_p(x3), _p(w3n), _p(lim), _p(y), ldy, _p(y3), _p(scale), _p(shift), _p(residual), ldr, res_images,
+                                           n, h, w, c, oh, ow, k, r, s, stride, pad, dil, act, _p(ws), ws.numel(), None, _stream()),
+          "dass_conv2d_x3_per_image_rep")
+
+
 def absmax_rows(x, ld, m, c):
     """device float [1] = max |x| over rows (dass_absmax_rows)"""
     b = torch.zeros((1,), dtype=torch.float32, device=x.device)
@@ -875,7 +894,11 @@ class _ConvBnAct(torch.autograd.Function):
                 rl.dead = True  # a consumer the link's launch does not see: the layer's d_out will be a sum
         kpad = _pad_to(k, _epv(dt))
         if kpad != k:  # e.g. the 19-class classifier: keep a zero pad column so rows stay 16-B aligned
-            out = zeros_act(n, kpad, oh, ow, dt, dev)[:, :k]
+            # (only the pad columns are zeroed: the conv writes the k real ones -- a full-tensor fill per classifier call was 2.5 % of
+            # the MC-dropout leg's kernel time)
+            buf = new_act(n, kpad, oh, ow, dt, dev)
+            buf[:, k:].zero_()
+            out = buf[:, :k]
         else:
             out = new_act(n, k, oh, ow, dt, dev)
         ldo = kpad

@@ -109,6 +109,42 @@ class Decoder(nn.Module):
         per = (wan.numel() - 16) // t
         return [(order[i * n:(i + 1) * n], lim[i * n:(i + 1) * n], wan[i * per:(i + 1) * per], None) for i in range(t)]
 
+    def head_mc_all(self, feats, prep, masks1, masks2):
+        """ALL T stochastic passes of last_conv as one launch per conv (two-part pre-split engine with the Dropout2d-sparse operands):
+        masks1 / masks2 [T, N, 256] -> low-resolution logits [T * N, classes, h, w], pass-major.  The T x N (pass, image) pairs are
+        the "images" of the per-image conv -- each with its own packed operand rows and weight copy, all sharing the batch's
+        deterministic low-level share as residual -- and of the dense second conv and the classifier: T x the tiles of one pass
+        fill the chip for ~40 rounds, where every single pass ended in a partly filled round + a stream-K fix-up launch.
+        None when that path is off (the caller then runs head_mc_pass per pass)."""
+        import torch
+
+        wa, st, yb, la, yb_amax, xa_amax = prep
+        if not (ops.x3_pipeline() and ops.mc_sparse() and ops.x3_parts() == 2 and la is not None and xa_amax is not None):
+            return None
+        n, c, h, w = feats.shape
+        t = masks1.shape[0]
+        v, rpi = t * n, h * w
+        m = v * rpi
+        if m * 1024 >= (1 << 32) - (1 << 20):   # the operand's 32-bit byte offsets (8 slabs x 128 B per row): the caller cuts T
+            return None
+        lc = self.last_conv
+        m1 = masks1.reshape(v, 256).contiguous()
+        order, lim = ops.dropout_pack(m1)
+        wan = ops.w3_pack_per_image(wa, 256 * 9, 256, order, lim)
+        bnd = (xa_amax * masks1.amax()).reshape(1)          # one bound for the masked operand of all passes, on the device
+        xa, lda = ops.rows(feats[:, :256])
+        xa3 = ops.split3_rows_packed_rep(xa, lda, m, 256, m1, order, lim, rpi, n, bnd)
+        h1_3 = ops.x3_alloc(m, 256, feats.device)
+        ops.x3_prepare_out(h1_3, m, 256, la, st.scale, st.shift, xa3, m, 256, ops._p(yb_amax), ops.ACT_RELU)
+        dims = (v, h, w, 256, h, w, 256, 3, 3, 1, 1, 1)
+        ops.conv_x3_per_image_rep_launch(xa3, wan, lim, None, 256, dims, n, y3=h1_3, scale=st.scale, shift=st.shift, residual=yb, ldr=256,
+                                         act=ops.ACT_RELU)
+        st2 = ops.bn_eval_state(lc[4], 256, feats.device)
+        h2 = ops.new_act(v, 256, h, w, torch.float32, feats.device)
+        ops.conv_x3_launch(h1_3, ops.weight_operand(lc[3].weight, 0, torch.float32, cpad=256, x3=True), h2, 256, dims,
+                           scale=st2.scale, shift=st2.shift, act=ops.ACT_RELU)
+        return ops.conv_bn_act(h2, lc[7], in_scale=masks2.reshape(v, 256).contiguous())
+
     def head_mc_pass(self, feats, prep, m1, m2, packed=None):
         """one stochastic pass of last_conv: masks m1 (ASPP Dropout2d, [N,256]) and m2 (last_conv[6]) folded into loaders;
         packed: this pass's entry of head_mc_pack (else the operands are packed here)"""

@@ -12,6 +12,8 @@ Additions (do not change the reference surface):
   * mc_dropout_votes(): the T-pass scoring tail with the deterministic prefix computed once
     (SURVEY.md 8a notes i-iii), used by active_selection.mc_dropout.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -127,6 +129,21 @@ class DeepLab(nn.Module):
             draws = torch.rand((2, steps, n, 256), device=dev, generator=generator)
             masks = ((draws[0] >= p1).to(torch.float32) * (1.0 / (1.0 - p1)), (draws[1] >= p2).to(torch.float32) * (1.0 / (1.0 - p2)))
         masks = (masks[0].to(dev).float().contiguous(), masks[1].to(dev).float().contiguous())
+        if prep is not None and os.environ.get("DASS_MC_BATCHED", "1") == "1":
+            # all T passes as ONE launch per conv (decoder.head_mc_all); T is cut only where the operand would outgrow 32-bit offsets
+            rows = n * feats.shape[2] * feats.shape[3]
+            tc = max(1, min(steps, ((1 << 32) - (1 << 21)) // 1024 // rows))
+            done = True
+            for t0 in range(0, steps, tc):
+                t1 = min(steps, t0 + tc)
+                low = self.decoder.head_mc_all(feats, prep, masks[0][t0:t1], masks[1][t0:t1])
+                if low is None:
+                    done = False
+                    break
+                for t in range(t0, t1):
+                    ops.upsample_argmax(low[(t - t0) * n:(t - t0 + 1) * n], hh, ww, votes, t)
+            if done:
+                return votes
         packs = self.decoder.head_mc_pack(prep, masks[0][:steps]) if prep is not None else None
 
         def one_pass(t):

@@ -469,6 +469,19 @@ int dass_conv2d_x3(const void *x3, const void *w3, void *y, int64_t ldy, void *y
 int dass_dropout_compact(const float *mask, int N, int C, int *order, int *cc_limit, void *stream);
 int dass_split3_rows_packed(const float *x, int64_t ld, void *out, int64_t M, int C, const float *mask, const int *order,
                             const int *cc_limit, int64_t rows_per_image, void *stream);
+/* All T stochastic passes of a scoring batch as ONE launch each (active_selection/mc_dropout.py:37-49 runs T full forwards one after
+ * the other; models/decoder.py:23-36 is the tail each of them re-runs).  dass_split3_rows_packed_rep: like
+ * dass_split3_rows_packed_bound for M = (T x images) x rows_per_image OUTPUT rows over an x that holds only src_images images --
+ * output image v packs source image v % src_images with its own mask / order / limit row.  dass_conv2d_x3_per_image_rep: like
+ * dass_conv2d_x3_per_image with a residual of only res_images images (image g adds the rows of image g % res_images: the batch's
+ * deterministic low-level share, the same in every pass).  N % res_images must be 0. */
+int dass_split3_rows_packed_rep(const float *x, int64_t ld, void *out, int64_t M, int C, const float *mask, const int *order,
+                                const int *cc_limit, int64_t rows_per_image, int src_images, const float *bound, float bound_mul,
+                                void *stream);
+int dass_conv2d_x3_per_image_rep(const void *x3, const void *w3, const int *cc_limit, void *y, int64_t ldy, void *y3,
+                                 const float *scale, const float *shift, const void *residual, int64_t ldr, int res_images, int N,
+                                 int H, int W, int C, int OH, int OW, int K, int R, int S, int stride, int pad, int dil, int act,
+                                 void *workspace, int64_t workspace_bytes, void *y_amax, void *stream);
 /* the same with the bound of the two-part format supplied by the caller: *bound * bound_mul >= max |x * mask| (no pass over x) */
 int dass_split3_rows_packed_bound(const float *x, int64_t ld, void *out, int64_t M, int C, const float *mask, const int *order,
                                   const int *cc_limit, int64_t rows_per_image, const float *bound, float bound_mul, void *stream);

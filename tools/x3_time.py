@@ -15,7 +15,7 @@ from conv_sweep import r101_shapes, timeit  # noqa: E402
 
 
 def main():
-    tiles = [int(a) for a in sys.argv[1:]] or [0, 11, 12, 14, 21, 22, 23, 24]
+    tiles = [int(a) for a in sys.argv[1:]] or [0, 11, 12, 14, 21, 22, 23, 24]   # + 1000: no loader wave, + 2000: loader wave (whole-tile launches)
     ops.set_f32_mma(os.environ.get("DASS_F32_MMA", "bf16x6"))   # (f16x3: the same kernels in their two-part mode)
     dev = "cuda"
     tot_old, tot_new, tot_best, tot_flop, tot_split = 0.0, {t: 0.0 for t in tiles}, 0.0, 0.0, 0.0
