@@ -82,6 +82,86 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const T *__restrict__ 
     }
 }
 
+// ---- round 4: the same two kernels with a FIXED 4-channel group per thread (blockDim = ppb * C/4 <= 256: thread t owns channel
+// group t % (C/4) of the pixels t / (C/4) + k * ppb of its row).  The 36 weights of the group are loaded ONCE into registers: the
+// kernels above fetch them again for every output -- 36 scalar loads next to the 9 tap loads, 45 vector-memory instructions per
+// 16 bytes of output; the depthwise passes ran at 0.10-0.13 of HBM in the config-C profile (profiles/r03_train_C_mbv2_summary.md).
+template <typename T>
+__global__ __launch_bounds__(256) void dw_fwd_cg_kernel(const T *__restrict__ x, long ldx, const float *__restrict__ w,
+                                                        T *__restrict__ y, long ldy, int N, int H, int W, int C, int OH,
+                                                        int OW, int stride, int pad, int dil, int cv, int ppb) {
+    const int cg = threadIdx.x % cv, pl = threadIdx.x / cv;
+    const int c = cg << 2;
+    f32x4 wr[9];  // wr[q] = floats 4 q .. 4 q + 3 of the group's 36 weights [4 channels][9 taps]
+#pragma unroll
+    for (int q = 0; q < 9; ++q) wr[q] = *reinterpret_cast<const f32x4 *>(w + (long)c * 9 + 4 * q);
+    auto wt = [&](int e, int tap) -> float { const int i = e * 9 + tap; return wr[i >> 2][i & 3]; };
+    for (long row = blockIdx.y; row < (long)N * OH; row += gridDim.y) {
+        const long n = row / OH;
+        const int oh = (int)(row - n * OH);
+        for (int ow = blockIdx.x * ppb + pl; ow < OW; ow += gridDim.x * ppb) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int iy = oh * stride - pad + r * dil;
+                if (iy < 0 || iy >= H) continue;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const int ix = ow * stride - pad + s * dil;
+                    if (ix < 0 || ix >= W) continue;
+                    const f32x4 v = ld4<T>(x + ((n * H + iy) * W + ix) * ldx + c);
+                    const int tap = r * 3 + s;
+                    a[0] += v[0] * wt(0, tap);
+                    a[1] += v[1] * wt(1, tap);
+                    a[2] += v[2] * wt(2, tap);
+                    a[3] += v[3] * wt(3, tap);
+                }
+            }
+            st4<T>(y + ((n * OH + oh) * OW + ow) * ldy + c, a);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dw_bwd_data_cg_kernel(const T *__restrict__ dy, long lddy, const float *__restrict__ w,
+                                                             T *__restrict__ dx, long lddx, int N, int H, int W, int C, int OH,
+                                                             int OW, int stride, int pad, int dil, int cv, int ppb) {
+    const int cg = threadIdx.x % cv, pl = threadIdx.x / cv;
+    const int c = cg << 2;
+    f32x4 wr[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) wr[q] = *reinterpret_cast<const f32x4 *>(w + (long)c * 9 + 4 * q);
+    auto wt = [&](int e, int tap) -> float { const int i = e * 9 + tap; return wr[i >> 2][i & 3]; };
+    for (long row = blockIdx.y; row < (long)N * H; row += gridDim.y) {
+        const long n = row / H;
+        const int iy = (int)(row - n * H);
+        for (int ix = blockIdx.x * ppb + pl; ix < W; ix += gridDim.x * ppb) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int ty = iy + pad - r * dil;
+                if (ty < 0 || ty % stride) continue;
+                const int oh = ty / stride;
+                if (oh >= OH) continue;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const int tx = ix + pad - s * dil;
+                    if (tx < 0 || tx % stride) continue;
+                    const int ow = tx / stride;
+                    if (ow >= OW) continue;
+                    const f32x4 g = ld4<T>(dy + ((n * OH + oh) * OW + ow) * lddy + c);
+                    const int tap = r * 3 + s;
+                    a[0] += g[0] * wt(0, tap);
+                    a[1] += g[1] * wt(1, tap);
+                    a[2] += g[2] * wt(2, tap);
+                    a[3] += g[3] * wt(3, tap);
+                }
+            }
+            st4<T>(dx + ((n * H + iy) * W + ix) * lddx + c, a);
+        }
+    }
+}
+
 // grid (C/64, pixel slabs); thread = (4-channel group cq of 16, pixel lane pl of 16): 9 taps x 4 channels of accumulators, 16-B
 // loads (16 lanes = 256 contiguous bytes of one pixel), the (n, oh, ow) cursor advanced by adds -- the round-1 kernel loaded
 // single floats and paid two 64-bit divisions per pixel (0.44 TB/s of algorithmic traffic in the config-C profile; this: see
@@ -392,6 +472,17 @@ extern "C" int dass_dwconv3x3_fwd(const void *x, int64_t ldx, const float *w, vo
     const long rows_ = (long)N * OH;
     const dim3 grid((unsigned)(gx < 1024 ? gx : 1024), (unsigned)(rows_ < 8192 ? rows_ : 8192));  // (ow, channel group) x output rows
     hipStream_t st = (hipStream_t)stream;
+    const int cv = C / 4;
+    if (cv <= 256 && !((uintptr_t)w & 15) && (dtype == DASS_F32 || dtype == DASS_BF16)) {  // one channel group per thread, weights in registers
+        const int ppb = 256 / cv;
+        const dim3 g2((unsigned)((OW + ppb - 1) / ppb), grid.y), b2((unsigned)(ppb * cv));
+        if (dtype == DASS_F32)
+            DASS_LAUNCH(dw_fwd_cg_kernel<float>, g2, b2, 0, st, (const float *)x, ldx, w, (float *)y, ldy, N, H, W, C, OH, OW, stride, pad, dil, cv, ppb);
+        else
+            DASS_LAUNCH(dw_fwd_cg_kernel<bf16_t>, g2, b2, 0, st, (const bf16_t *)x, ldx, w, (bf16_t *)y, ldy, N, H, W, C, OH, OW, stride, pad, dil, cv, ppb);
+        DASS_LAUNCH_CHECK();
+        return DASS_OK;
+    }
     if (dtype == DASS_F32)
         DASS_LAUNCH(dw_fwd_kernel<float>, grid, dim3(256), 0, st, (const float *)x, ldx, w, (float *)y, ldy, N, H, W, C, OH, OW, stride, pad, dil);
     else if (dtype == DASS_BF16)
@@ -412,6 +503,17 @@ extern "C" int dass_dwconv3x3_bwd_data(const void *dy, int64_t lddy, const float
     const long rows_ = (long)N * H;
     const dim3 grid((unsigned)(gx < 1024 ? gx : 1024), (unsigned)(rows_ < 8192 ? rows_ : 8192));  // (ix, channel group) x input rows
     hipStream_t st = (hipStream_t)stream;
+    const int cv = C / 4;
+    if (cv <= 256 && !((uintptr_t)w & 15) && (dtype == DASS_F32 || dtype == DASS_BF16)) {
+        const int ppb = 256 / cv;
+        const dim3 g2((unsigned)((W + ppb - 1) / ppb), grid.y), b2((unsigned)(ppb * cv));
+        if (dtype == DASS_F32)
+            DASS_LAUNCH(dw_bwd_data_cg_kernel<float>, g2, b2, 0, st, (const float *)dy, lddy, w, (float *)dx, lddx, N, H, W, C, OH, OW, stride, pad, dil, cv, ppb);
+        else
+            DASS_LAUNCH(dw_bwd_data_cg_kernel<bf16_t>, g2, b2, 0, st, (const bf16_t *)dy, lddy, w, (bf16_t *)dx, lddx, N, H, W, C, OH, OW, stride, pad, dil, cv, ppb);
+        DASS_LAUNCH_CHECK();
+        return DASS_OK;
+    }
     if (dtype == DASS_F32)
         DASS_LAUNCH(dw_bwd_data_kernel<float>, grid, dim3(256), 0, st, (const float *)dy, lddy, w, (float *)dx, lddx, N, H, W, C, OH, OW, stride, pad, dil);
     else if (dtype == DASS_BF16)
