@@ -1197,11 +1197,17 @@ static int dispatch_x3(X3P &p, hipStream_t st, long ws_bytes) {
         // (re-measured after the per-workgroup setup shrank to ~120 instructions, profiles/r03_x3_conv_sweep_f16.txt: whole 64 x 64
         //  tiles now also win the K <= 64 and the 2-slab layers of layer 1 -- their stream-K form pays the general kernel's setup
         //  and a fix-up pass -- and 256 x 128 whole tiles win where they give one well-filled round of 120..256 tiles)
-        if (p.K <= 64 || (t256 >= 4 * g_cus && s_tile <= 4)) { pick = 4; if (!mode) mode = 1; }
+        // (round 4, profiles/r04_x3_conv_sweep.txt: wherever whole 64 x 64 tiles were the pick, whole 128 x 64 tiles -- 25 % fewer
+        //  LDS-DMA pieces per MFMA; a piece costs the issuing wave ~100 cycles of in-order issue -- are 5-20 % faster once there are
+        //  ~2 of them per CU; 276 tiles (M = 8712, K = 256) quantise badly on 256 CUs and stay 64 x 64, and so do the output-bound
+        //  4-slab layers with >= 512 output channels, whose long tile epilogues overlap worse)
+        const long t128 = (long)((p.M + 127) / 128) * ((p.K + 63) / 64);
+        const bool wide = g_x3_parts == 2 && t128 >= 2 * g_cus && !(s_tile <= 4 && p.K >= 512);
+        if (p.K <= 64 || (t256 >= 4 * g_cus && s_tile <= 4)) { pick = wide ? 3 : 4; if (!mode) mode = 1; }
         else if (t256 >= 4 * g_cus) pick = 1;
         else if (s_tile >= 100) { pick = 1; if (!mode) mode = 2; }
         else if (g_x3_parts == 2 && t256 >= 120 && t256 <= g_cus && s_tile >= 16) { pick = 1; if (!mode) mode = 1; }
-        else { pick = 4; if (!mode) mode = 1; }  // short reductions: segments would be too short to amortise the fix-up
+        else { pick = wide ? 3 : 4; if (!mode) mode = 1; }  // short reductions: segments would be too short to amortise the fix-up
     }
     if (g_x3_parts == 2) {
         switch (pick) {
