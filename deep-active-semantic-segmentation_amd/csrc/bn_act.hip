@@ -4,6 +4,7 @@
 // Reference sites: every batchnorm(...) + ReLU pair in models/{aspp,decoder}.py and
 // models/backbone/{resnet,mobilenet}.py (F.batch_norm training=True/False semantics of torch).
 #include "dass_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -481,6 +482,99 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
     }
 }
 
+// ---- The train step's BN-backward apply, specialised (round 4): f32, batch statistics through the f64 sums, the activation gate
+// from stored gate bits (GATES) or re-derived from the conv output, split rows out (dx3, two- or three-part), optionally the f32
+// rows too (DX32) and the residual branch's gradient (DRES).  Everything bn_bwd_apply_kernel can do besides is compiled out: that
+// kernel needs 93-131 VGPRs for its options (3-5 waves per SIMD); this one keeps ONE 4-channel group per thread (the host sizes
+// the grid: bn_grid), its seven per-channel vectors in registers, and issues the loads of two rows before it touches either.
+// Same arithmetic, same rounding as the general kernel (tests/test_round4_gpu.py compares the two bit for bit).
+template <bool GATES, bool DRES, bool DX32>
+__global__ __launch_bounds__(256, 5) void bn_bwd_fast_kernel(const float *__restrict__ dout, long lddo, const float *__restrict__ x, long ldx,
+                                                          const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                          const float *__restrict__ gamma, const double *__restrict__ sums,
+                                                          float *__restrict__ dbeta_out, float *__restrict__ dgamma_out,
+                                                          const float *__restrict__ gate_scale, const float *__restrict__ gate_shift,
+                                                          float *__restrict__ dx, long lddx, float *__restrict__ dres, long lddr, long M, int K,
+                                                          float inv_count, int act, const unsigned char *__restrict__ gates,
+                                                          char *__restrict__ dx3, int parts) {
+    float x3s = 1.f;
+    if (parts == 2) {  // the tensor's bound for the two-part rows (see bn_bwd_apply_kernel)
+        __shared__ float s_g[4];
+        const float *dzmax = reinterpret_cast<const float *>(sums + 2 * (long)K);
+        const float sqm = sqrtf(M > 1 ? (float)(M - 1) : 1.f);
+        float gi = 0.f;
+        for (int k = threadIdx.x; k < K; k += blockDim.x) {
+            const float b = dzmax[k] + fabsf((float)sums[k]) * inv_count + sqm * fabsf((float)sums[K + k]) * inv_count;
+            gi = fmaxf(gi, fabsf((gamma ? gamma[k] : 1.f) * invstd[k]) * b);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gi = fmaxf(gi, __shfl_xor(gi, o, 64));
+        if ((threadIdx.x & 63) == 0) s_g[threadIdx.x >> 6] = gi;
+        __syncthreads();
+        const float bound = 1.25f * fmaxf(fmaxf(s_g[0], s_g[1]), fmaxf(s_g[2], s_g[3]));
+        x3s = x3_scale_of(bound);
+        if (blockIdx.x == 0) x3_zero_row(dx3, M, (K + 31) >> 5, 2, x3_inv_of(x3s), bound);
+    } else if (blockIdx.x == 0) {
+        x3_zero_row(dx3, M, (K + 31) >> 5);
+    }
+    if (blockIdx.x == 0)
+        for (int k = threadIdx.x; k < K; k += blockDim.x) {
+            if (dbeta_out) dbeta_out[k] = (float)sums[k];
+            if (dgamma_out) dgamma_out[k] = (float)sums[K + k];
+        }
+    const int cc3 = (K + 31) >> 5, kv = K >> 2;
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long dm = ((long)gridDim.x * blockDim.x) / kv;   // (host: the thread count is a multiple of kv)
+    long m = i0 / kv;
+    const int kq = (int)(i0 - m * kv), k = kq << 2;
+    const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + k), mu = *reinterpret_cast<const f32x4 *>(mean + k);
+    f32x4 ga = {1.f, 1.f, 1.f, 1.f}, db, dg, gsc = {0.f, 0.f, 0.f, 0.f}, gsh = gsc;
+    if (gamma) ga = *reinterpret_cast<const f32x4 *>(gamma + k);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        db[e] = (float)sums[k + e];
+        dg[e] = (float)sums[K + k + e];
+    }
+    if constexpr (!GATES) {
+        gsc = *reinterpret_cast<const f32x4 *>(gate_scale + k);
+        gsh = *reinterpret_cast<const f32x4 *>(gate_shift + k);
+    }
+    const f32x4 gis = ga * is;
+    auto finish = [&](long mm, f32x4 g, const f32x4 xin, const unsigned gb) __attribute__((always_inline)) {
+        if constexpr (GATES) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = ((gb >> e) & 1u) ? g[e] : 0.f;
+        } else {
+            const f32x4 o = bn_affine(xin, gsc, gsh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] *= act_grad_from_out(o[e], act);
+        }
+        if constexpr (DRES) *reinterpret_cast<f32x4 *>(dres + mm * lddr + k) = g;
+        const f32x4 xh = (xin - mu) * is;
+        const f32x4 r = g - (db + xh * dg) * inv_count;
+        const f32x4 dxv = r * gis;
+        if constexpr (DX32) *reinterpret_cast<f32x4 *>(dx + mm * lddx + k) = dxv;
+        x3_store4r(dx3, mm, cc3, k, dxv, parts, x3s);
+    };
+    for (; m + dm < M; m += 2 * dm) {
+        const long m1 = m + dm;
+        const f32x4 g0 = *reinterpret_cast<const f32x4 *>(dout + m * lddo + k), g1 = *reinterpret_cast<const f32x4 *>(dout + m1 * lddo + k);
+        const f32x4 x0 = *reinterpret_cast<const f32x4 *>(x + m * ldx + k), x1 = *reinterpret_cast<const f32x4 *>(x + m1 * ldx + k);
+        unsigned b0 = 0u, b1 = 0u;
+        if constexpr (GATES) {
+            b0 = gates[m * kv + kq];
+            b1 = gates[m1 * kv + kq];
+        }
+        finish(m, g0, x0, b0);
+        finish(m1, g1, x1, b1);
+    }
+    if (m < M) {
+        unsigned b0 = 0u;
+        if constexpr (GATES) b0 = gates[m * kv + kq];
+        finish(m, *reinterpret_cast<const f32x4 *>(dout + m * lddo + k), *reinterpret_cast<const f32x4 *>(x + m * ldx + k), b0);
+    }
+}
+
 // ---- BatchNorm over a handful of ROWS (the ASPP image-pool branch: BN of an [N, C] vector that the reference broadcasts to
 // H x W first, aspp.py:62-65,79-81).  The input is post-ReLU (mean >> deviation) and N is the batch size, so the batch
 // variance is a difference of nearly equal numbers and, for N = 2, the input gradient vanishes up to eps: sum / sum-of-squares
@@ -839,6 +933,28 @@ extern "C" int dass_bn_bwd_apply_sums(const void *dout, int64_t lddo, const void
     const int grid = bn_grid(M, K);
     const float inv_count = (float)(1.0 / count);
     hipStream_t st = (hipStream_t)stream;
+    const char *fast_env = getenv("DASS_BN_BWD_FAST");  // (read per call: the tests flip it between two launches)
+    const bool fast_on = !fast_env || atoi(fast_env) != 0;
+    // the train step's form: the lean kernel (bn_bwd_fast_kernel) -- f32, split rows out, gate from bits or from the conv output, no
+    // Dropout2d mask, a thread count that is a multiple of K / 4
+    if (fast_on && dtype == DASS_F32 && dx3 && !out && !nc_scale && ((long)grid * 256) % (K / 4) == 0 && (gates || (gate_scale && gate_shift))) {
+        const float *d = (const float *)dout, *xx = (const float *)x;
+        const unsigned char *gb = (const unsigned char *)gates;
+        const int parts = dass_get_x3_parts();
+#define BN_FAST(G, R, D)                                                                                                              \
+        DASS_LAUNCH((bn_bwd_fast_kernel<G, R, D>), dim3(grid), dim3(256), 0, st, d, lddo, xx, ldx, mean, invstd, gamma, sums, dbeta_out, dgamma_out, \
+                    gate_scale, gate_shift, (float *)dx, lddx, (float *)dres, lddr, M, K, inv_count, act, gb, (char *)dx3, parts)
+        if (gates) {
+            if (dres) { if (dx) BN_FAST(true, true, true); else BN_FAST(true, true, false); }
+            else { if (dx) BN_FAST(true, false, true); else BN_FAST(true, false, false); }
+        } else {
+            if (dres) { if (dx) BN_FAST(false, true, true); else BN_FAST(false, true, false); }
+            else { if (dx) BN_FAST(false, false, true); else BN_FAST(false, false, false); }
+        }
+#undef BN_FAST
+        DASS_LAUNCH_CHECK();
+        return DASS_OK;
+    }
     if (dtype == DASS_F32)
         DASS_LAUNCH(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)dout, lddo, (const float *)out, ldo,
                            (const float *)x, ldx, mean, invstd, gamma, (const float *)nullptr, (const float *)nullptr, nc_scale, (float *)dx,

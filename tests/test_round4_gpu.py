@@ -57,3 +57,73 @@ def test_batched_mc_tail_equals_per_pass_tail(backbone, n, hw, T):
             os.environ.pop("DASS_MC_BATCHED", None)
         else:
             os.environ["DASS_MC_BATCHED"] = keep_env
+
+
+@pytest.mark.parametrize("gates", [False, True])
+@pytest.mark.parametrize("with_res", [False, True])
+@pytest.mark.parametrize("want_dx32", [False, True])
+def test_lean_bn_backward_kernel_equals_general_kernel(gates, with_res, want_dx32):
+    """bn_bwd_fast_kernel (the train step's form of dass_bn_bwd_apply_sums) against the general kernel (DASS_BN_BWD_FAST=0, read
+    per call) on the same arguments: identical f32 rows, split rows, residual gradient and parameter gradients, bit for bit; and
+    against the formula in f64."""
+    from dass_hip import ops
+    from dass_hip._lib import check, lib
+
+    keep, keep_env = ops.f32_mma(), os.environ.get("DASS_BN_BWD_FAST")
+    try:
+        ops.set_f32_mma("f16x3")
+        torch.manual_seed(7)
+        m, k = 8 * 33 * 33, 256
+        dev = "cuda"
+        x = torch.randn((m, k), device=dev)                      # conv output (pre-BN)
+        dout = torch.randn((m, k), device=dev) * 1e-3
+        gamma = torch.rand((k,), device=dev) + 0.5
+        mean, var = x.mean(0), x.var(0, unbiased=False)
+        invstd = (var + 1e-5).rsqrt()
+        scale, shift = (gamma * invstd).contiguous(), (-mean * gamma * invstd).contiguous()
+        res = torch.randn((m, k), device=dev) if with_res else None
+        pre = torch.addcmul(shift.expand(m, k), x, scale.expand(m, k))
+        gate = (pre + res > 0) if with_res else None             # residual layers: the gate exists only as stored bits
+        use_bits = gates or with_res
+        gbits = None
+        if use_bits:
+            gt = gate if gate is not None else pre > 0
+            g4 = gt.view(m, k // 4, 4).to(torch.uint8)
+            gbits = (g4[..., 0] | (g4[..., 1] << 1) | (g4[..., 2] << 2) | (g4[..., 3] << 3)).contiguous()
+        sums = torch.zeros((3 * k,), dtype=torch.float64, device=dev)
+
+        def run(fast):
+            os.environ["DASS_BN_BWD_FAST"] = "1" if fast else "0"
+            dx = torch.empty((m, k), device=dev) if want_dx32 else None
+            dres = torch.empty((m, k), device=dev) if with_res else None
+            dx3 = ops.x3_alloc_for(m, k, dev)
+            pg = torch.empty((2, k), device=dev)
+            check(lib.dass_bn_bwd_apply_sums(ops._p(dout), k, None, k, ops._p(x), k, ops._p(mean), ops._p(invstd), ops._p(gamma), ops._p(sums),
+                                             ops._p(pg[0]), ops._p(pg[1]), ops._p(None if use_bits else scale), ops._p(None if use_bits else shift), None,
+                                             ops._p(dx), k, ops._p(dres), k, m, k, 33 * 33, float(m), ops.ACT_RELU, ops._p(gbits),
+                                             gbits.numel() if use_bits else 0, ops.F32, ops._p(dx3), ops._stream()), "bn_bwd_apply_sums")
+            return dx, dres, dx3, pg
+
+        # the sums the reduce pass would have left (sum dz, sum dz xhat, max |dz| per channel), with the gate the kernels will use
+        gt = (gate if gate is not None else pre > 0)
+        dz = dout * gt
+        xh = ((x - mean) * invstd)
+        sums[:k] = dz.double().sum(0)
+        sums[k:2 * k] = (dz.double() * xh.double()).sum(0)
+        sums.view(torch.float32)[4 * k:5 * k] = dz.abs().amax(0)
+        a, b = run(True), run(False)
+        assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+        if want_dx32:
+            assert torch.equal(a[0], b[0])
+            ref = (dz.double() - (sums[:k] + xh.double() * sums[k:2 * k]) / m) * (gamma * invstd).double()
+            near = (pre.abs() < 1e-6) if not use_bits else torch.zeros_like(pre, dtype=torch.bool)   # (re-derived gates: fma vs two roundings)
+            err = ((a[0].double() - ref).abs() * (~near)).max().item()
+            assert err <= 2e-6 * ref.abs().max().item() + 1e-12, err
+        if with_res:
+            assert torch.equal(a[1], b[1])
+    finally:
+        ops.set_f32_mma(keep)
+        if keep_env is None:
+            os.environ.pop("DASS_BN_BWD_FAST", None)
+        else:
+            os.environ["DASS_BN_BWD_FAST"] = keep_env
