@@ -10,7 +10,7 @@ launches with the picked index handed over in device memory, one host copy at th
 import numpy as np
 import torch
 
-from active_selection.base import ActiveSelectionBase
+from active_selection.base import ActiveSelectionBase, merged_batches, score_merge
 from dass_hip import ops
 
 
@@ -59,7 +59,7 @@ class ActiveSelectionCoreSet(ActiveSelectionBase):
         main = torch.cuda.current_stream(dev)
         used_side = False
         with torch.no_grad():
-            for i, sample in enumerate(self.make_loader(local, False)):
+            for i, sample in enumerate(merged_batches(self.make_loader(local, False), score_merge())):
                 batch = (sample['image'] if isinstance(sample, dict) else sample).to(dev)
                 side = lanes[i % len(lanes)] if i > 0 else None
                 if side is not None:

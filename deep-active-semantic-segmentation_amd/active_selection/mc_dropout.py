@@ -17,7 +17,7 @@ import random
 import torch
 
 import constants
-from active_selection.base import ActiveSelectionBase
+from active_selection.base import ActiveSelectionBase, merged_batches, score_merge
 from dass_hip import ops
 
 
@@ -97,7 +97,7 @@ class ActiveSelectionMCDropout(ActiveSelectionBase):
                 image_batch.record_stream(pre)
                 return state, done, label_batch
 
-            loader = iter(self.make_loader(local, True))
+            loader = iter(merged_batches(self.make_loader(local, True), score_merge()))  # (two loader batches per scoring forward)
             nxt = next(loader, None)
             cur = start(nxt) if nxt is not None else None
             while cur is not None:

@@ -491,8 +491,9 @@ def test_pipelined_image_scores_equal_sequential_scores():
 
     sel = ActiveSelectionMCDropout(ncls, None, hw, 3, loader_factory=factory)
     res = {}
-    keep = {k: os.environ.get(k) for k in ("DASS_MC_PIPELINE", "DASS_MC_STREAMS")}
+    keep = {k: os.environ.get(k) for k in ("DASS_MC_PIPELINE", "DASS_MC_STREAMS", "DASS_SCORE_MERGE")}
     try:
+        os.environ["DASS_SCORE_MERGE"] = "1"   # (merged loader batches would draw their masks in a different order: not what this test is about)
         for mode, (pipe, streams) in {"sequential": ("0", "1"), "pipelined": ("1", "2")}.items():
             os.environ["DASS_MC_PIPELINE"], os.environ["DASS_MC_STREAMS"] = pipe, streams
             torch.manual_seed(77)          # the same Bernoulli draws in both runs (torch.rand on the device, per batch)

@@ -127,3 +127,51 @@ def test_lean_bn_backward_kernel_equals_general_kernel(gates, with_res, want_dx3
             os.environ.pop("DASS_BN_BWD_FAST", None)
         else:
             os.environ["DASS_BN_BWD_FAST"] = keep_env
+
+
+def test_merged_loader_batches_give_the_same_features_and_scores():
+    """DASS_SCORE_MERGE: two loader batches per scoring forward.  Core-set features (no randomness) of a 10-image pool with merge 1
+    and merge 2 agree to f32 rounding of a different tile schedule (<= 2e-5 of the feature scale); the MC-dropout scores of the merged
+    run stay deterministic under a fixed seed and rank the pool like the unmerged run's draws would only by chance -- so here
+    only shape, finiteness and determinism are asserted for them."""
+    from active_selection.core_set import ActiveSelectionCoreSet
+    from active_selection.mc_dropout import ActiveSelectionMCDropout, _turn_on_dropout
+    from dass_hip.dist import ModuleWrapper
+
+    pm, O = _model("resnet", seed=15)
+    hw = 513   # (the 2736-wide core-set feature = 304 channels x 3 x 3 pooled cells of the 129 x 129 decoder map)
+    pool = {("img_%03d" % i).encode("ascii"): O.synthetic_batch(1, hw, hw, 19, first_index=500 + i) for i in range(10)}
+    keys = list(pool)
+
+    def fimg(images, include_labels, bs=3):
+        for i in range(0, len(images), bs):
+            yield torch.cat([pool[k][0] for k in images[i:i + bs]])
+
+    def fdict(images, include_labels, bs=3):
+        for i in range(0, len(images), bs):
+            chunk = images[i:i + bs]
+            yield {"image": torch.cat([pool[k][0] for k in chunk]), "label": torch.cat([pool[k][1] for k in chunk])}
+
+    keep = os.environ.get("DASS_SCORE_MERGE")
+    try:
+        feats = {}
+        for merge in ("1", "2"):
+            os.environ["DASS_SCORE_MERGE"] = merge
+            feats[merge] = ActiveSelectionCoreSet(None, hw, 3, loader_factory=fimg)._features(ModuleWrapper(pm), keys).cpu()
+        assert feats["1"].shape == feats["2"].shape == (10, 2736)
+        assert (feats["1"] - feats["2"]).abs().max().item() <= 2e-5 * feats["1"].abs().max().item()
+        os.environ["DASS_SCORE_MERGE"] = "2"
+        sel = ActiveSelectionMCDropout(19, None, hw, 3, loader_factory=fdict)
+        pm.apply(_turn_on_dropout)
+        runs = []
+        for _ in range(2):
+            torch.manual_seed(5)
+            torch.cuda.manual_seed(5)
+            runs.append(sel._image_scores(pm, keys, 4).cpu())
+        pm.eval()
+        assert runs[0].shape == (10,) and torch.isfinite(runs[0]).all() and torch.equal(runs[0], runs[1])
+    finally:
+        if keep is None:
+            os.environ.pop("DASS_SCORE_MERGE", None)
+        else:
+            os.environ["DASS_SCORE_MERGE"] = keep
