@@ -139,16 +139,21 @@ class KernelTimer(object):
         self.work = {n: _conv_gflop for n in conv if n in PROTOTYPES}
         self.work.update({n: _bn_gbytes for n in bn if n in PROTOTYPES})
         self.calls = []
+        self.shapes = []  # per call: (N, OH, OW, C, K, R) of a conv entry point, else None (diagnostics: tools/step_shapes.py)
         self.saved = {}
 
     def _wrap(self, name, fn):
         pick = lib.dass_x3_last_pick if ("x3" in name and "wgrad" not in name and "conv2d" in name) else None
         work = self.work[name]
 
+        idx = {n: i for i, n in enumerate(ARG_NAMES[name])}
+        dims = [idx[k] for k in ("N", "OH", "OW", "C", "K", "R") if k in idx]
+
         def timed(*args):
             i0 = lib.dass_prof_count()
             rc = fn(*args)
             self.calls.append((name, pick() if pick is not None else 0, work(name, args), i0, lib.dass_prof_count()))
+            self.shapes.append(tuple(int(_val(args[i])) for i in dims) if len(dims) == 6 else None)   # (N, OH, OW, C, K, R) of a conv call
             return rc
 
         return timed
@@ -169,6 +174,7 @@ class KernelTimer(object):
     def restart(self):
         """forget what was recorded so far (e.g. an untimed first step) and keep recording"""
         self.calls = []
+        self.shapes = []
         check(lib.dass_prof_begin(), "dass_prof_begin")
 
     def results(self):
