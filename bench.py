@@ -837,7 +837,8 @@ def main():
             other["coreset"]["kcenter"].pop("picks", None)
     if env.rank == 0:
         b, s, world = args.batch, args.size, env.world
-        line = {"metric": "train_images_per_s (DeepLab-v3+ R101 513x513; + mc_dropout pool-images/s in 'mc_dropout')",
+        line = {"metric": "train_images_per_s (DeepLab-v3+ %s %dx%d; + mc_dropout pool-images/s in 'mc_dropout')"
+                          % ({"resnet101": "R101", "resnet": "R50", "mobilenet": "MobileNetV2"}.get(args.backbone, args.backbone), s, s),
                 "value": round(head["train_ips"], 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(head["ms_per_step"], 3), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
