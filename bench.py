@@ -438,7 +438,9 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
                      "sharding": "contiguous key shards per rank + RCCL all_gather of per-image scores" if world > 1 else "single rank"}
 
         # -------------------------------------------------------------- config E: core-set features + k-center greedy
-        if not args.no_coreset and args.only != "mc":
+        # (the reference's core-set feature is 2736-wide = 304 channels x 3 x 3 cells of avg_pool2d(64, 32) over the 129 x 129 decoder
+        #  map, core_set.py:45-47: defined at the 513 x 513 crop only, so the leg is skipped at other sizes)
+        if not args.no_coreset and args.only != "mc" and (s + 3) // 4 == 129:
             from active_selection.core_set import ActiveSelectionCoreSet
             from dass_hip.dist import ModuleWrapper
 
