@@ -156,6 +156,12 @@ if _state["f32_mma"] == "f16x3":
     lib.dass_set_x3_parts(2)
 
 
+def set_rows_only(on):
+    """DASS_ROWS_ONLY: may a layer whose only reader is a pre-split conv (conv_bn_act(sole_consumer=True)) skip the f32 copy of its output"""
+    global _ROWS_ONLY
+    _ROWS_ONLY = bool(on)
+
+
 def x3_pipeline(training=False):
     """is the pre-split engine on for an inference call site (training=False) / for a call that records autograd"""
     if _state["f32_mma"] not in ("bf16x6", "f16x3"):
@@ -176,6 +182,7 @@ _SELECT = (int(os.environ.get("DASS_X3_SELECT_TAPS", "9")), int(os.environ.get("
 _X3_MIN_ROWS = 256  # output rows below which a conv stays on the classic kernel
 _FANOUT = os.environ.get("DASS_FANOUT", "1") == "1"  # gradients of multi-consumer tensors summed by one library pass (0: autograd's adds)
 _SKIP_DY32 = os.environ.get("DASS_SKIP_DY32", "1") == "1"  # BN backward writes only the split rows of dy when nothing reads its f32 form
+_ROWS_ONLY = os.environ.get("DASS_ROWS_ONLY", "1") == "1"  # a layer whose only reader is a pre-split conv writes only its split rows (conv_bn_act(sole_consumer=True))
 
 
 def _cdt(t):
@@ -451,6 +458,9 @@ def x3_operand(t, xs, ld, m, c, nc_scale=None, rows_per_image=1):
         hit = t.__dict__.get("_dass_x3") if hasattr(t, "__dict__") else None
         if hit is not None and hit[0] == (t.data_ptr(), t._version, m, c, x3_parts()):
             return hit[1]
+        if hasattr(t, "__dict__") and t.__dict__.get("_dass_rows_only"):
+            raise RuntimeError("dass_hip: split rows of a rows-only activation (conv_bn_act(sole_consumer=True)) are stale or of another "
+                               "format, and its f32 values were never written")
         buf = split3_rows(xs, ld, m, c)
         if hasattr(t, "__dict__"):
             attach_x3(t, buf, m, c)  # other consumers of the same tensor (the ASPP branches share their input) reuse the rows
@@ -879,6 +889,7 @@ class _ConvBnAct(torch.autograd.Function):
         else:
             xs, ldx = rows(_cast_act(x))
             c = c_in
+        x_rows_only = bool(hasattr(x, "__dict__") and x.__dict__.get("_dass_rows_only"))
         oh = conv_out_size(h, r, spec.stride, spec.pad, spec.dil)
         ow = conv_out_size(w, weight.shape[3], spec.stride, spec.pad, spec.dil)
         m = n * oh * ow
@@ -918,6 +929,10 @@ class _ConvBnAct(torch.autograd.Function):
         use_x3 = (x3_fwd and dt == torch.float32 and not spec.depthwise and not rowtap and not image_input and k > 32
                   and m >= _X3_MIN_ROWS)
         dims = (n, h, w, c, oh, ow, k, r, weight.shape[3], spec.stride, spec.pad, spec.dil)
+        if x_rows_only and not (use_x3 and attached_x3(x, n * h * w, c) is not None):
+            raise RuntimeError("dass_hip: this activation was produced with sole_consumer=True (split rows only, its f32 values were never "
+                               "written) but its consumer does not take split rows -- drop sole_consumer at the producer or set DASS_ROWS_ONLY=0")
+        rows_only = bool(getattr(spec, "rows_only", False))
         if fuse and use_x3:
             scale = shift = None
             if bn is not None:
@@ -943,9 +958,12 @@ class _ConvBnAct(torch.autograd.Function):
                     else:
                         res_keep, res_amax = bound_of(residual, res_t, ldr, m, k)
                 x3_prepare_out(y3, m, k, weight_l1(weight), scale, shift, x3, n * h * w, c, res_amax, spec.act)
-            conv_x3_launch(x3, w_op, out, ldo, dims, y3=y3, scale=scale, shift=shift, residual=res_t, ldr=ldr or 0, act=spec.act)
+            skip_f32 = rows_only and y3 is not None and res_t is None
+            conv_x3_launch(x3, w_op, None if skip_f32 else out, ldo, dims, y3=y3, scale=scale, shift=shift, residual=res_t, ldr=ldr or 0, act=spec.act)
             if y3 is not None:
                 attach_x3(out, y3, m, k)
+                if skip_f32:
+                    out.__dict__["_dass_rows_only"] = True
             if nc_scale is not None:
                 scale_shift_act(out, ldo, out, ldo, m, k, None, None, nc_scale=nc_scale, rows_per_image=oh * ow)
         elif fuse:
@@ -1028,7 +1046,9 @@ class _ConvBnAct(torch.autograd.Function):
                 res_keep, res_bound = None, None
                 if out3 is not None and x3_parts() == 2 and res_t is not None:  # the output's bound includes the residual's
                     res_keep, res_bound = bound_of(residual, res_t, ldr, m, k)
-                check(lib.dass_bn_apply_train(_p(y_raw), k, _p(out), ldo, _p(sums), float(m), _p(bn.weight), _p(bn.bias), _p(rm), _p(rv),
+                skip_f32 = (rows_only and out3 is not None and res_t is None and gates is None
+                            and (not need_grad or (y_raw is not None and spec.act != ACT_NONE)))  # (backward: gate from y_raw, never from `out`)
+                check(lib.dass_bn_apply_train(_p(y_raw), k, None if skip_f32 else _p(out), ldo, _p(sums), float(m), _p(bn.weight), _p(bn.bias), _p(rm), _p(rv),
                                               mom, float(bn.eps), _p(state.mean), _p(state.invstd), _p(state.scale), _p(state.shift),
                                               _p(res_t), ldr or 0, _p(nc_scale), m, k, oh * ow, spec.act, _dt(out), _p(out3), _p(gates),
                                               gates.numel() if gates is not None else 0, res_bound, _stream()), "dass_bn_apply_train")
@@ -1038,6 +1058,8 @@ class _ConvBnAct(torch.autograd.Function):
                                 nc_scale=nc_scale, rows_per_image=oh * ow, act=spec.act, out3=out3)
             if out3 is not None:
                 attach_x3(out, out3, m, k)
+                if sums is not None and skip_f32:
+                    out.__dict__["_dass_rows_only"] = True
             if (_BN_LINK and need_grad and sums is not None and nc_scale is None and dt == torch.float32 and ldo == k and k % 4 == 0
                     and state is not None and sync_bn_world(bn) == 1):
                 # (the gate is re-derived from y_raw unless the layer has a residual, whose gate bits `gates` holds; a residual
@@ -1498,7 +1520,7 @@ def _dgrad_operand_uncached(wsrc, dtype, x3=False):
 
 
 def conv_bn_act(x, conv, bn=None, act=ACT_NONE, residual=None, nc_scale=None, extra_pad=0, image_input=False,
-                in_scale=None, emit_x3=True, fork=False, consumer=None):
+                in_scale=None, emit_x3=True, fork=False, consumer=None, sole_consumer=False):
     """in_scale: [N,C] f32 multipliers applied to the INPUT while it is staged (inference only): a
     Dropout2d mask of the producer folded into this conv's loader (MC-dropout tail, SURVEY 8a note iii).
     fork=True -> (out, x'): x' is x again, to be used for the OTHER consumer of x (the identity branch of a residual
@@ -1507,7 +1529,8 @@ def conv_bn_act(x, conv, bn=None, act=ACT_NONE, residual=None, nc_scale=None, ex
     spec.grad_enabled = torch.is_grad_enabled()
     spec.fork = bool(fork) and spec.grad_enabled and x.requires_grad
     if fork and not spec.fork:
-        return conv_bn_act(x, conv, bn, act, residual, nc_scale, extra_pad, image_input, in_scale, emit_x3, consumer=consumer), x
+        return conv_bn_act(x, conv, bn, act, residual, nc_scale, extra_pad, image_input, in_scale, emit_x3, consumer=consumer,
+                           sole_consumer=sole_consumer), x
     # consumer: the nn.Conv2d that reads this output.  If the train step runs THAT conv on the pre-split kernels
     # (DASS_X3=select: long 3x3 reductions), the BN-apply pass of this layer writes the split rows along with the f32
     # ones (6 more bytes per element) instead of the consumer running a conversion pass (4 read + 6 written)
@@ -1515,6 +1538,20 @@ def conv_bn_act(x, conv, bn=None, act=ACT_NONE, residual=None, nc_scale=None, ex
                             and consumer.out_channels > 32
                             and _x3_train_layer(consumer.kernel_size[0] * consumer.kernel_size[1], conv.out_channels))
     spec.emit_x3 = emit_x3  # False where the consumer is not a dense conv (concat / pool / upsample / classifier)
+    # sole_consumer: `consumer` is the ONLY reader of this output (conv1 -> conv2 -> conv3 inside a bottleneck).  If that conv is sure
+    # to take the split rows this layer emits (two-part engine, dense, > 32 output channels, enough output rows for the pre-split
+    # kernels), the f32 copy of the output is never read by anyone -- this layer's own backward re-derives its gate from the conv
+    # output -- and is NOT WRITTEN: 4 of the 12 bytes per element the BN-apply / fused epilogue pass moves.  The tensor handed back
+    # then carries only its attached rows and is flagged; a reader that wants its f32 values fails loudly (x3_operand, _ConvBnAct).
+    spec.rows_only = False
+    if (sole_consumer and _ROWS_ONLY and consumer is not None and emit_x3 and residual is None and nc_scale is None and act != ACT_NONE
+            and compute_dtype() == torch.float32 and x3_parts() == 2 and x3_pipeline(training=spec.grad_enabled)
+            and consumer.groups == 1 and consumer.out_channels > 32 and conv.out_channels % 32 == 0 and not image_input):
+        oh = conv_out_size(x.shape[2], conv.kernel_size[0], spec.stride, spec.pad, spec.dil)
+        ow = conv_out_size(x.shape[3], conv.kernel_size[1], spec.stride, spec.pad, spec.dil)
+        ch = conv_out_size(oh, consumer.kernel_size[0], consumer.stride[0], consumer.padding[0], consumer.dilation[0])
+        cw = conv_out_size(ow, consumer.kernel_size[1], consumer.stride[1], consumer.padding[1], consumer.dilation[1])
+        spec.rows_only = x.shape[0] * ch * cw >= _X3_MIN_ROWS and x.shape[0] * oh * ow >= _X3_MIN_ROWS and conv.out_channels > 32
     if in_scale is not None:
         assert bn is None or not bn_use_batch_stats(bn), "in_scale needs eval-mode BN"
         spec.in_scale = in_scale.contiguous()

@@ -29,13 +29,14 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         if self.downsample:
             xa, xb = ops.fanout(x, 2)
-            out = ops.conv_bn_act(xa, self.conv1, self.bn1, ops.ACT_RELU, consumer=self.conv2)
+            out = ops.conv_bn_act(xa, self.conv1, self.bn1, ops.ACT_RELU, consumer=self.conv2, sole_consumer=True)
             residual = ops.conv_bn_act(xb, self.downsample[0], self.downsample[1], ops.ACT_NONE)
         else:
             # identity block: conv1 hands x back for the skip connection, so that the skip gradient is added inside
             # conv1's input-gradient launch (no separate accumulation pass over the block input)
-            out, residual = ops.conv_bn_act(x, self.conv1, self.bn1, ops.ACT_RELU, fork=True, consumer=self.conv2)
-        out = ops.conv_bn_act(out, self.conv2, self.bn2, ops.ACT_RELU)
+            out, residual = ops.conv_bn_act(x, self.conv1, self.bn1, ops.ACT_RELU, fork=True, consumer=self.conv2, sole_consumer=True)
+        # (conv1's and conv2's outputs have exactly one reader each -- the next conv of the block -- so only their split rows are written)
+        out = ops.conv_bn_act(out, self.conv2, self.bn2, ops.ACT_RELU, consumer=self.conv3, sole_consumer=True)
         # bn3 -> += residual -> relu (resnet.py:36-43) in one epilogue
         return ops.conv_bn_act(out, self.conv3, self.bn3, ops.ACT_RELU, residual=residual)
 

@@ -5,6 +5,22 @@ every parameter gradient can be compared at the rounding level."""
 import torch
 
 
+def activation_values(ops, t):
+    """f32 values of an activation handed out by conv_bn_act: the tensor itself, or -- for a rows-only output (sole_consumer=True:
+    its f32 copy is never written) -- decoded from its attached two-part split rows: [rows + 1][ceil(C/32)][2 parts][32] f16, then a
+    trailer whose first float is 1 / scale; x = (h0 + h1) / scale."""
+    if not (hasattr(t, "__dict__") and t.__dict__.get("_dass_rows_only")):
+        return t.detach()
+    n, c, h, w = t.shape
+    m, cc = n * h * w, (c + 31) // 32
+    buf = ops.attached_x3(t, m, c)
+    assert buf is not None and ops.x3_parts() == 2
+    rows = buf[: (m + 1) * cc * 128].view(torch.float16).view(m + 1, cc, 2, 32)[:m]
+    inv = buf[(m + 1) * cc * 128:(m + 1) * cc * 128 + 4].view(torch.float32)
+    vals = (rows[:, :, 0].float() + rows[:, :, 1].float()) * inv          # [m, cc, 32]
+    return vals.reshape(n, h, w, cc * 32)[..., :c].permute(0, 3, 1, 2)
+
+
 class GateReplay(object):
     """records the gates of every ReLU / ReLU6 site of the HIP forward; replays them, matched by shape in call order, in place
     of torch.nn.functional.relu / hardtanh during the oracle's forward"""
@@ -20,7 +36,7 @@ class GateReplay(object):
             out = rec._orig_cba(x, conv, bn, act, **kw)
             if act in (ops.ACT_RELU, ops.ACT_RELU6):
                 first = out[0] if isinstance(out, tuple) else out  # fork=True: (out, the input again)
-                d = first.detach()
+                d = activation_values(ops, first)
                 rec.gates.append(((d > 0) if act == ops.ACT_RELU else ((d > 0) & (d < 6))).cpu())
             return out
 

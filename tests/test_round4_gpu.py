@@ -175,3 +175,59 @@ def test_merged_loader_batches_give_the_same_features_and_scores():
             os.environ.pop("DASS_SCORE_MERGE", None)
         else:
             os.environ["DASS_SCORE_MERGE"] = keep
+
+
+def test_rows_only_outputs_change_nothing_but_the_bytes_written():
+    """conv_bn_act(sole_consumer=True): conv1 / conv2 of every bottleneck write ONLY the split rows their one reader takes.  One
+    train step of DeepLab-ResNet50 with the switch on and off (deterministic weight gradients): identical loss, identical gradients
+    of all parameters, identical running statistics; eval logits identical; and a rows-only activation handed to a consumer that
+    does not take split rows fails loudly instead of reading memory nobody wrote."""
+    from dass_hip import ops
+    from models.deeplab import DeepLab
+    from utils.loss import SegmentationLosses
+
+    keep = ops.f32_mma()
+    try:
+        ops.set_f32_mma("f16x3")
+        ops.set_deterministic(True)
+        _, O = _model("resnet", seed=3)
+        om = O.ODeepLab("resnet", 16, 19)
+        O.fill_state_dict(om, seed=3, randomize_bn_stats=False)
+        x, lab = O.synthetic_batch(2, 129, 129, 19, first_index=700)
+        m1, m2 = O.dropout_masks(2, 1, seed=4)
+        res = {}
+        for on in (True, False):
+            ops.set_rows_only(on)
+            pm = DeepLab(backbone="resnet", output_stride=16, num_classes=19, sync_bn=False, pretrained=False)
+            pm.load_state_dict(om.state_dict())
+            pm = pm.cuda().train()
+            loss = SegmentationLosses(cuda=True).build_loss("ce")(pm(x.cuda(), dropout_masks=(m1[0].cuda(), m2[0].cuda())), lab.cuda())
+            loss.backward()
+            grads = {k: p.grad.clone() for k, p in pm.named_parameters()}
+            stats = {k: v.clone() for k, v in pm.state_dict().items() if "running" in k}
+            pm.eval()
+            with torch.no_grad():
+                logits = pm(x.cuda()).clone()
+            res[on] = (loss.item(), grads, stats, logits)
+        assert res[True][0] == res[False][0]
+        for k in res[True][1]:
+            assert torch.equal(res[True][1][k], res[False][1][k]), k
+        for k in res[True][2]:
+            assert torch.equal(res[True][2][k], res[False][2][k]), k
+        assert torch.equal(res[True][3], res[False][3])
+        # misuse: the producer was told its only reader is `c2`, but the tensor goes to a depthwise conv
+        ops.set_rows_only(True)
+        c1 = torch.nn.Conv2d(64, 64, 1, bias=False).cuda()
+        c2 = torch.nn.Conv2d(64, 64, 3, padding=1, bias=False).cuda()
+        dw = torch.nn.Conv2d(64, 64, 3, padding=1, groups=64, bias=False).cuda()
+        xin = torch.randn(2, 64, 33, 33, device="cuda").contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            o = ops.conv_bn_act(xin, c1, None, ops.ACT_RELU, consumer=c2, sole_consumer=True)
+            assert o.__dict__.get("_dass_rows_only")
+            ops.conv_bn_act(o, c2, None, ops.ACT_RELU)           # the declared reader: fine
+            with pytest.raises(RuntimeError, match="sole_consumer"):
+                ops.conv_bn_act(o, dw, None, ops.ACT_NONE)
+    finally:
+        ops.set_rows_only(True)
+        ops.set_deterministic(False)
+        ops.set_f32_mma(keep)
