@@ -53,10 +53,11 @@ import torch  # noqa: E402
 
 # MI355X_MICROARCH.md dense peaks, per ALGORITHMIC flop of each conv engine: the split engines execute 6 (3) bf16
 # MFMA products per f32 product, so their ceiling in algorithmic TFLOP/s is the bf16 peak / 6 (/ 3)
-MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16x6": 2500.0 / 6, "bf16x3": 2500.0 / 3, "f16x3": 2500.0 / 3, "bf16": 2500.0}
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16x6": 2500.0 / 6, "bf16x3": 2500.0 / 3, "f16x3": 2500.0 / 3, "bf16": 2500.0, "bf16x1": 2500.0}
 PEAK_NOTE = {"f32": "f32 MFMA dense", "bf16x6": "bf16 MFMA dense 2500 / 6 products per f32 product",
              "bf16x3": "bf16 MFMA dense 2500 / 3 products per f32 product",
-             "f16x3": "f16 MFMA dense 2500 / 3 products per f32 product (two scaled f16 parts per operand)", "bf16": "bf16 MFMA dense"}
+             "f16x3": "f16 MFMA dense 2500 / 3 products per f32 product (two scaled f16 parts per operand)", "bf16": "bf16 MFMA dense",
+             "bf16x1": "bf16 MFMA dense (one bf16 part per operand, one product: a perf engine on f32 tensors, not parity-grade)"}
 TRAIN_GFLOP_PER_IMAGE = 556.9  # 3 x 92.81 GMAC x 2 (R101 os16 513^2)
 MC_GFLOP_PER_IMAGE = 573.6     # 2 x (71.26 + 10 x 21.55) GMAC, T=10
 
@@ -76,9 +77,12 @@ def parse():
     ap.add_argument("--no-coreset", action="store_true")
     ap.add_argument("--no-pool-reader", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="headline mode (f32 = parity mode)")
-    ap.add_argument("--f32-mma", default=os.environ.get("DASS_F32_MMA", "f16x3"), choices=["f16x3", "bf16x6", "f32", "bf16x3"],
+    ap.add_argument("--f32-mma", default=os.environ.get("DASS_F32_MMA", "f16x3"), choices=["f16x3", "bf16x6", "f32", "bf16x3", "bf16x1"],
                     help="conv engine of the f32 headline (f16x3 = two scaled f16 parts per operand, three products: the default parity "
                          "engine; bf16x6 = three bf16 parts, six products)")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="capture the train step into a hipGraph (dass_hip/graph.py) and time K replays: 'auto' = on for the perf engine "
+                         "bf16x1, whose step is bound by the host's ~550 launches per step, off for the GPU-bound parity engines")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mc", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -215,7 +219,7 @@ def conv_aggregate(args, ops, tdt):
         wop = ops.prepare_conv_weight(wt.to(tdt) if tdt != torch.float32 else wt, x3=x3_fwd)
         wop_t = ops.prepare_conv_weight((wt.permute(3, 1, 2, 0).flip(1, 2).contiguous()).to(tdt) if tdt != torch.float32
                                         else wt.permute(3, 1, 2, 0).flip(1, 2).contiguous(), x3=x3_dg)
-        if x3_fwd and ops.x3_parts() == 2:
+        if x3_fwd and ops.x3_parts() <= 2:
             x3_ = ops.split3_rows(x, c, n * h * w, c)      # (written by the producer's BN-apply pass in the step)
             tot["fwd"] += cnt * timeit(lambda: ops.conv_x3_launch(x3_, wop, y, k, (n, h, w, c, oh, ow, k, ks, ks, st, pad, dil)))
         elif x3_fwd:
@@ -385,13 +389,23 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
         torch.cuda.synchronize()
         if rank == 0:
             log("[%s] warm-up step %d: %.1f ms" % (dtype_name, i, (time.perf_counter() - tw) * 1e3))
+    use_graph = steps > 0 and world == 1 and (args.graph == "on" or (args.graph == "auto" and engine == "bf16x1"))
+    timed_step = train_step
+    if use_graph:
+        from dass_hip.graph import GraphedStep
+
+        timed_step = GraphedStep(train_step, warmup=2)   # zero_grad + forward + loss + backward + SGD as ONE graph launch
+        for _ in range(2):
+            timed_step()
+        if rank == 0:
+            log("[%s] train step captured into a hipGraph" % dtype_name)
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss = train_step()
+        loss = timed_step()
     barrier()
     dt = max(tmax(time.perf_counter() - t0), 1e-9)
-    res = {"train_ips": b * world * steps / dt, "ms_per_step": dt / max(steps, 1) * 1e3, "final_loss": float(loss.detach())}
+    res = {"train_ips": b * world * steps / dt, "ms_per_step": dt / max(steps, 1) * 1e3, "final_loss": float(loss.detach()), "graph": bool(use_graph)}
     if rank == 0 and steps > 0:
         log("[%s] train: %.2f images/s (%.1f ms/step)" % (dtype_name, res["train_ips"], res["ms_per_step"]))
 
@@ -526,10 +540,10 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
         if os.path.exists(tfile):  # HBM bytes per launch from the rocprofv3 --pmc passes (collected offline, see profiles/)
             traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
         kname = {"f32": "float,128,128,2,2", "bf16": "bf16,128,128,2,2", "bf16x6": "float,128,128,4,1,split=3",
-                 "bf16x3": "float,128,128,2,2,split=2", "f16x3": "float,128,128,4,1,split=3"}[engine]
+                 "bf16x3": "float,128,128,2,2,split=2", "f16x3": "float,128,128,4,1,split=3", "bf16x1": "float,128,128,4,1,split=3"}[engine]
         if x3_best:
             kname_full = "conv_x3_kernel<256,128,4,2,2,%s> + fix-up, pre-split operands (3x3 304->256 @%dx%d, batch %d)" % (
-                "NP=2: two f16 parts" if engine == "f16x3" else "NP=3: three bf16 parts", h_, h_, n_)
+                {"f16x3": "NP=2: two f16 parts", "bf16x1": "NP=1: one bf16 part"}.get(engine, "NP=3: three bf16 parts"), h_, h_, n_)
         else:
             kname_full = "conv_igemm_kernel<%s> (3x3 304->256 @%dx%d, batch %d)" % (kname, h_, h_, n_)
         best = {"kernel": kname_full, "achieved": round(achieved, 2),
@@ -552,7 +566,7 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
         cfile = os.path.join(ROOT, "profiles", "r02_clock_probe.json")
         if os.path.exists(cfile) and engine != "f32":
             cp = json.load(open(cfile))
-            div = {"bf16x6": 6.0, "bf16x3": 3.0, "f16x3": 3.0, "bf16": 1.0}[engine]
+            div = {"bf16x6": 6.0, "bf16x3": 3.0, "f16x3": 3.0, "bf16": 1.0, "bf16x1": 1.0}[engine]
             speak = cp["sustained_bf16_mfma_peak_tflops"] / div
             sustained = {"clock_ghz": cp["sustained_clock_ghz_all_cus_lds_fed"], "peak": round(speak, 1),
                          "frac": round(in_step / speak, 4), "isolated_frac": round(agg["achieved"] / speak, 4),
@@ -819,6 +833,8 @@ def main():
         if args.dtype == "f32":
             if args.f32_mma != "f32":
                 others["f32_mfma_mode"] = run_mode(args, env, "f32", k2, 4, "f32")
+            if args.f32_mma != "bf16x1":
+                others["bf16x1_perf_mode"] = run_mode(args, env, "f32", k2, 4, "bf16x1")  # one bf16 part per operand on the pipelined kernels
             others["bf16_perf_mode"] = run_mode(args, env, "bf16", k2, 4)  # 4 warm-up steps: the allocator re-grows after empty_cache()
         else:
             others["f32_parity_mode"] = run_mode(args, env, "f32", k2, 4, args.f32_mma)
@@ -847,16 +863,18 @@ def main():
                 "config": {"workload": "DeepLab-v3+ %s os16 %d-class %dx%d train step (fwd+CE+bwd+SGD), per-GPU batch %d"
                                        % (args.backbone, args.classes, s, s, b),
                            "global_batch": b * world, "parallelism": "dp%d" % world, "bn": "per-GPU",
-                           "f32_mma": args.f32_mma if args.dtype == "f32" else None,
+                           "f32_mma": args.f32_mma if args.dtype == "f32" else None, "hip_graph": head.get("graph", False),
                            "final_loss": round(head["final_loss"], 5)},
                 "mc_dropout": head["mc"], "core_set": head["coreset"], "pool_reader": reader, "roofline": head["roofline"],
                 "cpu_baseline": cpu}
         notes = {"bf16_perf_mode": "informational; bf16 storage does not meet the parity bar (tests/test_bf16_gpu.py measures the deviation)",
+                 "bf16x1_perf_mode": "informational; f32 tensors, the pipelined pre-split kernels with ONE bf16 part per operand and one product "
+                                     "(what autocast-bf16 multiplies); not parity-grade (tests/test_bf16_gpu.py)",
                  "f32_mfma_mode": "same f32 tensors, convs on v_mfma_f32_32x32x2_f32; parity-grade as well",
                  "f32_parity_mode": "the parity mode (f32 tensors)"}
         for name, other in others.items():
             line[name] = {"train_images_per_s": round(other["train_ips"], 3), "ms_per_step": round(other["ms_per_step"], 3),
-                          "final_loss": round(other["final_loss"], 5), "mc_dropout": other["mc"], "core_set": other["coreset"],
+                          "final_loss": round(other["final_loss"], 5), "hip_graph": other.get("graph", False), "mc_dropout": other["mc"], "core_set": other["coreset"],
                           "roofline": other["roofline"],
                           "note": notes[name]}
         print(json.dumps(line))

@@ -185,8 +185,8 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const T *__restric
                                                               const float *__restrict__ shift,
                                                               const T *__restrict__ res, long ldr,
                                                               const float *__restrict__ nc_scale, long M, int K,
-                                                              long rows_per_image, int act, char *__restrict__ out3) {
-    if (out3 && blockIdx.x == 0) x3_zero_row(out3, M, (K + 31) >> 5);
+                                                              long rows_per_image, int act, char *__restrict__ out3, int parts) {
+    if (out3 && blockIdx.x == 0) x3_zero_row(out3, M, (K + 31) >> 5, parts);
     const int cc3 = (K + 31) >> 5;
     // (row, 4-channel group) walked incrementally: the grid stride is decomposed once, so the loop has no 64-bit division
     const int kv = K >> 2;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const T *__restric
         for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
         if (nc_scale) v *= *reinterpret_cast<const f32x4 *>(nc_scale + (m / rows_per_image) * K + k);
         if (out) st4<T>(out + m * ldo + k, v);
-        if (out3) x3_store4(out3, m, cc3, k, v);  // the same values as three bf16 parts: operand of the next dense conv
+        if (out3) x3_store4r(out3, m, cc3, k, v, parts, 1.f);  // the same values as three (one) bf16 parts: operand of the next dense conv
     }
 }
 
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void bn_apply_train_kernel(const T *__restrict
         x3s = x3_scale_of(bound);
         if (blockIdx.x == 0) x3_zero_row(out3, M, (K + 31) >> 5, 2, x3_inv_of(x3s), bound);
     } else if (out3 && blockIdx.x == 0) {
-        x3_zero_row(out3, M, (K + 31) >> 5);
+        x3_zero_row(out3, M, (K + 31) >> 5, parts);
     }
     const int cc3 = (K + 31) >> 5;
     const int kv = K >> 2;
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
         x3s = x3_scale_of(bound);
         if (blockIdx.x == 0) x3_zero_row(dx3, M, (K + 31) >> 5, 2, x3_inv_of(x3s), bound);
     } else if (dx3 && blockIdx.x == 0) {
-        x3_zero_row(dx3, M, (K + 31) >> 5);
+        x3_zero_row(dx3, M, (K + 31) >> 5, parts);
     }
     if (sums && blockIdx.x == 0)  // the f64 sums of dass_bn_bwd_reduce_sums, rounded once: the parameter gradients
         for (int k = threadIdx.x; k < K; k += blockDim.x) {
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256, 5) void bn_bwd_fast_kernel(const float *__rest
         x3s = x3_scale_of(bound);
         if (blockIdx.x == 0) x3_zero_row(dx3, M, (K + 31) >> 5, 2, x3_inv_of(x3s), bound);
     } else if (blockIdx.x == 0) {
-        x3_zero_row(dx3, M, (K + 31) >> 5);
+        x3_zero_row(dx3, M, (K + 31) >> 5, parts);
     }
     if (blockIdx.x == 0)
         for (int k = threadIdx.x; k < K; k += blockDim.x) {
@@ -720,17 +720,17 @@ extern "C" int dass_scale_shift_act(const void *x, int64_t ldx, void *out, int64
                                     int64_t M, int K, int64_t rows_per_image, int act, int dtype, void *out3, void *stream) {
     if (!x || (!out && !out3) || M <= 0 || !ok4(K, ldx, out ? ldo : 4, residual ? ldr : 4) || rows_per_image <= 0) return DASS_ERR_ARG;
     if (out3 && (dtype != DASS_F32 || ((uintptr_t)out3 & 15))) return DASS_ERR_ARG;
-    if (out3 && dass_get_x3_parts() != 3) return DASS_ERR_UNSUPPORTED;  // no bound of x here: the consumer converts (dass_split3_rows)
+    if (out3 && dass_get_x3_parts() == 2) return DASS_ERR_UNSUPPORTED;  // no bound of x here: the consumer converts (dass_split3_rows)
     const int grid = dass_grid_1d(M * (K / 4), 256);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DASS_F32)
         DASS_LAUNCH(scale_shift_act_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, ldx,
                            (float *)out, ldo, scale, shift, (const float *)residual, ldr, nc_scale, M, K,
-                           rows_per_image, act, (char *)out3);
+                           rows_per_image, act, (char *)out3, dass_get_x3_parts());
     else if (dtype == DASS_BF16)
         DASS_LAUNCH(scale_shift_act_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t *)x, ldx,
                            (bf16_t *)out, ldo, scale, shift, (const bf16_t *)residual, ldr, nc_scale, M, K,
-                           rows_per_image, act, (char *)nullptr);
+                           rows_per_image, act, (char *)nullptr, 3);
     else
         return DASS_ERR_UNSUPPORTED;
     DASS_LAUNCH_CHECK();
@@ -779,7 +779,7 @@ extern "C" int dass_bn_bwd_apply_gate(const void *dout, int64_t lddo, const void
                                       const float *gate_shift, const float *nc_scale, void *dx, int64_t lddx, int64_t M, int K,
                                       int64_t rows_per_image, double count, int train, int act, int dtype, void *dx3, void *stream) {
     if (dx3 && ((uintptr_t)dx3 & 15)) return DASS_ERR_ARG;
-    if (dx3 && dass_get_x3_parts() != 3) return DASS_ERR_UNSUPPORTED;  // the two-part form needs max|dz| (the sums path supplies it)
+    if (dx3 && dass_get_x3_parts() == 2) return DASS_ERR_UNSUPPORTED;  // the two-part form needs max|dz| (the sums path supplies it)
     if (!dout || !x || !dx || !invstd || !gate_scale || !gate_shift || M <= 0 || !ok4(K, lddo, ldx, lddx) || rows_per_image <= 0)
         return DASS_ERR_ARG;
     if (train && (!mean || !dbeta || !dgamma || count <= 0)) return DASS_ERR_ARG;
@@ -809,7 +809,7 @@ extern "C" int dass_bn_bwd_apply(const void *dout, int64_t lddo, const void *out
                                  double count, int train, int act, int dtype, void *dx3, void *stream) {
     if (!dout || !out || M <= 0 || !ok4(K, lddo, ldo) || rows_per_image <= 0) return DASS_ERR_ARG;
     if (dx3 && (!dx || dtype != DASS_F32 || ((uintptr_t)dx3 & 15))) return DASS_ERR_ARG;
-    if (dx3 && dass_get_x3_parts() != 3) return DASS_ERR_UNSUPPORTED;
+    if (dx3 && dass_get_x3_parts() == 2) return DASS_ERR_UNSUPPORTED;
     if (dx && (!invstd || lddx % 4)) return DASS_ERR_ARG;
     if (dx && train && (!x || !mean || !dbeta || !dgamma || ldx % 4 || count <= 0)) return DASS_ERR_ARG;
     if (dres && lddr % 4) return DASS_ERR_ARG;

@@ -1068,8 +1068,9 @@ __global__ void weight_split3_kernel(const float *__restrict__ src, bf16_t *__re
 // desc[w] = {src, dst, K, R, S, Csrc, Cdst, mode} as 8 x int64; start[w] = first TILE of weight w, a tile being 32 operand
 // rows x one 32-wide reduction slab of one tap.  One 256-thread block per tile: the source is read along its contiguous
 // axis (c), transposed through LDS for the dgrad operand (mode 1), and written along the slab (coalesced both ways).
+// parts = 3: [3][32] bf16 slabs (DASS_F32X6); parts = 1: [1][32] bf16 slabs, the plain RNE cast (DASS_BF16X1, + a 1.0 trailer)
 __global__ __launch_bounds__(256) void weight_split3_batch_kernel(const long *__restrict__ desc, const long *__restrict__ start, int n,
-                                                                  long total_tiles) {
+                                                                  long total_tiles, int parts) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     for (long tl = blockIdx.x; tl < total_tiles; tl += gridDim.x) {
@@ -1114,11 +1115,15 @@ __global__ __launch_bounds__(256) void weight_split3_batch_kernel(const long *__
             const float r1 = v - bf16_to_f32(h);
             const bf16_t m = f32_to_bf16(r1);
             const bf16_t l = f32_to_bf16(r1 - bf16_to_f32(m));
-            bf16_t *o = dst + (((long)row * taps + t) * cch + cc) * 96 + tx;
+            bf16_t *o = dst + (((long)row * taps + t) * cch + cc) * (32 * parts) + tx;
             o[0] = h;
-            o[32] = m;
-            o[64] = l;
+            if (parts == 3) {
+                o[32] = m;
+                o[64] = l;
+            }
         }
+        if (parts == 1 && tl == start[lo] && threadIdx.x == 0)  // the trailer every pre-split operand carries: inverse scale 1.0
+            *reinterpret_cast<uint4 *>(dst + (long)rows * taps * cch * 32) = make_uint4(0x3f800000u, 0u, 0u, 0u);
     }
 }
 
@@ -1527,7 +1532,17 @@ extern "C" int dass_weight_split_batch(const void *desc, const int64_t *start, i
     if (!desc || !start || n <= 0 || total <= 0) return DASS_ERR_ARG;
     const long grid = total < 256 * 32 ? total : 256 * 32;
     DASS_LAUNCH(weight_split3_batch_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
-                       (const long *)desc, (const long *)start, n, (long)total);
+                       (const long *)desc, (const long *)start, n, (long)total, 3);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+/* the DASS_BF16X1 form (one bf16 part per weight: the "bf16x1" perf engine of the pre-split kernels, dass_set_x3_parts(1)) */
+extern "C" int dass_weight_split_batch_bf16(const void *desc, const int64_t *start, int n, int64_t total, void *stream) {
+    if (!desc || !start || n <= 0 || total <= 0) return DASS_ERR_ARG;
+    const long grid = total < 256 * 32 ? total : 256 * 32;
+    DASS_LAUNCH(weight_split3_batch_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
+                       (const long *)desc, (const long *)start, n, (long)total, 1);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
@@ -1538,6 +1553,7 @@ extern "C" int64_t dass_weight_split_bytes(int rows, int R, int S, int red) {
 /* bytes of the pre-split operand of `dtype` (DASS_F32X6: three bf16 parts; DASS_F16X3: two scaled f16 parts + scale trailer) */
 extern "C" int64_t dass_weight_operand_bytes(int rows, int R, int S, int red, int dtype) {
     if (dtype == DASS_F16X3) return (int64_t)rows * R * S * ((red + 31) / 32) * 128 + 16;
+    if (dtype == DASS_BF16X1) return (int64_t)rows * R * S * ((red + 31) / 32) * 64 + 16;
     return dass_weight_split_bytes(rows, R, S, red);
 }
 

@@ -111,6 +111,7 @@ template <int NP> __device__ __forceinline__ f32x4 mfma32(const uint4 &a, const 
 template <int NP> struct Terms;
 template <> struct Terms<3> { static constexpr int N = 6; static constexpr int PA[6] = {0, 2, 1, 0, 1, 0}; static constexpr int PB[6] = {2, 0, 1, 1, 0, 0}; };
 template <> struct Terms<2> { static constexpr int N = 3; static constexpr int PA[3] = {0, 1, 0}; static constexpr int PB[3] = {1, 0, 0}; };
+template <> struct Terms<1> { static constexpr int N = 1; static constexpr int PA[1] = {0}; static constexpr int PB[1] = {0}; };  // "bf16x1": one bf16 part, one product
 
 // fused epilogue of ONE 4-channel group of output pixel m (tile-independent: used by the main kernel and the fix-up pass)
 // (pre: the caller already holds this lane's 4 scale / shift values and its residual in sc4 / sh4 / r4 -- loaded once per pass of
@@ -517,13 +518,13 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
             const unsigned voff = valid ? rbo + nx_a_uni : p.zero_off + chunk_off;
             const unsigned dst = __builtin_amdgcn_readfirstlane(st + q * PG);
             dma16(rsa, dst, voff);
-            dma16(rsa, dst + 1024, voff + 64);
+            if constexpr (NP >= 2) dma16(rsa, dst + 1024, voff + 64);
             if constexpr (NP == 3) dma16(rsa, dst + 2048, voff + 128);
         } else if (!XE_NO_DMAB) {
             const unsigned voff = rbo + nx_b_uni;
             const unsigned dst = __builtin_amdgcn_readfirstlane(st + A_BYTES + (q - AG) * PG);
             dma16(rsb, dst, voff);
-            dma16(rsb, dst + 1024, voff + 64);
+            if constexpr (NP >= 2) dma16(rsb, dst + 1024, voff + 64);
             if constexpr (NP == 3) dma16(rsb, dst + 2048, voff + 128);
         }
     };
@@ -558,8 +559,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
             between(T);
         };
         one(std::integral_constant<int, 0>{});
-        one(std::integral_constant<int, 1>{});
-        one(std::integral_constant<int, 2>{});
+        if constexpr (NP >= 2) {
+            one(std::integral_constant<int, 1>{});
+            one(std::integral_constant<int, 2>{});
+        }
         if constexpr (NP == 3) {
             one(std::integral_constant<int, 3>{});
             one(std::integral_constant<int, 4>{});
@@ -596,7 +599,11 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
                     if (more) {
                         __builtin_amdgcn_sched_barrier(0);
                         issue16(T, nxt);
-                        if constexpr (tv == TT::N - 1 && RG > TT::N) issue16(std::integral_constant<int, (RG > TT::N ? TT::N : 0)>{}, nxt);
+                        if constexpr (tv == TT::N - 1) {  // the last term carries every rowgroup the terms did not cover (one term: all but the first)
+                            if constexpr (RG > TT::N) issue16(std::integral_constant<int, (RG > TT::N ? TT::N : 0)>{}, nxt);
+                            if constexpr (RG > TT::N + 1) issue16(std::integral_constant<int, (RG > TT::N + 1 ? TT::N + 1 : 0)>{}, nxt);
+                            if constexpr (RG > TT::N + 2) issue16(std::integral_constant<int, (RG > TT::N + 2 ? TT::N + 2 : 0)>{}, nxt);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -746,7 +753,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
         y3_scale = x3_scale_of(*reinterpret_cast<const float *>(p.y3 + ((long)p.M + 1) * p.cc_out * 128 + 4));
     if (p.y3 && tile == 0 && s_lo == 0) {  // the zero row consumers point padded taps at (+ the trailer of a three-part y3)
         const int zb = p.y3_parts * 64, n16 = p.cc_out * p.y3_parts * 4;
-        for (int i = tid; i < n16 + (p.y3_parts == 3 ? 1 : 0); i += 64 * NW)
+        for (int i = tid; i < n16 + (p.y3_parts != 2 ? 1 : 0); i += 64 * NW)
             *reinterpret_cast<uint4 *>(p.y3 + (long)p.M * p.cc_out * zb + i * 16) = i < n16 ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(0x3f800000u, 0u, 0u, 0u);
     }
 #pragma unroll
@@ -1047,7 +1054,10 @@ __global__ __launch_bounds__(256) void split3_rows_kernel(const float *__restric
             }
         }
         char *d = out + (m * CC + cc) * SB + oct * 16;
-        if constexpr (NP == 3) {
+        if constexpr (NP == 1) {
+            *reinterpret_cast<uint4 *>(d) = make_uint4(pk_bf16(dass_f32x2{v0[0], v0[1]}), pk_bf16(dass_f32x2{v0[2], v0[3]}),
+                                                       pk_bf16(dass_f32x2{v1[0], v1[1]}), pk_bf16(dass_f32x2{v1[2], v1[3]}));
+        } else if constexpr (NP == 3) {
             uint2 a0, a1, a2, b0, b1, b2;
             split3_4(v0, a0, a1, a2);
             split3_4(v1, b0, b1, b2);
@@ -1141,7 +1151,7 @@ template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE, int NP = 3> int 
     }
     const bool simple = p.whole && p.o_mul == 1;  // (per-image groups included: their tile -> rows map is two more multiplies)
     // whole-tile forms of the two-part kernel: the production picks + the 128 x 64 tile (wins layer-1 / 2 / 4 shapes, r04 sweep)
-    constexpr bool has_simple = NP == 2 && ((BM == 64 && BN == 64) || (BM == 256 && BN == 128) || (BM == 128 && BN == 64));
+    constexpr bool has_simple = NP <= 2 && ((BM == 64 && BN == 64) || (BM == 256 && BN == 128) || (BM == 128 && BN == 64));
     if (p.bs_sums && !(has_simple && simple)) p.bs_sums = nullptr;  // not fused: the caller runs dass_bn_bwd_reduce_sums itself
     g_bn_fused = p.bs_sums ? 1 : 0;
     g_last_pick = (BM << 16) | (BN << 4) | ((has_simple && simple) ? 2 : 0) | (stream ? 1 : 0);
@@ -1152,7 +1162,7 @@ template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE, int NP = 3> int 
             return DASS_OK;
         }
     }
-    if (m16 || NP == 2)  // (the two-part format is built for the 16x16x32 shape only)
+    if (m16 || NP != 3)  // (the two-part and one-part formats are built for the 16x16x32 shape only)
         DASS_LAUNCH((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE, true, NP>), dim3(p.sk_wgs), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
     else if constexpr (NP == 3)
         DASS_LAUNCH((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE, false, 3>), dim3(p.sk_wgs), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
@@ -1202,11 +1212,11 @@ static int dispatch_x3(X3P &p, hipStream_t st, long ws_bytes) {
         //  ~2 of them per CU; 276 tiles (M = 8712, K = 256) quantise badly on 256 CUs and stay 64 x 64, and so do the output-bound
         //  4-slab layers with >= 512 output channels, whose long tile epilogues overlap worse)
         const long t128 = (long)((p.M + 127) / 128) * ((p.K + 63) / 64);
-        const bool wide = g_x3_parts == 2 && t128 >= 2 * g_cus && !(s_tile <= 4 && p.K >= 512);
+        const bool wide = g_x3_parts <= 2 && t128 >= 2 * g_cus && !(s_tile <= 4 && p.K >= 512);
         if (p.K <= 64 || (t256 >= 4 * g_cus && s_tile <= 4)) { pick = wide ? 3 : 4; if (!mode) mode = 1; }
         else if (t256 >= 4 * g_cus) pick = 1;
         else if (s_tile >= 100) { pick = 1; if (!mode) mode = 2; }
-        else if (g_x3_parts == 2 && t256 >= 120 && t256 <= g_cus && s_tile >= 16) { pick = 1; if (!mode) mode = 1; }
+        else if (g_x3_parts <= 2 && t256 >= 120 && t256 <= g_cus && s_tile >= 16) { pick = 1; if (!mode) mode = 1; }
         else { pick = wide ? 3 : 4; if (!mode) mode = 1; }  // short reductions: segments would be too short to amortise the fix-up
     }
     if (g_x3_parts == 2) {
@@ -1220,6 +1230,14 @@ static int dispatch_x3(X3P &p, hipStream_t st, long ws_bytes) {
         case 8: return launch_x3<256, 128, 4, 2, 3, 2>(p, st, mode, ws_bytes, true);  // three stages of 48 KB fit only in the two-part format
         case 9: return launch_x3<64, 64, 2, 2, 4, 2>(p, st, mode, ws_bytes, true);   // four stages of 16 KB: three slabs in flight per workgroup
         default: return launch_x3<64, 64, 2, 2, 2, 2>(p, st, mode, ws_bytes, true);
+        }
+    }
+    if (g_x3_parts == 1) {  // "bf16x1": the production tiles only
+        switch (pick) {
+        case 1: case 8: return launch_x3<256, 128, 4, 2, 2, 1>(p, st, mode, ws_bytes, true);
+        case 2: case 5: case 7: return launch_x3<128, 128, 4, 2, 3, 1>(p, st, mode, ws_bytes, true);
+        case 3: return launch_x3<128, 64, 4, 1, 2, 1>(p, st, mode, ws_bytes, true);
+        default: return launch_x3<64, 64, 2, 2, 2, 1>(p, st, mode, ws_bytes, true);
         }
     }
     switch (pick) {
@@ -1257,7 +1275,7 @@ extern "C" int64_t dass_conv2d_x3_workspace_bytes(void) { return (int64_t)2 * 25
 
 /* operand format of the pre-split kernels and of every x3 buffer allocated from now on: 3 (default) or 2, see dass_common.h */
 extern "C" int dass_set_x3_parts(int parts) {
-    if (parts != 2 && parts != 3) return DASS_ERR_ARG;
+    if (parts < 1 || parts > 3) return DASS_ERR_ARG;
     g_x3_parts = parts;
     return DASS_OK;
 }
@@ -1290,6 +1308,9 @@ extern "C" int dass_split3_rows(const float *x, int64_t ld, void *out, int64_t M
         const int rc = dass_absmax_rows(x, ld, M, C, nc_scale, rows_per_image, (float *)(tr + 4), stream);
         if (rc != DASS_OK) return rc;
         DASS_LAUNCH(split3_rows_kernel<2>, dim3(dass_grid_1d((M + 1) * CC * 4, 256)), dim3(256), 0, st, x, (long)ld, (char *)out, (long)M, C,
+                           CC, nc_scale, (long)rows_per_image);
+    } else if (g_x3_parts == 1) {
+        DASS_LAUNCH(split3_rows_kernel<1>, dim3(dass_grid_1d((M + 1) * CC * 4, 256)), dim3(256), 0, st, x, (long)ld, (char *)out, (long)M, C,
                            CC, nc_scale, (long)rows_per_image);
     } else {
         DASS_LAUNCH(split3_rows_kernel<3>, dim3(dass_grid_1d((M + 1) * CC * 4, 256)), dim3(256), 0, st, x, (long)ld, (char *)out, (long)M, C,
@@ -1537,7 +1558,10 @@ __global__ __launch_bounds__(256) void split3_rows_packed_kernel(const float *__
             v1[e] = src[ci[4 + e]] * sc[4 + e];
         }
         char *d = out + (m * CC + cc) * SB + oct * 16;
-        if constexpr (NP == 3) {
+        if constexpr (NP == 1) {
+            *reinterpret_cast<uint4 *>(d) = make_uint4(pk_bf16(dass_f32x2{v0[0], v0[1]}), pk_bf16(dass_f32x2{v0[2], v0[3]}),
+                                                       pk_bf16(dass_f32x2{v1[0], v1[1]}), pk_bf16(dass_f32x2{v1[2], v1[3]}));
+        } else if constexpr (NP == 3) {
             uint2 a0, a1, a2, b0, b1, b2;
             split3_4(v0, a0, a1, a2);
             split3_4(v1, b0, b1, b2);
@@ -1611,7 +1635,7 @@ static int split_packed_impl(const float *x, int64_t ld, void *out, int64_t M, i
     if (g_x3_parts == 2) {
         if ((ld & 3) || (C & 3) || ((uintptr_t)x & 15)) return DASS_ERR_ARG;
         char *tr = (char *)out + x3_trailer_off(M, CC, 2);
-        if (!bound && src_images > 0) return DASS_ERR_ARG;  // (the replicated form needs the caller's bound)
+        if (g_x3_parts == 2 && !bound && src_images > 0) return DASS_ERR_ARG;  // (the replicated form needs the caller's bound)
         if (!bound) {  // no bound supplied: max |x * mask| by one more pass over the tensor
             if (hipMemsetAsync(tr, 0, 16, st) != hipSuccess) return DASS_ERR_LAUNCH;
             const int rc = dass_absmax_rows(x, ld, M, C, mask, rows_per_image, (float *)(tr + 4), stream);
@@ -1621,6 +1645,9 @@ static int split_packed_impl(const float *x, int64_t ld, void *out, int64_t M, i
         }
         DASS_LAUNCH(split3_rows_packed_kernel<2>, dim3((unsigned)(images * chunks + 1)), dim3(256), 0, st, x, (long)ld, (char *)out, (long)M,
                            C, CC, mask, order, cc_limit, (long)rows_per_image, (int)chunks, bound, bound_mul, src_images);
+    } else if (g_x3_parts == 1) {
+        DASS_LAUNCH(split3_rows_packed_kernel<1>, dim3((unsigned)(images * chunks + 1)), dim3(256), 0, st, x, (long)ld, (char *)out, (long)M,
+                           C, CC, mask, order, cc_limit, (long)rows_per_image, (int)chunks, (const float *)nullptr, 1.f, src_images);
     } else {
         DASS_LAUNCH(split3_rows_packed_kernel<3>, dim3((unsigned)(images * chunks + 1)), dim3(256), 0, st, x, (long)ld, (char *)out, (long)M,
                            C, CC, mask, order, cc_limit, (long)rows_per_image, (int)chunks, (const float *)nullptr, 1.f, src_images);
@@ -1658,6 +1685,9 @@ extern "C" int dass_w3_pack_per_image(const void *w3, void *out, int64_t rows, i
     const int CC = (C + 31) / 32;
     if (g_x3_parts == 2)
         DASS_LAUNCH(w3_pack_per_image_kernel<2>, dim3(dass_grid_1d((long)N * rows * CC * 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned short *)w3, (unsigned short *)out, (long)rows, CC, N, order, cc_limit);
+    else if (g_x3_parts == 1)
+        DASS_LAUNCH(w3_pack_per_image_kernel<1>, dim3(dass_grid_1d((long)N * rows * CC * 4, 256)), dim3(256), 0, (hipStream_t)stream,
                            (const unsigned short *)w3, (unsigned short *)out, (long)rows, CC, N, order, cc_limit);
     else
         DASS_LAUNCH(w3_pack_per_image_kernel<3>, dim3(dass_grid_1d((long)N * rows * CC * 4, 256)), dim3(256), 0, (hipStream_t)stream,

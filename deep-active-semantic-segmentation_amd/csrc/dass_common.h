@@ -93,6 +93,8 @@ __device__ __forceinline__ void split3_4(f32x4 v, uint2 &p0, uint2 &p1, uint2 &p
 //   [NP parts][32 ch] 2-byte elements (NP * 64 B), then ONE all-zero row (padded taps point at it), then a 16-B trailer
 //   {float inv_scale, float bound >= max |x|, float amax (max |x| itself where the producer knows it, else the bound), 0}.
 //   NP = 3 ("bf16x6" engine): x = x0 + x1 + x2, three bf16 parts, exact to 2^-26 |x|; six products per pair; trailer unused (1.0).
+//   NP = 1 ("bf16x1" engine, a PERF mode -- not parity-grade): x ~ bf16(x), one part, one product per pair: what autocast-bf16 multiplies;
+//            trailer unused (1.0).  f32 tensors everywhere else, exactly as in the two parity engines.
 //   NP = 2 ("f16x3" engine): x * s = h0 + h1, two f16 parts (h0 = f16(x s), h1 = f16(x s - h0): 11 + 1 + 11 significant bits,
 //            |x s - h0 - h1| <= 2^-23 |x s|); s = a power of two chosen per TENSOR from a guaranteed bound B >= max |x| so that
 //            B s lies in [2^14, 2^15) (f16 overflows at 65504); three products per pair (h0 g1, h1 g0, h0 g0 -- the dropped
@@ -134,6 +136,8 @@ template <int NP> __device__ __forceinline__ void x3_store4p(char *base, long m,
         *reinterpret_cast<uint2 *>(d) = q0;
         *reinterpret_cast<uint2 *>(d + 64) = q1;
         *reinterpret_cast<uint2 *>(d + 128) = q2;
+    } else if constexpr (NP == 1) {  // one bf16 part (RNE): the "bf16x1" perf engine
+        *reinterpret_cast<uint2 *>(d) = make_uint2(pk_bf16(dass_f32x2{v[0], v[1]}), pk_bf16(dass_f32x2{v[2], v[3]}));
     } else {
         uint2 q0, q1;
         split2_4(v * scale, q0, q1);
@@ -142,9 +146,10 @@ template <int NP> __device__ __forceinline__ void x3_store4p(char *base, long m,
     }
 }
 __device__ __forceinline__ void x3_store4(char *base, long m, int cc, int k, f32x4 v) { x3_store4p<3>(base, m, cc, k, v, 1.f); }
-// runtime-parts form for the streaming producers (BN apply / backward): parts in {2, 3}
+// runtime-parts form for the streaming producers (BN apply / backward): parts in {1, 2, 3}
 __device__ __forceinline__ void x3_store4r(char *base, long m, int cc, int k, f32x4 v, int parts, float scale) {
     if (parts == 2) x3_store4p<2>(base, m, cc, k, v, scale);
+    else if (parts == 1) x3_store4p<1>(base, m, cc, k, v, 1.f);
     else x3_store4p<3>(base, m, cc, k, v, 1.f);
 }
 // the all-zero row (index rows) + the trailer {inv_scale, bound}; call from ONE block of a producer kernel

@@ -59,6 +59,14 @@ __device__ __forceinline__ void wdma16x6(v4i rsrc, unsigned lds, unsigned soff, 
                  : "v"(v4), "v"(v5), "s"(lds + 4096u), "s"(rsrc), "s"(soff)
                  : "memory");
 }
+__device__ __forceinline__ void wdma16x2(v4i rsrc, unsigned lds, unsigned soff, unsigned v0, unsigned v1) {  // one-part rows: two pieces per chunk
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %0, %3, %4 offen lds\n\t"
+                 "buffer_load_dwordx4 %1, %3, %4 offen offset:1024 lds"
+                 :
+                 : "v"(v0), "v"(v1), "s"(lds), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
 constexpr unsigned WX3_BIAS = 8192u;  // the buffer descriptors start this many bytes BELOW the operands, so that `source - 1024 i` never wraps
 __device__ __forceinline__ v4i wmake_srd(const void *base, unsigned bytes) {
     const unsigned long long a = (unsigned long long)base;
@@ -91,7 +99,7 @@ template <int BMK, int BNC, int WARPS_M, int WARPS_N, int NSTAGE, int NP>
 __device__ __forceinline__ void wgrad_x3_body(const WX3P &p, int wg, char *smem) {
     constexpr int NW = WARPS_M * WARPS_N;
     constexpr int SB = NP * 64, CHB = NP * 2048;  // bytes of a row-slab in memory / of one 32-channel chunk of a 32-pixel LDS stage
-    constexpr int NTERM = NP == 3 ? 6 : 3;
+    constexpr int NTERM = NP == 3 ? 6 : NP == 2 ? 3 : 1;
     constexpr int TMW = BMK / WARPS_M, TNW = BNC / WARPS_N, MT = TMW / 32, NT = TNW / 32;
     constexpr int ACH = BMK / 32, BCH = BNC / 32;           // 32-channel chunks per operand
     constexpr int A_BYTES = ACH * CHB, B_BYTES = BCH * CHB, STAGE = A_BYTES + B_BYTES;
@@ -175,7 +183,11 @@ __device__ __forceinline__ void wgrad_x3_body(const WX3P &p, int wg, char *smem)
         ++next_slab;
         const unsigned s0 = src_of(pix, ROLE), s1 = src_of(pix + 16, ROLE);
         const v4i rs = decltype(ROLE)::value == 0 ? rsa : rsb;
-        if constexpr (NP == 2) {
+        if constexpr (NP == 1) {
+            const unsigned v0 = s0 + piece_k(0, 0), v1 = s1 + piece_k(0, 1);
+#pragma unroll
+            for (int j = 0; j < CHW; ++j) wdma16x2(rs, __builtin_amdgcn_readfirstlane(st + ldsoff[j]), soff[j], v0, v1);
+        } else if constexpr (NP == 2) {
             const unsigned v0 = s0 + piece_k(0, 0), v1 = s1 + piece_k(0, 1), v2 = s0 + piece_k(1, 0), v3 = s1 + piece_k(1, 1);
 #pragma unroll
             for (int j = 0; j < CHW; ++j) wdma16x4(rs, __builtin_amdgcn_readfirstlane(st + ldsoff[j]), soff[j], v0, v1, v2, v3);
@@ -231,8 +243,8 @@ __device__ __forceinline__ void wgrad_x3_body(const WX3P &p, int wg, char *smem)
                 for (int nt = 0; nt < NT; ++nt) {
                     // smallest products first.  NP = 3: (0,2) (2,0) (1,1) (0,1) (1,0) (0,0); NP = 2: (0,1) (1,0) (0,0)
                     constexpr int PA3[6] = {0, 2, 1, 0, 1, 0}, PB3[6] = {2, 0, 1, 1, 0, 0}, PA2[3] = {0, 1, 0}, PB2[3] = {1, 0, 0};
-                    const v8s av = frag(a[NP == 3 ? PA3[term] : PA2[term % 3]][mt]), bv = frag(b[NP == 3 ? PB3[term] : PB2[term % 3]][nt]);
-                    if constexpr (NP == 3)
+                    const v8s av = frag(a[NP == 3 ? PA3[term] : NP == 2 ? PA2[term % 3] : 0][mt]), bv = frag(b[NP == 3 ? PB3[term] : NP == 2 ? PB2[term % 3] : 0][nt]);
+                    if constexpr (NP != 2)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&av),
                                                                               *reinterpret_cast<const bf16x8 *>(&bv), acc[mt][nt], 0, 0, 0);
                     else
@@ -424,6 +436,10 @@ extern "C" int dass_conv2d_wgrad_x3(const void *x3, const void *dy3, float *dw, 
         if (big) return launch_wx3<128, 128, 4, 2, 3, 2>(p, st, target, min_slabs);
         return launch_wx3<64, 64, 2, 2, 3, 2>(p, st, target, min_slabs);
     }
+    if (parts == 1) {
+        if (big) return launch_wx3<128, 128, 2, 2, 2, 1>(p, st, target, min_slabs);
+        return launch_wx3<64, 64, 2, 2, 3, 1>(p, st, target, min_slabs);
+    }
     if (big) return launch_wx3<128, 128, 4, 2, 3>(p, st, target, min_slabs);
     return launch_wx3<64, 64, 2, 2, 3>(p, st, target, min_slabs);
 }
@@ -456,23 +472,38 @@ int launch_group(GroupItem *it, int n, char *scratch, hipStream_t st) {
         }
         it[j + 1] = key;
     }
-    // pinned staging tables (truly asynchronous copies), a ring of 8: a slot is rewritten only after the copy out of it, issued
-    // eight grouped launches earlier, has completed -- the host never waits for the stream in steady state
+    // pinned staging tables (truly asynchronous copies), a ring of 64: a slot is rewritten only after the copy out of it, issued
+    // 64 grouped launches earlier, has completed -- the host never waits for the stream in steady state.
+    // Under stream capture (a hipGraph around the train step) the copy becomes a graph node that reads the slot at EVERY replay:
+    // a slot used inside a capture is never handed out again (`pinned`), nothing is (re)allocated or waited for while capturing --
+    // the ring is sized once, outside (dass_conv2d_wgrad_x3_group_reserve) -- and a capture that needs more slots than are left fails
     struct Slot {
         WX3P *p = nullptr;
         int *b = nullptr;
         int cap = 0;
         hipEvent_t done = nullptr;
-        bool used = false;
+        bool used = false, pinned = false;
     };
-    static thread_local Slot ring[8];
+    constexpr int NSLOT = 64;
+    static thread_local Slot ring[NSLOT];
     static thread_local int next_slot = 0;
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cap_status) == hipSuccess && cap_status == hipStreamCaptureStatusActive;
+    int tries = 0;
+    // eager: the next slot that no captured graph owns; capturing: the next such slot that already HAS its buffers (eager warm-up
+    // steps on the same threads created them: a capture follows a few eager steps by construction, torch.cuda.graph demands it)
+    while (tries < NSLOT && (ring[next_slot].pinned || (capturing && (ring[next_slot].cap < n || !ring[next_slot].done)))) {
+        next_slot = (next_slot + 1) % NSLOT;
+        ++tries;
+    }
+    if (tries == NSLOT) return DASS_ERR_UNSUPPORTED;  // every slot belongs to a captured graph / none is ready for a capture
     Slot &sl = ring[next_slot];
-    next_slot = (next_slot + 1) & 7;
-    if (sl.used && hipEventSynchronize(sl.done) != hipSuccess) return DASS_ERR_LAUNCH;
+    next_slot = (next_slot + 1) % NSLOT;
+    if (!capturing && sl.used && hipEventSynchronize(sl.done) != hipSuccess) return DASS_ERR_LAUNCH;
+    if (capturing) sl.pinned = true;
     if (sl.cap < n) {
         if (sl.p) { (void)hipHostFree(sl.p); (void)hipHostFree(sl.b); }
-        sl.cap = n + 64;
+        sl.cap = n > 448 ? n + 64 : 512;
         if (hipHostMalloc((void **)&sl.p, sizeof(WX3P) * sl.cap) != hipSuccess || hipHostMalloc((void **)&sl.b, sizeof(int) * (sl.cap + 1)) != hipSuccess) {
             sl.cap = 0;
             sl.p = nullptr;
@@ -494,8 +525,8 @@ int launch_group(GroupItem *it, int n, char *scratch, hipStream_t st) {
     int *dev_b = reinterpret_cast<int *>(scratch + sizeof(WX3P) * n);
     if (hipMemcpyAsync(dev_p, host_p, sizeof(WX3P) * n, hipMemcpyHostToDevice, st) != hipSuccess) return DASS_ERR_LAUNCH;
     if (hipMemcpyAsync(dev_b, host_b, sizeof(int) * (n + 1), hipMemcpyHostToDevice, st) != hipSuccess) return DASS_ERR_LAUNCH;
-    if (hipEventRecord(sl.done, st) != hipSuccess) return DASS_ERR_LAUNCH;
-    sl.used = true;
+    if (!capturing && hipEventRecord(sl.done, st) != hipSuccess) return DASS_ERR_LAUNCH;
+    sl.used = !capturing;
     DASS_LAUNCH((wgrad_x3_group_kernel<BMK, BNC, WARPS_M, WARPS_N, NSTAGE, NP>), dim3((unsigned)total), dim3(64 * WARPS_M * WARPS_N), 0, st, dev_p, dev_b, n);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
@@ -555,6 +586,8 @@ extern "C" int dass_conv2d_wgrad_x3_group(const int64_t *items, int n, void *scr
             else if (gtile == 2) rc = launch_group<128, 128, 2, 2, 3, 2>(big, nb, sc, st);  // the same with three stages (one workgroup per CU)
             else if (gtile == 3) rc = launch_group<128, 128, 4, 2, 2, 2>(big, nb, sc, st);  // 8 waves of 32 x 64, two stages
             else rc = launch_group<128, 128, 4, 2, 3, 2>(big, nb, sc, st);
+        } else if (parts == 1) {
+            rc = launch_group<128, 128, 2, 2, 2, 1>(big, nb, sc, st);
         } else {
             rc = launch_group<128, 128, 4, 2, 3, 3>(big, nb, sc, st);
         }
@@ -562,6 +595,7 @@ extern "C" int dass_conv2d_wgrad_x3_group(const int64_t *items, int n, void *scr
     if (rc == DASS_OK) {
         char *sc2 = sc + ((sizeof(WX3P) * nb + sizeof(int) * (nb + 1) + 63) / 64) * 64;
         if (parts == 2) rc = launch_group<64, 64, 2, 2, 3, 2>(small, ns, sc2, st);
+        else if (parts == 1) rc = launch_group<64, 64, 2, 2, 3, 1>(small, ns, sc2, st);
         else rc = launch_group<64, 64, 2, 2, 3, 3>(small, ns, sc2, st);
     }
     delete[] big;

@@ -16,13 +16,14 @@ import torch
 
 from ._lib import check, lib
 
-F32, BF16, F32X3, F32X6, F16X3 = 0, 1, 2, 3, 4
+F32, BF16, F32X3, F32X6, F16X3, BF16X1 = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 
 _state = {"dtype": torch.float32, "f32_mma": os.environ.get("DASS_F32_MMA", "f16x3"),
           "x3": os.environ.get("DASS_X3", "select"), "mc_sparse": os.environ.get("DASS_MC_SPARSE", "1") != "0"}
 assert _state["x3"] in ("off", "infer", "select", "all"), "DASS_X3 must be off, infer, select or all"
-assert _state["f32_mma"] in ("f32", "bf16x3", "bf16x6", "f16x3"), "DASS_F32_MMA must be f32, bf16x3, bf16x6 or f16x3"
+assert _state["f32_mma"] in ("f32", "bf16x3", "bf16x6", "f16x3", "bf16x1"), "DASS_F32_MMA must be f32, bf16x3, bf16x6, f16x3 or bf16x1"
+_X3_ENGINES = ("bf16x6", "f16x3", "bf16x1")  # engines that can run the pre-split (x3) kernels
 _state["x3_f16"] = os.environ.get("DASS_X3_F16", "all")  # where the pre-split kernels run under the f16x3 engine
 assert _state["x3_f16"] in ("off", "infer", "select", "all")
 
@@ -50,21 +51,26 @@ def set_f32_mma(mode):
                products per pair run on the f16 MFMA pipe: the f32 product to 2^-22, half the matrix work of "bf16x6"; same
                parity bars (include/dass_hip.h "dass_set_x3_parts").  Layers the pre-split kernels do not take (<= 32 output
                channels, stems, depthwise) run the classic kernels exactly as under "bf16x6".
+      "bf16x1" a PERF engine, not a parity mode (round 4): the same pre-split kernels with ONE bf16 part per element and one
+               product per pair (dass_set_x3_parts(1)) -- what autocast-bf16 multiplies -- on f32 tensors: BN, loss, gradients
+               and master weights stay f32, every round-3/4 launch structure (grouped weight gradients, fused BN sums, whole-
+               tile kernels, rows-only outputs, batched MC tail) carries over.  A third of f16x3's matrix work, half its operand
+               bytes.  tests/test_bf16_gpu.py measures its deviation from the parity mode.
     Initial value from the environment variable DASS_F32_MMA."""
-    assert mode in ("f32", "bf16x3", "bf16x6", "f16x3")
+    assert mode in ("f32", "bf16x3", "bf16x6", "f16x3", "bf16x1")
     _state["f32_mma"] = mode
-    check(lib.dass_set_x3_parts(2 if mode == "f16x3" else 3), "dass_set_x3_parts")
+    check(lib.dass_set_x3_parts({"f16x3": 2, "bf16x1": 1}.get(mode, 3)), "dass_set_x3_parts")
 
 
 def x3_parts():
-    """parts per element of the x3 operand format in force (3 = bf16 triple, 2 = scaled f16 pair)"""
-    return 2 if _state["f32_mma"] == "f16x3" else 3
+    """parts per element of the x3 operand format in force (3 = bf16 triple, 2 = scaled f16 pair, 1 = one bf16: perf engine)"""
+    return {"f16x3": 2, "bf16x1": 1}.get(_state["f32_mma"], 3)
 
 
 def _x3_mode():
     """effective placement of the pre-split kernels: DASS_X3 under "bf16x6", DASS_X3_F16 (default "all") under "f16x3" -- with
     4 B instead of 6 B per split element and half the products, the all-layers form pays in training as well"""
-    return _state["x3_f16"] if _state["f32_mma"] == "f16x3" else _state["x3"]
+    return _state["x3_f16"] if _state["f32_mma"] in ("f16x3", "bf16x1") else _state["x3"]
 
 
 def f32_mma():
@@ -86,7 +92,7 @@ def set_x3_pipeline(mode):
     Same six products in the same order either way: results agree to the last bit or two."""
     mode = {True: "all", False: "off"}.get(mode, mode)
     assert mode in ("off", "infer", "select", "all")
-    _state["x3_f16" if _state["f32_mma"] == "f16x3" else "x3"] = mode
+    _state["x3_f16" if _state["f32_mma"] in ("f16x3", "bf16x1") else "x3"] = mode
 
 
 def x3_mode():
@@ -152,8 +158,8 @@ def set_deterministic(on):
 
 if os.environ.get("DASS_DETERMINISTIC", "0") == "1":
     lib.dass_set_deterministic(1)
-if _state["f32_mma"] == "f16x3":
-    lib.dass_set_x3_parts(2)
+if _state["f32_mma"] in ("f16x3", "bf16x1"):
+    lib.dass_set_x3_parts(2 if _state["f32_mma"] == "f16x3" else 1)
 
 
 def set_rows_only(on):
@@ -164,7 +170,7 @@ def set_rows_only(on):
 
 def x3_pipeline(training=False):
     """is the pre-split engine on for an inference call site (training=False) / for a call that records autograd"""
-    if _state["f32_mma"] not in ("bf16x6", "f16x3"):
+    if _state["f32_mma"] not in _X3_ENGINES:
         return False
     mode = _x3_mode()
     return mode == "all" or (mode in ("infer", "select") and not training)
@@ -172,7 +178,7 @@ def x3_pipeline(training=False):
 
 def _x3_train_layer(taps, red_channels):
     """training launches that go to the pre-split engine: all of them ("all") or the long 3x3 reductions ("select")"""
-    if _state["f32_mma"] not in ("bf16x6", "f16x3"):
+    if _state["f32_mma"] not in _X3_ENGINES:
         return False
     mode = _x3_mode()
     return mode == "all" or (mode == "select" and taps >= _SELECT[0] and red_channels >= _SELECT[1])
@@ -189,7 +195,7 @@ def _cdt(t):
     """dtype code for the MFMA conv entry points"""
     d = _dt(t)
     if d == F32:
-        return {"f32": F32, "bf16x3": F32X3, "bf16x6": F32X6, "f16x3": F32X6}[_state["f32_mma"]]
+        return {"f32": F32, "bf16x3": F32X3, "bf16x6": F32X6, "f16x3": F32X6, "bf16x1": F32X6}[_state["f32_mma"]]
     return d
 
 
@@ -648,7 +654,7 @@ def bn_eval_state(bn, k, device):
     tensors changes (version counters), so the T passes of MC-dropout scoring and every pool batch reuse one launch"""
     def ver(t):
         return None if t is None else (t.data_ptr(), t._version)
-    key = (ver(bn.weight), ver(bn.bias), ver(bn.running_mean), ver(bn.running_var), float(bn.eps), k, str(device))
+    key = (ver(bn.weight), ver(bn.bias), ver(bn.running_mean), ver(bn.running_var), float(bn.eps), k, str(device), _wepoch["n"])
     hit = bn.__dict__.get("_dass_eval_state")
     if hit is not None and hit[0] == key:
         return hit[1]
@@ -691,6 +697,14 @@ def bn_use_batch_stats(bn):
 
 # ----------------------------------------------------------------------------- weight operands
 _wcache = {}
+_wepoch = {"n": 0}  # bumped by weights_changed(): part of every operand cache key next to the parameter's version counter
+
+
+def weights_changed():
+    """parameters were written behind autograd's back -- a replayed hipGraph that contains the optimizer step (dass_hip/graph.py) --
+    so their version counters did not move: every cached weight operand (casts, splits, L1 norms) is stale from now on"""
+    _wepoch["n"] += 1
+    _l1_cache.clear()
 
 
 def _krsc_master(weight):
@@ -707,8 +721,10 @@ def _krsc_master(weight):
 def _split_fmt(dtype, x3):
     """pre-split operand format of an f32 conv weight: None (plain), F32X6 (three bf16 parts: classic bf16x6 kernel, pre-split
     kernels in their three-part mode) or F16X3 (two scaled f16 parts: pre-split kernels under the "f16x3" engine)"""
-    if dtype != torch.float32 or _state["f32_mma"] not in ("bf16x6", "f16x3"):
+    if dtype != torch.float32 or _state["f32_mma"] not in _X3_ENGINES:
         return None
+    if x3 and _state["f32_mma"] == "bf16x1":
+        return BF16X1
     return F16X3 if (x3 and _state["f32_mma"] == "f16x3") else F32X6
 
 
@@ -718,7 +734,7 @@ def weight_operand(weight, mode, dtype, cpad=None, x3=False):
     k, c, r, s = weight.shape
     cdst = c if cpad is None else cpad
     split6 = _split_fmt(dtype, x3)
-    key = (weight.data_ptr(), weight._version, mode, dtype, cdst, tuple(weight.shape), split6)
+    key = (weight.data_ptr(), weight._version, mode, dtype, cdst, tuple(weight.shape), split6, _wepoch["n"])
     hit = _wcache.get((id(weight), mode, split6))
     if hit is not None and hit[0] == key and hit[2]() is weight:
         return hit[1]
@@ -762,14 +778,14 @@ def _split6_registered(weight, master, mode, cdst, fmt=F32X6):
         ent.op = torch.empty((lib.dass_weight_operand_bytes(rows, r, s, red, fmt),), dtype=torch.uint8, device=weight.device)
         ent.items = ((rows + 31) // 32) * r * s * ((red + 31) // 32)  # tiles of 32 rows x one slab
         _split_reg["entries"][(id(weight), mode, fmt)] = ent
-    if ent.version != weight._version:
+    if ent.version != (weight._version, _wepoch["n"]):
         dead = [kk for kk, e in _split_reg["entries"].items() if e.weight() is None]
         for kk in dead:  # parameters that no longer exist: release their operands
             del _split_reg["entries"][kk]
         stale = []
         for e in _split_reg["entries"].values():
             wt = e.weight()
-            if e.fmt == fmt and e.version != wt._version and wt.device == weight.device and wt.data_ptr() == e.master.data_ptr():
+            if e.fmt == fmt and e.version != (wt._version, _wepoch["n"]) and wt.device == weight.device and wt.data_ptr() == e.master.data_ptr():
                 stale.append((e, wt))
         key = tuple((e.master.data_ptr(), e.mode, e.op.data_ptr()) for e, _ in stale)
         if _split_reg["table_key"].get(fmt) != key:
@@ -784,10 +800,12 @@ def _split6_registered(weight, master, mode, cdst, fmt=F32X6):
         desc, start_t, total = _split_reg["table"][fmt]
         if fmt == F16X3:
             check(lib.dass_weight_split_batch_f16(_p(desc), _p(start_t), len(stale), total, _stream()), "dass_weight_split_batch_f16")
+        elif fmt == BF16X1:
+            check(lib.dass_weight_split_batch_bf16(_p(desc), _p(start_t), len(stale), total, _stream()), "dass_weight_split_batch_bf16")
         else:
             check(lib.dass_weight_split_batch(_p(desc), _p(start_t), len(stale), total, _stream()), "dass_weight_split_batch")
         for e, wt in stale:
-            e.version = wt._version
+            e.version = (wt._version, _wepoch["n"])
     return ent.op
 
 
@@ -796,11 +814,14 @@ def _split6_operand(master, k, r, s, c, cdst, mode, fmt=F32X6):
     scaled f16 parts + trailer: a one-entry dass_weight_split_batch_f16)"""
     rows, red = (k, cdst) if mode == 0 else (c, k)
     op = torch.empty((lib.dass_weight_operand_bytes(rows, r, s, red, fmt),), dtype=torch.uint8, device=master.device)
-    if fmt == F16X3:
+    if fmt in (F16X3, BF16X1):
         desc = torch.tensor([[master.data_ptr(), op.data_ptr(), k, r, s, c, cdst, mode]], dtype=torch.int64).to(master.device)
         start = torch.zeros((1,), dtype=torch.int64, device=master.device)
         total = ((rows + 31) // 32) * r * s * ((red + 31) // 32)
-        check(lib.dass_weight_split_batch_f16(_p(desc), _p(start), 1, total, _stream()), "dass_weight_split_batch_f16")
+        if fmt == F16X3:
+            check(lib.dass_weight_split_batch_f16(_p(desc), _p(start), 1, total, _stream()), "dass_weight_split_batch_f16")
+        else:
+            check(lib.dass_weight_split_batch_bf16(_p(desc), _p(start), 1, total, _stream()), "dass_weight_split_batch_bf16")
         op._dass_keep = (master, desc, start)  # (the launches read these asynchronously)
     else:
         check(lib.dass_weight_transform(_p(master), _p(op), k, r, s, c, cdst, mode, F32X6, _stream()), "dass_weight_transform")
@@ -1034,7 +1055,7 @@ class _ConvBnAct(torch.autograd.Function):
                 scale, shift = None, (bias.detach().float() if bias is not None else None)
             out3 = None
             if ((x3_on or (need_grad and getattr(spec, "x3_consumer", False))) and dt == torch.float32
-                    and getattr(spec, "emit_x3", True) and k >= 32 and kpad == k and (x3_parts() == 3 or sums is not None)):
+                    and getattr(spec, "emit_x3", True) and k >= 32 and kpad == k and (x3_parts() != 2 or sums is not None)):
                 out3 = x3_alloc_for(m, k, dev)  # the consumer is (almost always) the next dense conv: hand it split rows
             if sums is not None:
                 state = BNState(k, dev)
@@ -1199,7 +1220,7 @@ class _ConvBnAct(torch.autograd.Function):
             if (dt == torch.float32 and not spec.depthwise and not ctx.image_input and k >= 32
                     and ((ctx.x3_dgrad and ctx.needs_input_grad[0] and c > 32)
                          or (ctx.x3_on and ctx.needs_input_grad[1] and x3_in is not None))
-                    and (x3_parts() == 3 or bsums is not None)):  # two-part rows need max |dz|: the sums path supplies it
+                    and (x3_parts() != 2 or bsums is not None)):  # two-part rows need max |dz|: the sums path supplies it
                 dy3 = x3_alloc_for(m, k, dev)  # dy also as split rows: operand of the input- and weight-gradient launches
             if bsums is not None:
                 if dy3 is not None and not spec.depthwise and not getattr(spec, "rowtap", False):
@@ -1267,7 +1288,7 @@ class _ConvBnAct(torch.autograd.Function):
                 dy3_w = None
                 if x3_in is not None and kk == k and ctx.x3_on and x3_in.numel() == lib.dass_x3_bytes(n * h * w, c):
                     dy3_w = attached_x3(dy, m, k)
-                    if dy3_w is None and x3_parts() == 2 and lddy % 4 == 0:  # (no BN pass emitted them: convert once, both gradients use them)
+                    if dy3_w is None and x3_parts() <= 2 and lddy % 4 == 0:  # (no BN pass emitted them: convert once, both gradients use them)
                         dy3_w = x3_operand(dy, dy, lddy, m, k)
                 if dy3_w is not None and _wg["on"] and side is None and c == c_in:
                     # a weight gradient has no consumer before the optimizer step: queue it; ALL queued layers are computed by
@@ -1302,7 +1323,7 @@ class _ConvBnAct(torch.autograd.Function):
                     dy3 = x3_operand(dy, dy, lddy, m, kk)
                     link = getattr(ctx, "in_link", None)
                     if (link is not None and not link.dead and spec.stride == 1 and d_fork is None and ctx.x_dtype == dx.dtype
-                            and x3_parts() == 2):
+                            and x3_parts() <= 2):
                         # dx is the d_out of the layer that produced this conv's input: its BN-backward sums ride in this
                         # launch's epilogue (no separate pass over dx and that layer's conv output)
                         conv_x3_dgrad_bnstats(dy3, w_t, dx, (n, oh, ow, kk, h, w, c, r, s, 1, pad_t, spec.dil), link, residual=add_t,
@@ -1465,6 +1486,20 @@ def _wgrad_flush(final=True):
         _wgrad_finish(q)
 
 
+def graph_capture_begin():
+    """call right before capturing a step into a hipGraph (dass_hip/graph.py): the zeroed arenas (conv weight gradients, BN f64
+    sums) are dropped, so the capture allocates -- and ZEROES, as graph nodes -- fresh ones: every replay starts from zeros"""
+    _dw_arena["buf"], _dw_arena["off"] = None, 0
+    _bn_sum_arena["buf"], _bn_sum_arena["off"] = None, 0
+    flush_bn_counters()
+
+
+def graph_capture_end():
+    """after the capture: eager steps must not cut from arenas that belong to the graph's memory pool"""
+    _dw_arena["buf"], _dw_arena["off"] = None, 0
+    _bn_sum_arena["buf"], _bn_sum_arena["off"] = None, 0
+
+
 _dw_arena = {"buf": None, "off": 0, "size": 1 << 21, "on": os.environ.get("DASS_DW_ARENA", "1") == "1"}
 
 
@@ -1545,7 +1580,7 @@ def conv_bn_act(x, conv, bn=None, act=ACT_NONE, residual=None, nc_scale=None, ex
     # then carries only its attached rows and is flagged; a reader that wants its f32 values fails loudly (x3_operand, _ConvBnAct).
     spec.rows_only = False
     if (sole_consumer and _ROWS_ONLY and consumer is not None and emit_x3 and residual is None and nc_scale is None and act != ACT_NONE
-            and compute_dtype() == torch.float32 and x3_parts() == 2 and x3_pipeline(training=spec.grad_enabled)
+            and compute_dtype() == torch.float32 and x3_parts() <= 2 and x3_pipeline(training=spec.grad_enabled)
             and consumer.groups == 1 and consumer.out_channels > 32 and conv.out_channels % 32 == 0 and not image_input):
         oh = conv_out_size(x.shape[2], conv.kernel_size[0], spec.stride, spec.pad, spec.dil)
         ow = conv_out_size(x.shape[3], conv.kernel_size[1], spec.stride, spec.pad, spec.dil)

@@ -43,6 +43,9 @@ extern "C" {
 #define DASS_F16X3 4 /* weight-operand format of the pre-split kernels in their two-part mode (dass_set_x3_parts(2)):
                         w * s as two f16 parts, s = a per-tensor power of two; three products per pair.  See "x3 rows". */
 
+#define DASS_BF16X1 5 /* weight-operand format of the pre-split kernels in their ONE-part mode (dass_set_x3_parts(1), the "bf16x1" perf
+                         engine): bf16(w), one product per pair -- what autocast-bf16 multiplies; NOT parity-grade */
+
 #define DASS_ACT_NONE 0
 #define DASS_ACT_RELU 1
 #define DASS_ACT_RELU6 2
@@ -119,6 +122,8 @@ int64_t dass_weight_operand_bytes(int rows, int R, int S, int red, int dtype);
 int dass_weight_split_batch(const void *desc, const int64_t *start, int n, int64_t total, void *stream);
 /* the same table, DASS_F16X3 operands: zero the trailers, max |w| per tensor (the scale), split -- three launches */
 int dass_weight_split_batch_f16(const void *desc, const int64_t *start, int n, int64_t total, void *stream);
+/* the same table, DASS_BF16X1 operands (64 B per slab + trailer): one launch */
+int dass_weight_split_batch_bf16(const void *desc, const int64_t *start, int n, int64_t total, void *stream);
 
 /* depthwise 3x3 (MobileNetV2 InvertedResidual, mobilenet.py:49,59): w[c][3][3] f32 */
 int dass_dwconv3x3_fwd(const void *x, int64_t ldx, const float *w, void *y, int64_t ldy,
@@ -409,6 +414,9 @@ int64_t dass_x3_bytes(int64_t rows, int C);
 int dass_weight_l1(const float *w, int K, int64_t row_len, float *l1, void *stream);
 int dass_x3_prepare_out(void *y3, int64_t out_rows, int K, const float *l1, const float *scale, const float *shift, const void *x3_in,
                         int64_t in_rows, int in_C, const float *res_amax, float mask_max, int act, void *stream);
+/* parts: 3 (three bf16 parts, "bf16x6"), 2 (two scaled f16 parts, "f16x3") or 1 -- ONE bf16 part per element, one product per pair:
+ * the "bf16x1" PERF engine (round 4).  Same kernels, same f32 tensors everywhere else; 64-B row-slabs, no per-tensor scales.  What it
+ * multiplies is what autocast-bf16 multiplies: not parity-grade (tests/test_bf16_gpu.py measures its deviation). */
 int dass_set_x3_parts(int parts);
 int dass_get_x3_parts(void);
 /* bound[0] = max over rows of |x[m][c] * nc_scale[m / rows_per_image][c]| (nc_scale nullable), as an atomic max: zero it first */
