@@ -1361,7 +1361,8 @@ class _ConvBnAct(torch.autograd.Function):
 # autograd's AccumulateGrad node would have done; the Function itself returns None for the weight.  DASS_WGRAD_DEFER=0 /
 # set_deferred_wgrad(False): per-layer launches inside backward.
 _wg = {"on": os.environ.get("DASS_WGRAD_DEFER", "1") == "1", "queue": [], "armed": False, "pending": set(),
-       "chunk": int(os.environ.get("DASS_WGRAD_CHUNK", "16")), "side": os.environ.get("DASS_WGRAD_SIDE", "1") == "1"}
+       "chunk": int(os.environ.get("DASS_WGRAD_CHUNK", "16")), "side": os.environ.get("DASS_WGRAD_SIDE", "1") == "1",
+       "side_capture": os.environ.get("DASS_WGRAD_SIDE_CAPTURE", "1") == "1"}
 if not hasattr(torch._C, "_current_graph_task_id"):
     _wg["on"] = False  # without the graph-task id a failed backward pass could not be told from the next one: per-layer launches
 
@@ -1463,7 +1464,9 @@ def _wgrad_flush(final=True):
     nbytes = lib.dass_conv2d_wgrad_x3_group_scratch_bytes(len(q)) + 128
     scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
     side = None
-    if not final and _wg["side"] and not torch.cuda.is_current_stream_capturing():
+    # (under stream capture the side stream joins the capture through the fork event and re-joins at the next flush: the graph keeps
+    #  the two-stream shape of the eager step; DASS_WGRAD_SIDE_CAPTURE=0: one stream inside a graph)
+    if not final and _wg["side"] and (_wg["side_capture"] or not torch.cuda.is_current_stream_capturing()):
         key = ("wgrad", dev.index if dev.index is not None else torch.cuda.current_device())
         side = _mc_side.get(key)
         if side is None:
