@@ -1470,7 +1470,14 @@ def _wgrad_flush(final=True):
         key = ("wgrad", dev.index if dev.index is not None else torch.cuda.current_device())
         side = _mc_side.get(key)
         if side is None:
-            side = _mc_side[key] = torch.cuda.Stream(device=dev)
+            # (DASS_WGRAD_SIDE_PRIO: HIP stream priority of the side stream, default 0; a positive value = below the caller's stream,
+            #  where the runtime offers such a level)
+            prio = int(os.environ.get("DASS_WGRAD_SIDE_PRIO", "0"))
+            try:
+                side = torch.cuda.Stream(device=dev, priority=prio)
+            except Exception:  # noqa: BLE001  (priority outside the device's range)
+                side = torch.cuda.Stream(device=dev)
+            _mc_side[key] = side
         ev = torch.cuda.Event()
         ev.record(main)           # operands (and the zeroed gradient arena) are complete on the caller's stream
         side.wait_event(ev)
