@@ -81,8 +81,9 @@ def parse():
                     help="conv engine of the f32 headline (f16x3 = two scaled f16 parts per operand, three products: the default parity "
                          "engine; bf16x6 = three bf16 parts, six products)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                    help="capture the train step into a hipGraph (dass_hip/graph.py) and time K replays: 'auto' = on for the perf engine "
-                         "bf16x1, whose step is bound by the host's ~550 launches per step, off for the GPU-bound parity engines")
+                    help="capture the train step into a hipGraph (dass_hip/graph.py) and time K replays: 'auto' = on for the single-GPU f16x3 / "
+                         "bf16x1 legs (the step's ~550 launches cost the host 26-29 ms, at or above the GPU time), falling back to eager steps "
+                         "if the capture fails; 'off' = eager")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mc", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -389,16 +390,27 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
         torch.cuda.synchronize()
         if rank == 0:
             log("[%s] warm-up step %d: %.1f ms" % (dtype_name, i, (time.perf_counter() - tw) * 1e3))
-    use_graph = steps > 0 and world == 1 and (args.graph == "on" or (args.graph == "auto" and engine == "bf16x1"))
+    # 'auto': every single-GPU f32-tensor leg.  The parity step is ~28 ms of GPU time against 26-29 ms of host time for its ~550 launches
+    # (the host's share differs from box to box: 285 img/s eager on one, 249 on another whose CPU needs 32 ms per step), the perf engine
+    # 21 ms against the same host time: a graph replay takes the host out of the step.  The bf16-storage mode keeps its eager loop.
+    use_graph = steps > 0 and world == 1 and dtype_name.startswith("f32") and mma in ("f16x3", "bf16x1") and args.graph in ("on", "auto")
+    if args.graph == "on" and steps > 0 and world == 1:
+        use_graph = True
     timed_step = train_step
     if use_graph:
         from dass_hip.graph import GraphedStep
 
-        timed_step = GraphedStep(train_step, warmup=2)   # zero_grad + forward + loss + backward + SGD as ONE graph launch
-        for _ in range(2):
-            timed_step()
-        if rank == 0:
-            log("[%s] train step captured into a hipGraph" % dtype_name)
+        try:
+            timed_step = GraphedStep(train_step, warmup=2)   # zero_grad + forward + loss + backward + SGD as ONE graph launch
+            for _ in range(2):
+                timed_step()
+            torch.cuda.synchronize()
+            if rank == 0:
+                log("[%s] train step captured into a hipGraph (two streams inside)" % dtype_name)
+        except Exception as exc:  # noqa: BLE001  (a capture the runtime refuses must not cost the run: eager steps instead)
+            log("[%s] hipGraph capture FAILED (%r): timing eager steps" % (dtype_name, exc))
+            use_graph, timed_step = False, train_step
+            torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):

@@ -215,8 +215,13 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream
+_cur_device = torch._C._cuda_getDevice
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # (the raw accessor: torch.cuda.current_stream() builds a Stream object per call, ~8 us, and a step asks ~360 times)
+    return ctypes.c_void_p(_raw_stream(_cur_device()))
 
 
 def _require_cuda(t):
@@ -448,7 +453,7 @@ _x3_ws = {}
 
 def _x3_workspace(device):
     """scratch for the stream-K schedule of dass_conv2d_x3 (one per device and stream: launches on one stream are ordered)"""
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    key = (device, _raw_stream(device.index if device.index is not None else _cur_device()))
     ws = _x3_ws.get(key)
     if ws is None:
         ws = _x3_ws[key] = torch.empty((lib.dass_conv2d_x3_workspace_bytes(),), dtype=torch.uint8, device=device)
