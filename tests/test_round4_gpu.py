@@ -295,7 +295,9 @@ def test_graphed_train_step_follows_the_eager_trajectory(engine):
             elif "running" in k and "bn_global_average_pool" not in k:
                 # (the ASPP image-pool BN -- 4 samples per channel -- amplifies the reordered f32 atomics of the weight gradients ~1e3 and is
                 #  left out; bf16 products amplify them everywhere else too)
-                tol = 1e-2 if engine == "f16x3" else 5e-2
+                # (129^2 crops: the 9x9 ASPP maps hold 324 samples per channel, and a variance over so few moves by a few 1e-2 between two
+                #  runs of the SAME eager step already -- the weight gradients' f32 atomics land in a different order each run)
+                tol = 5e-2
                 assert (sa[k] - sb[k]).abs().max().item() <= tol * max(1.0, sa[k].abs().max().item()), k
         dl = (runs["eager"][2] - runs["graph"][2]).abs().max().item() / runs["eager"][2].abs().max().item()
         assert dl <= (2e-2 if engine == "f16x3" else 1e-1), dl          # eval after the replays runs on the updated weights (stale operand caches would be off by a step)
