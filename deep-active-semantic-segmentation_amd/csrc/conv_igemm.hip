@@ -1575,6 +1575,11 @@ extern "C" int dass_conv2d_rowtap(const void *x, const void *w, void *y, int64_t
         return DASS_ERR_ARG;
     if (dtype != DASS_F32) return DASS_ERR_UNSUPPORTED;
     if (R > 64 || S * Cin > 32 || stride < 1 || (long)N * OH * OW >= (1l << 31)) return DASS_ERR_ARG;
+    {   // the stems of the three backbones: exact f32 MFMAs, one predicated load per window value (stem_rowtap.hip)
+        const int fast = dass_rowtap_fwd_fast((const float *)x, (const float *)w, (float *)y, (long)ldy, N, H, W, Cin, OH, OW, K, R, S, stride, pad,
+                                              (hipStream_t)stream);
+        if (fast) return fast > 0 ? DASS_OK : DASS_ERR_LAUNCH;
+    }
     ConvP p;
     p.x = (const char *)x; p.w = (const char *)w; p.y = (char *)y;
     p.scale = nullptr; p.shift = nullptr; p.res = nullptr; p.in_scale = nullptr; p.stat_partial = nullptr; p.stat_sums = nullptr;
@@ -1600,6 +1605,10 @@ extern "C" int dass_conv2d_rowtap_wgrad(const void *x, const void *dy, int64_t l
     if (S * Cin > 64 || K % 4 != 0 || lddy % 4 != 0 || (long)N * OH * OW >= (1l << 31)) return DASS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * R * S * Cin, st) != hipSuccess) return DASS_ERR_LAUNCH;
+    {   // whole K x (R S Cin) gradient per wave, dy streamed once (stem_rowtap.hip)
+        const int fast = dass_rowtap_wgrad_fast((const float *)x, (const float *)dy, (long)lddy, dw, N, H, W, Cin, OH, OW, K, R, S, stride, pad, st);
+        if (fast) return fast > 0 ? DASS_OK : DASS_ERR_LAUNCH;
+    }
     WgradP p;
     p.x = (const char *)x; p.dy = (const char *)dy; p.dw = dw;
     p.ldx = Cin; p.lddy = lddy;

@@ -31,6 +31,12 @@ void dass_prof_slot(const void *fn, long long grid, hipStream_t st, hipEvent_t *
         if (hipGetLastError() != hipSuccess) return DASS_ERR_LAUNCH; \
     } while (0)
 
+// csrc/stem_rowtap.hip: the stems' f32-MFMA kernels.  1 = launched, 0 = shape outside the specialisation, < 0 = launch error
+int dass_rowtap_fwd_fast(const float *x, const float *w, float *y, long ldy, int N, int H, int W, int Cin, int OH, int OW, int K, int R, int S,
+                         int stride, int pad, hipStream_t st);
+int dass_rowtap_wgrad_fast(const float *x, const float *dy, long lddy, float *dw, int N, int H, int W, int Cin, int OH, int OW, int K, int R,
+                           int S, int stride, int pad, hipStream_t st);
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     // round-to-nearest-even via the hardware convert (keeps NaN a NaN, see MI355X_MICROARCH hazards table)
