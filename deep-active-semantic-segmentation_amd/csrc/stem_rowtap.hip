@@ -296,7 +296,8 @@ int dass_rowtap_fwd_fast(const float *x, const float *w, float *y, long ldy, int
 int dass_rowtap_wgrad_fast(const float *x, const float *dy, long lddy, float *dw, int N, int H, int W, int Cin, int OH, int OW, int K, int R, int S,
                            int stride, int pad, hipStream_t st) {
     const int L = R * S * Cin;
-    if (!fast_enabled() || !((K == 64 && L <= 160) || (K == 32 && L <= 32))) return 0;
+    // (dass_set_deterministic(1): the generic kernel with ONE pixel split -- this kernel's workgroups meet in atomics)
+    if (!fast_enabled() || dass_get_deterministic() || !((K == 64 && L <= 160) || (K == 32 && L <= 32))) return 0;
     RowtapP p{};
     if (!fill(p, N, H, W, Cin, OH, OW, K, R, S, stride, pad)) return 0;
     p.x = x; p.dy = dy; p.dw = dw; p.ldy = lddy;

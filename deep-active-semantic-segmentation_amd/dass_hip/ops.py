@@ -787,6 +787,8 @@ def _split6_registered(weight, master, mode, cdst, fmt=F32X6):
         dead = [kk for kk, e in _split_reg["entries"].items() if e.weight() is None]
         for kk in dead:  # parameters that no longer exist: release their operands
             del _split_reg["entries"][kk]
+        # (tried in round 4 and dropped: refreshing the input-gradient operands (mode 1) on the side stream beside the forward pass --
+        #  0.3 of the 0.6 ms this refresh costs at the head of a step -- left the train step where it was and cost the MC-dropout leg 20 %)
         stale = []
         for e in _split_reg["entries"].values():
             wt = e.weight()
@@ -803,12 +805,8 @@ def _split6_registered(weight, master, mode, cdst, fmt=F32X6):
             _split_reg["table"][fmt] = (torch.tensor(rows_, dtype=torch.int64).to(weight.device), torch.tensor(start, dtype=torch.int64).to(weight.device), acc)
             _split_reg["table_key"][fmt] = key
         desc, start_t, total = _split_reg["table"][fmt]
-        if fmt == F16X3:
-            check(lib.dass_weight_split_batch_f16(_p(desc), _p(start_t), len(stale), total, _stream()), "dass_weight_split_batch_f16")
-        elif fmt == BF16X1:
-            check(lib.dass_weight_split_batch_bf16(_p(desc), _p(start_t), len(stale), total, _stream()), "dass_weight_split_batch_bf16")
-        else:
-            check(lib.dass_weight_split_batch(_p(desc), _p(start_t), len(stale), total, _stream()), "dass_weight_split_batch")
+        fn = {F16X3: lib.dass_weight_split_batch_f16, BF16X1: lib.dass_weight_split_batch_bf16}.get(fmt, lib.dass_weight_split_batch)
+        check(fn(_p(desc), _p(start_t), len(stale), total, _stream()), "dass_weight_split_batch")
         for e, wt in stale:
             e.version = (wt._version, _wepoch["n"])
     return ent.op
@@ -1406,6 +1404,8 @@ def _wgrad_enqueue(weight, x3, dy3, dwk, dims, k, c_in):
         # hooks for it -- and arm the callback again for this pass
         _wg["task"] = task
         _wg["queue"], _wg["inflight"], _wg["pending"], _wg["armed"] = [], [], set(), False
+    # (tried in round 4 and dropped: one more flush when only a few layers are left, so that less of the last chunk trails the pass --
+    #  the 0.5 ms tail moved under the end of backward and slowed that by as much: the chip is busy either way, tools/step_timeline.py)
     if _wg["chunk"] and len(_wg["queue"]) >= _wg["chunk"]:
         # the layers already queued have returned from their backward, and autograd has run their (empty-handed) AccumulateGrad
         # nodes -- those have the highest priority in the engine's ready queue -- so their hooks may fire for real now

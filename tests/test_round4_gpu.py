@@ -255,7 +255,7 @@ def test_graphed_train_step_follows_the_eager_trajectory(engine):
         xd, ld = x.cuda(), lab.cuda()
         crit = SegmentationLosses(cuda=True).build_loss("ce")
         runs = {}
-        for mode in ("eager", "graph"):
+        for mode in ("eager", "eager2", "graph"):
             pm = DeepLab(backbone="resnet", output_stride=16, num_classes=19, sync_bn=False, pretrained=False)
             pm.load_state_dict(om.state_dict())
             pm = pm.cuda().train()
@@ -273,7 +273,7 @@ def test_graphed_train_step_follows_the_eager_trajectory(engine):
                 return loss
 
             losses = []
-            if mode == "eager":
+            if mode != "graph":
                 for _ in range(6):
                     losses.append(float(step().detach()))
             else:
@@ -299,7 +299,15 @@ def test_graphed_train_step_follows_the_eager_trajectory(engine):
                 #  runs of the SAME eager step already -- the weight gradients' f32 atomics land in a different order each run)
                 tol = 5e-2
                 assert (sa[k] - sb[k]).abs().max().item() <= tol * max(1.0, sa[k].abs().max().item()), k
-        dl = (runs["eager"][2] - runs["graph"][2]).abs().max().item() / runs["eager"][2].abs().max().item()
-        assert dl <= (2e-2 if engine == "f16x3" else 1e-1), dl          # eval after the replays runs on the updated weights (stale operand caches would be off by a step)
+        # eval after the replays runs on the updated weights (stale operand caches would be off by a step).  The yardstick is what two
+        # runs of the SAME eager loop differ by after six steps (f32 atomics of the weight gradients in a different order each run)
+        # (RMS over all logits: the maximum is set by a handful of near-tie pixels of the 129^2 crops and moves by 2-4x between runs)
+        ref = runs["eager"][2]
+        rms = lambda t: float(t.double().pow(2).mean().sqrt())
+        dl = rms(ref - runs["graph"][2]) / rms(ref)
+        noise = rms(ref - runs["eager2"][2]) / rms(ref)
+        dmax = (ref - runs["graph"][2]).abs().max().item() / ref.abs().max().item()
+        print(engine, "eval logits: graph vs eager rms %.3e (max %.3e), eager vs eager rms %.3e" % (dl, dmax, noise))
+        assert dl <= max(1e-2 if engine == "f16x3" else 5e-2, 4 * noise), (dl, noise)
     finally:
         ops.set_f32_mma(keep)
