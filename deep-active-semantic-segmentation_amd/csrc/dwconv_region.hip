@@ -228,6 +228,212 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const T *__restrict_
     }
 }
 
+// Strip form of the depthwise forward and (stride 1) input-gradient passes, f32: out[row][o] = sum over taps of w[tap] * in[row * S - pad
+// + r * D][o * S - pad + s * D].  Same walk as the weight-gradient strip kernel below: a thread owns 4 channels (their 36 weights in
+// registers, per tap one 4-channel vector) and 16 consecutive outputs of one row with the 3 x (2 D + 1) input window in registers -- S new
+// columns per output instead of 9 loads behind 9 branches (dw_fwd_cg_kernel ran at 2.3 TB/s, the input gradient at 1.5).  The input
+// gradient of a stride-1 conv is this form over dy with pad' = 2 D - pad and the taps flipped (FLIP); the products are added in the
+// ORIGINAL tap order either way, so results equal the kernels above bit for bit (an invalid tap adds +0 instead of nothing).
+template <int DIL, int STRIDE, bool FLIP>
+__global__ __launch_bounds__(256) void dw_conv_strip_kernel(const float *__restrict__ in, int ldi, const float *__restrict__ w,
+                                                            float *__restrict__ out, int ldo, int IH, int IW, int C, int OH, int OW,
+                                                            int pad, int nsegw, int nstrips) {
+    constexpr int SEG = 16, WW = 2 * DIL + 1, KEEP = WW - STRIDE, PF = 3;
+    const int cq = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cq * 4;
+    if (c >= C) return;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 wv[9];  // wv[tap] = the tap's weight of the 4 channels
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wv[t][e] = w[(long)(c + e) * 9 + t];
+    for (int strip = blockIdx.y * 16 + pl; strip < nstrips; strip += gridDim.y * 16) {
+        const int row = strip / nsegw, sg = strip - row * nsegw;
+        const int n = row / OH, oh = row - n * OH;
+        const int o0 = sg * SEG, ix0 = o0 * STRIDE - pad;
+        const float *xr[3];
+        bool rok[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int iy = oh * STRIDE - pad + r * DIL;
+            rok[r] = (unsigned)iy < (unsigned)IH;
+            xr[r] = in + ((n * IH + (rok[r] ? iy : 0)) * IW) * ldi + c;
+        }
+        float *op = out + (row * OW + o0) * ldo + c;
+        f32x4 win[3][WW];
+#pragma unroll
+        for (int j = 0; j < KEEP; ++j) {
+            const int ix = ix0 + j;
+            const bool cok = (unsigned)ix < (unsigned)IW;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(xr[r] + ((rok[r] & cok) ? ix : 0) * ldi);
+                win[r][j] = (rok[r] & cok) ? v : zero;
+            }
+        }
+        f32x4 nc[PF][STRIDE][3];
+        auto issue = [&](int i, int slot) {  // raw loads from clamped addresses; invalid taps are zeroed where the value is used
+#pragma unroll
+            for (int j = 0; j < STRIDE; ++j) {
+                const int ix = ix0 + i * STRIDE + KEEP + j;
+                const bool cok = (unsigned)ix < (unsigned)IW;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) nc[slot][j][r] = *reinterpret_cast<const f32x4 *>(xr[r] + ((rok[r] & cok) ? ix : 0) * ldi);
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < PF; ++i) issue(i, i);
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) {
+            const int slot = i % PF;
+#pragma unroll
+            for (int j = 0; j < STRIDE; ++j) {
+                const bool cok = (unsigned)(ix0 + i * STRIDE + KEEP + j) < (unsigned)IW;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) win[r][KEEP + j] = (rok[r] & cok) ? nc[slot][j][r] : zero;
+            }
+            if (i + PF < SEG) issue(i + PF, slot);
+            f32x4 a = zero;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int s2 = 0; s2 < 3; ++s2) a += win[FLIP ? 2 - r : r][(FLIP ? 2 - s2 : s2) * DIL] * wv[r * 3 + s2];
+            if (o0 + i < OW) *reinterpret_cast<f32x4 *>(op + i * ldo) = a;
+#pragma unroll
+            for (int j = 0; j < KEEP; ++j)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) win[r][j] = win[r][j + STRIDE];
+        }
+    }
+}
+
+// 1: launched; 0: outside the specialisation
+template <bool FLIP>
+static int launch_dw_strip(const float *in, long ldi, const float *w, float *out, long ldo, int N, int IH, int IW, int C, int OH, int OW, int stride,
+                           int pad, int dil, hipStream_t st) {
+    const char *e = getenv("DASS_DW_STRIP");
+    if (e && e[0] == '0') return 0;
+    if (!(dil == 1 || dil == 2) || !(stride == 1 || stride == 2) || (FLIP && stride != 1)) return 0;
+    if ((long)N * IH * IW * ldi >= (1l << 31) || (long)N * OH * OW * ldo >= (1l << 31)) return 0;
+    const int cblocks = (C + 63) / 64, nsegw = (OW + 15) / 16;
+    const long nstrips = (long)N * OH * nsegw;
+    long gy = (2048 + cblocks - 1) / cblocks;
+    if (gy > (nstrips + 15) / 16) gy = (nstrips + 15) / 16;
+    const dim3 grid(cblocks, (unsigned)(gy < 1 ? 1 : gy));
+#define DASS_DW_CS(D, S)                                                                                                              \
+    DASS_LAUNCH((dw_conv_strip_kernel<D, S, FLIP>), grid, dim3(256), 0, st, in, (int)ldi, w, out, (int)ldo, IH, IW, C, OH, OW, pad, nsegw, \
+                (int)nstrips)
+    if (dil == 1 && stride == 1) DASS_DW_CS(1, 1);
+    else if (dil == 2 && stride == 1) DASS_DW_CS(2, 1);
+    else if constexpr (!FLIP) {
+        if (dil == 1) DASS_DW_CS(1, 2);
+        else DASS_DW_CS(2, 2);
+    }
+#undef DASS_DW_CS
+    return 1;
+}
+
+// Strip form of the depthwise weight gradient (f32, dilation 1 or 2, stride 1 or 2 -- every depthwise conv of MobileNetV2 and
+// Xception at os16, reference models/backbone/mobilenet.py:33-79).  A thread owns 4 channels and walks a strip of 16 consecutive
+// output pixels of ONE output row with the 3 x (2 dil + 1) input window of its channels in registers: a step loads `stride` new
+// input columns (3 rows) and one dy value instead of 9 + 1, and every address is a 32-bit add (the pixel-cursor kernel above spent
+// its time in 64-bit multiplies for 9 tap addresses per pixel: 0.8 TB/s of algorithmic traffic in profiles/r04_train_C_mbv2_summary.md).
+// Loads are unconditional from clamped addresses, invalid taps are selected to zero: no branches in the strip.
+template <int DIL, int STRIDE>
+__global__ __launch_bounds__(256) void dw_bwd_weight_strip_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ dy, int lddy,
+                                                                  float *__restrict__ dw, int H, int W, int C, int OH, int OW, int pad,
+                                                                  int nsegw, int nstrips) {
+    constexpr int SEG = 16, WW = 2 * DIL + 1, KEEP = WW - STRIDE;
+    static_assert(KEEP >= 1, "window");
+    __shared__ float red[16][9][64 + 4];
+    const int cq = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cq * 4;
+    f32x4 a[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) a[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        for (int strip = blockIdx.y * 16 + pl; strip < nstrips; strip += gridDim.y * 16) {
+            const int row = strip / nsegw, sg = strip - row * nsegw;  // (one division pair per 16 pixels)
+            const int n = row / OH, oh = row - n * OH;
+            const int ow0 = sg * SEG, ix0 = ow0 * STRIDE - pad;
+            const float *xr[3];
+            bool rok[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int iy = oh * STRIDE - pad + r * DIL;
+                rok[r] = (unsigned)iy < (unsigned)H;
+                xr[r] = x + ((n * H + (rok[r] ? iy : 0)) * W) * ldx + c;
+            }
+            const float *dyp = dy + (row * OW + ow0) * lddy + c;
+            auto ldcol = [&](int r, int ix) -> f32x4 {
+                const bool ok = rok[r] & ((unsigned)ix < (unsigned)W);
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(xr[r] + (ok ? ix : 0) * ldx);
+                return ok ? v : zero;
+            };
+            f32x4 win[3][WW];
+#pragma unroll
+            for (int j = 0; j < KEEP; ++j)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) win[r][j] = ldcol(r, ix0 + j);
+            // the loads of step i + PF are issued when step i has consumed its slot: PF steps of loads stay in flight (without the
+            // ring the compiler waits for every step's four loads right where it issued them: vmcnt(0) sixteen times per strip)
+            constexpr int PF = 3;
+            f32x4 nc[PF][STRIDE][3], ng[PF];
+            // (raw loads from clamped addresses here; the select-to-zero of invalid taps happens where the value is USED -- a select
+            //  next to its load makes the compiler wait for the load on the spot)
+            auto issue = [&](int i, int slot) {
+                const bool live = ow0 + i < OW;
+                ng[slot] = *reinterpret_cast<const f32x4 *>(dyp + (live ? i : 0) * lddy);
+#pragma unroll
+                for (int j = 0; j < STRIDE; ++j) {
+                    const int ix = ix0 + i * STRIDE + KEEP + j;
+                    const bool cok = (unsigned)ix < (unsigned)W;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) nc[slot][j][r] = *reinterpret_cast<const f32x4 *>(xr[r] + ((rok[r] & cok) ? ix : 0) * ldx);
+                }
+            };
+#pragma unroll
+            for (int i = 0; i < PF; ++i) issue(i, i);
+#pragma unroll
+            for (int i = 0; i < SEG; ++i) {
+                const int slot = i % PF;
+                const f32x4 g = (ow0 + i < OW) ? ng[slot] : zero;
+#pragma unroll
+                for (int j = 0; j < STRIDE; ++j) {
+                    const bool cok = (unsigned)(ix0 + i * STRIDE + KEEP + j) < (unsigned)W;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) win[r][KEEP + j] = (rok[r] & cok) ? nc[slot][j][r] : zero;
+                }
+                if (i + PF < SEG) issue(i + PF, slot);
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int s2 = 0; s2 < 3; ++s2) a[r * 3 + s2] += g * win[r][s2 * DIL];
+#pragma unroll
+                for (int j = 0; j < KEEP; ++j)
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) win[r][j] = win[r][j + STRIDE];
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[pl][t][cq * 4 + e] = a[t][e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * 64; i += 256) {
+        const int t = i >> 6, cl = i & 63;
+        const int cc = blockIdx.x * 64 + cl;
+        if (cc >= C) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v += red[q][t][cl];
+        atomicAdd(dw + (long)cc * 9 + t, v);
+    }
+}
+
 // ---------------------------------------------------------------------------------------- regions
 // horizontal then vertical running box sums (valid), f64 accumulators -> f32
 __global__ void box_rows_kernel(const float *__restrict__ in, float *__restrict__ tmp, int N, int H, int W, int r) {
@@ -473,6 +679,10 @@ extern "C" int dass_dwconv3x3_fwd(const void *x, int64_t ldx, const float *w, vo
     const dim3 grid((unsigned)(gx < 1024 ? gx : 1024), (unsigned)(rows_ < 8192 ? rows_ : 8192));  // (ow, channel group) x output rows
     hipStream_t st = (hipStream_t)stream;
     const int cv = C / 4;
+    if (dtype == DASS_F32 && launch_dw_strip<false>((const float *)x, ldx, w, (float *)y, ldy, N, H, W, C, OH, OW, stride, pad, dil, st)) {
+        DASS_LAUNCH_CHECK();
+        return DASS_OK;
+    }
     if (cv <= 256 && !((uintptr_t)w & 15) && (dtype == DASS_F32 || dtype == DASS_BF16)) {  // one channel group per thread, weights in registers
         const int ppb = 256 / cv;
         const dim3 g2((unsigned)((OW + ppb - 1) / ppb), grid.y), b2((unsigned)(ppb * cv));
@@ -504,6 +714,12 @@ extern "C" int dass_dwconv3x3_bwd_data(const void *dy, int64_t lddy, const float
     const dim3 grid((unsigned)(gx < 1024 ? gx : 1024), (unsigned)(rows_ < 8192 ? rows_ : 8192));  // (ix, channel group) x input rows
     hipStream_t st = (hipStream_t)stream;
     const int cv = C / 4;
+    // (stride 1: the input gradient is the forward form over dy with pad' = 2 dil - pad and flipped taps; output rows = the H x W of dx)
+    if (dtype == DASS_F32 && stride == 1 && 2 * dil - pad >= 0 &&
+        launch_dw_strip<true>((const float *)dy, lddy, w, (float *)dx, lddx, N, OH, OW, C, H, W, 1, 2 * dil - pad, dil, st)) {
+        DASS_LAUNCH_CHECK();
+        return DASS_OK;
+    }
     if (cv <= 256 && !((uintptr_t)w & 15) && (dtype == DASS_F32 || dtype == DASS_BF16)) {
         const int ppb = 256 / cv;
         const dim3 g2((unsigned)((W + ppb - 1) / ppb), grid.y), b2((unsigned)(ppb * cv));
@@ -541,6 +757,27 @@ extern "C" int dass_dwconv3x3_bwd_weight(const void *x, int64_t ldx, const void 
     const long ppb = (M + slabs - 1) / slabs;
     slabs = (M + ppb - 1) / ppb;
     dim3 grid(cblocks, (unsigned)slabs);
+    const bool strip_on = !(getenv("DASS_DW_WGRAD_STRIP") && getenv("DASS_DW_WGRAD_STRIP")[0] == '0');
+    if (dtype == DASS_F32 && strip_on && (dil == 1 || dil == 2) && (stride == 1 || stride == 2) && (long)N * H * W * ldx < (1l << 31) &&
+        M * lddy < (1l << 31)) {
+        // strips of 16 output pixels of one row; ~8 blocks per CU, every thread several strips
+        const int nsegw = (OW + 15) / 16;
+        const long nstrips = (long)N * OH * nsegw;
+        const long tgt = getenv("DASS_DW_GY") ? atol(getenv("DASS_DW_GY")) : 512;
+        long gy = (tgt + cblocks - 1) / cblocks;
+        if (gy > (nstrips + 15) / 16) gy = (nstrips + 15) / 16;
+        const dim3 g2(cblocks, (unsigned)(gy < 1 ? 1 : gy));
+#define DASS_DW_STRIP(D, S)                                                                                                              \
+    DASS_LAUNCH((dw_bwd_weight_strip_kernel<D, S>), g2, dim3(256), 0, st, (const float *)x, (int)ldx, (const float *)dy, (int)lddy, dw, H, W, \
+                C, OH, OW, pad, nsegw, (int)nstrips)
+        if (dil == 1 && stride == 1) DASS_DW_STRIP(1, 1);
+        else if (dil == 1) DASS_DW_STRIP(1, 2);
+        else if (stride == 1) DASS_DW_STRIP(2, 1);
+        else DASS_DW_STRIP(2, 2);
+#undef DASS_DW_STRIP
+        DASS_LAUNCH_CHECK();
+        return DASS_OK;
+    }
     if (dtype == DASS_F32)
         DASS_LAUNCH(dw_bwd_weight_kernel<float>, grid, dim3(256), 0, st, (const float *)x, ldx, (const float *)dy, lddy, dw, N, H, W, C, OH, OW, stride, pad, dil, ppb);
     else if (dtype == DASS_BF16)

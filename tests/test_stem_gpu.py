@@ -105,3 +105,107 @@ def test_stem_full_size_timing():
     ey = (out["1"][0] - out["0"][0]).abs().max().item() / out["0"][0].abs().max().item()
     ew = (out["1"][1] - out["0"][1]).abs().max().item() / out["0"][1].abs().max().item()
     assert ey <= 2e-4 and ew <= 2e-5, (ey, ew)
+
+
+DW_SHAPES = [  # n, h, w, c, stride, dil
+    (2, 33, 33, 96, 1, 1),
+    (2, 65, 47, 144, 2, 1),     # ragged channels (144 = 2.25 x 64), stride 2, output rows of 24 pixels (1.5 strips)
+    (3, 33, 33, 576, 1, 2),     # the dilated blocks of MobileNetV2 at os16
+    (1, 17, 19, 32, 2, 2),
+    (16, 129, 129, 144, 1, 1),  # config C size
+]
+
+
+@pytest.mark.parametrize("strip", ["1", "0"])
+@pytest.mark.parametrize("shape", DW_SHAPES)
+def test_depthwise_weight_gradient_strip_kernel_vs_f64(shape, strip):
+    """dass_dwconv3x3_bwd_weight: the strip kernel (window in registers, csrc/dwconv_region.hip) and the pixel-cursor kernel it replaces
+    (DASS_DW_WGRAD_STRIP=0) against an f64 convolution's weight gradient; f32 sums of up to 266 k terms: 2e-5 of the largest value"""
+    from dass_hip._lib import lib
+
+    n, h, w, c, stride, dil = shape
+    pad = dil
+    oh, ow = (h + 2 * pad - 2 * dil - 1) // stride + 1, (w + 2 * pad - 2 * dil - 1) // stride + 1
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, h, w, c, generator=g)
+    dy = torch.randn(n, oh, ow, c, generator=g)
+    xd, dyd = x.cuda(), dy.cuda()
+    dw = torch.full((c, 9), float("nan"), device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    keep = os.environ.get("DASS_DW_WGRAD_STRIP")
+    os.environ["DASS_DW_WGRAD_STRIP"] = strip
+    try:
+        t = []
+        for it in range(4):
+            if it == 1:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            assert lib.dass_dwconv3x3_bwd_weight(_p(xd), c, _p(dyd), c, _p(dw), n, h, w, c, oh, ow, stride, pad, dil, 0, st) == 0
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t0) / 3 * 1e6
+    finally:
+        if keep is None:
+            os.environ.pop("DASS_DW_WGRAD_STRIP", None)
+        else:
+            os.environ["DASS_DW_WGRAD_STRIP"] = keep
+    w64 = torch.zeros(c, 1, 3, 3, dtype=torch.float64, requires_grad=True)
+    y64 = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w64, stride=stride, padding=pad, dilation=dil, groups=c)
+    (y64 * dy.double().permute(0, 3, 1, 2)).sum().backward()
+    ref = w64.grad.reshape(c, 9)
+    err = (dw.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    gb = (x.numel() + dy.numel()) * 4 / 1e9
+    print(shape, "strip" if strip == "1" else "cursor", "err %.2e  %.0f us  %.2f TB/s" % (err, us, gb / us * 1e6 / 1e3))
+    assert err <= 2e-5
+
+
+@pytest.mark.parametrize("shape", DW_SHAPES + [(2, 33, 33, 64, 1, 1), (1, 9, 40, 1024, 1, 2)])
+def test_depthwise_forward_and_input_gradient_strip_kernels(shape):
+    """dass_dwconv3x3_fwd / dass_dwconv3x3_bwd_data: the strip kernels against an f64 convolution (1e-5 of the largest value) and
+    against the per-pixel kernels they replace (DASS_DW_STRIP=0): the products are added in the same order, so the bits are equal"""
+    from dass_hip._lib import lib
+
+    n, h, w, c, stride, dil = shape
+    pad = dil
+    oh, ow = (h + 2 * pad - 2 * dil - 1) // stride + 1, (w + 2 * pad - 2 * dil - 1) // stride + 1
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(n, h, w, c, generator=g)
+    wt = torch.randn(c, 9, generator=g)
+    dy = torch.randn(n, oh, ow, c, generator=g)
+    xd, wd, dyd = x.cuda(), wt.cuda(), dy.cuda()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    res = {}
+    keep = os.environ.get("DASS_DW_STRIP")
+    try:
+        for strip in ("1", "0"):
+            os.environ["DASS_DW_STRIP"] = strip
+            y = torch.full((n, oh, ow, c), float("nan"), device="cuda")
+            dx = torch.full((n, h, w, c), float("nan"), device="cuda")
+            us = []
+            for fn in ("fwd", "bwd"):
+                for it in range(4):
+                    if it == 1:
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                    if fn == "fwd":
+                        assert lib.dass_dwconv3x3_fwd(_p(xd), c, _p(wd), _p(y), c, n, h, w, c, oh, ow, stride, pad, dil, 0, st) == 0
+                    else:
+                        assert lib.dass_dwconv3x3_bwd_data(_p(dyd), c, _p(wd), _p(dx), c, n, h, w, c, oh, ow, stride, pad, dil, 0, st) == 0
+                torch.cuda.synchronize()
+                us.append((time.perf_counter() - t0) / 3 * 1e6)
+            res[strip] = (y.cpu(), dx.cpu(), us)
+    finally:
+        if keep is None:
+            os.environ.pop("DASS_DW_STRIP", None)
+        else:
+            os.environ["DASS_DW_STRIP"] = keep
+    x64 = x.double().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    y64 = torch.nn.functional.conv2d(x64, wt.double().reshape(c, 1, 3, 3), stride=stride, padding=pad, dilation=dil, groups=c)
+    (y64 * dy.double().permute(0, 3, 1, 2)).sum().backward()
+    ey = (res["1"][0].double().permute(0, 3, 1, 2) - y64.detach()).abs().max().item() / y64.abs().max().item()
+    ex = (res["1"][1].double().permute(0, 3, 1, 2) - x64.grad).abs().max().item() / x64.grad.abs().max().item()
+    gb = (x.numel() + dy.numel()) * 4 / 1e3
+    print(shape, "fwd %.1e (%.0f us, %.2f TB/s; per-pixel kernel %.0f us)  input gradient %.1e (%.0f us, %.2f TB/s; per-pixel %.0f us)" % (
+        ey, res["1"][2][0], gb / res["1"][2][0] / 1e3, res["0"][2][0], ex, res["1"][2][1], gb / res["1"][2][1] / 1e3, res["0"][2][1]))
+    assert ey <= 1e-5 and ex <= 1e-5
+    assert torch.equal(res["1"][0], res["0"][0])
+    assert torch.equal(res["1"][1], res["0"][1])
