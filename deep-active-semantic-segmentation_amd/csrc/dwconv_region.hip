@@ -234,15 +234,31 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const T *__restrict_
 // columns per output instead of 9 loads behind 9 branches (dw_fwd_cg_kernel ran at 2.3 TB/s, the input gradient at 1.5).  The input
 // gradient of a stride-1 conv is this form over dy with pad' = 2 D - pad and the taps flipped (FLIP); the products are added in the
 // ORIGINAL tap order either way, so results equal the kernels above bit for bit (an invalid tap adds +0 instead of nothing).
-template <int DIL, int STRIDE, bool FLIP>
+struct DwBnLink {  // BNS: the layer whose output this launch's result is the gradient of (dass_dwconv3x3_bwd_data_bnstats)
+    const float *y, *mean, *invstd, *gsc, *gsh;  // its conv output [rows][C] and per-channel mean / 1/std / gate scale / gate shift
+    double *sums;                                // [2][C] f64 (sum dz, sum dz xhat) + C floats (max |dz|)
+    int act;
+};
+
+template <int DIL, int STRIDE, bool FLIP, bool BNS>
 __global__ __launch_bounds__(256) void dw_conv_strip_kernel(const float *__restrict__ in, int ldi, const float *__restrict__ w,
                                                             float *__restrict__ out, int ldo, int IH, int IW, int C, int OH, int OW,
-                                                            int pad, int nsegw, int nstrips) {
-    constexpr int SEG = 16, WW = 2 * DIL + 1, KEEP = WW - STRIDE, PF = 3;
+                                                            int pad, int nsegw, int nstrips, int seg, const DwBnLink bl) {
+    constexpr int WW = 2 * DIL + 1, KEEP = WW - STRIDE, PF = 3;  // (seg: outputs per strip = ceil(OW / nsegw) <= 16, e.g. 3 x 11 at OW = 33)
     const int cq = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int c = blockIdx.x * 64 + cq * 4;
-    if (c >= C) return;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bs0 = zero, bs1 = zero, bsm = zero;  // BNS: this thread's share of sum dz, sum dz xhat, max |dz| of its 4 channels
+    if (c < C) {
+    f32x4 mu = zero, is = zero, gsc = zero, gsh = zero;
+    if constexpr (BNS) {
+        mu = *reinterpret_cast<const f32x4 *>(bl.mean + c);
+        is = *reinterpret_cast<const f32x4 *>(bl.invstd + c);
+        if (bl.act != DASS_ACT_NONE) {
+            gsc = *reinterpret_cast<const f32x4 *>(bl.gsc + c);
+            gsh = *reinterpret_cast<const f32x4 *>(bl.gsh + c);
+        }
+    }
     f32x4 wv[9];  // wv[tap] = the tap's weight of the 4 channels
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -251,7 +267,8 @@ __global__ __launch_bounds__(256) void dw_conv_strip_kernel(const float *__restr
     for (int strip = blockIdx.y * 16 + pl; strip < nstrips; strip += gridDim.y * 16) {
         const int row = strip / nsegw, sg = strip - row * nsegw;
         const int n = row / OH, oh = row - n * OH;
-        const int o0 = sg * SEG, ix0 = o0 * STRIDE - pad;
+        const int o0 = sg * seg, ix0 = o0 * STRIDE - pad;
+        const int o_end = o0 + seg < OW ? o0 + seg : OW;
         const float *xr[3];
         bool rok[3];
 #pragma unroll
@@ -261,6 +278,7 @@ __global__ __launch_bounds__(256) void dw_conv_strip_kernel(const float *__restr
             xr[r] = in + ((n * IH + (rok[r] ? iy : 0)) * IW) * ldi + c;
         }
         float *op = out + (row * OW + o0) * ldo + c;
+        const float *yp = BNS ? bl.y + (row * OW + o0) * C + c : nullptr;
         f32x4 win[3][WW];
 #pragma unroll
         for (int j = 0; j < KEEP; ++j) {
@@ -272,8 +290,9 @@ __global__ __launch_bounds__(256) void dw_conv_strip_kernel(const float *__restr
                 win[r][j] = (rok[r] & cok) ? v : zero;
             }
         }
-        f32x4 nc[PF][STRIDE][3];
+        f32x4 nc[PF][STRIDE][3], ny[BNS ? PF : 1];
         auto issue = [&](int i, int slot) {  // raw loads from clamped addresses; invalid taps are zeroed where the value is used
+            if constexpr (BNS) ny[slot] = *reinterpret_cast<const f32x4 *>(yp + (o0 + i < o_end ? i : 0) * C);
 #pragma unroll
             for (int j = 0; j < STRIDE; ++j) {
                 const int ix = ix0 + i * STRIDE + KEEP + j;
@@ -284,46 +303,92 @@ __global__ __launch_bounds__(256) void dw_conv_strip_kernel(const float *__restr
         };
 #pragma unroll
         for (int i = 0; i < PF; ++i) issue(i, i);
+        for (int i0 = 0; i0 < seg; i0 += PF) {
 #pragma unroll
-        for (int i = 0; i < SEG; ++i) {
-            const int slot = i % PF;
+            for (int u = 0; u < PF; ++u) {  // (slot u: the ring index stays a compile-time constant)
+                const int i = i0 + u;
 #pragma unroll
-            for (int j = 0; j < STRIDE; ++j) {
-                const bool cok = (unsigned)(ix0 + i * STRIDE + KEEP + j) < (unsigned)IW;
+                for (int j = 0; j < STRIDE; ++j) {
+                    const bool cok = (unsigned)(ix0 + i * STRIDE + KEEP + j) < (unsigned)IW;
 #pragma unroll
-                for (int r = 0; r < 3; ++r) win[r][KEEP + j] = (rok[r] & cok) ? nc[slot][j][r] : zero;
+                    for (int r = 0; r < 3; ++r) win[r][KEEP + j] = (rok[r] & cok) ? nc[u][j][r] : zero;
+                }
+                f32x4 yl = zero;
+                if constexpr (BNS) yl = ny[u];  // (before the slot is re-issued)
+                issue(i + PF, u);  // (past the strip: clamped addresses, values never used)
+                f32x4 a = zero;
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int s2 = 0; s2 < 3; ++s2) a += win[FLIP ? 2 - r : r][(FLIP ? 2 - s2 : s2) * DIL] * wv[r * 3 + s2];
+                if (o0 + i < o_end) *reinterpret_cast<f32x4 *>(op + i * ldo) = a;
+                if constexpr (BNS) {
+                    // dz = dx * act'(out) with out re-derived from the layer's conv output by the forward's own fma (bn_affine), xhat = (y - mean) / std
+                    f32x4 gz = (o0 + i < o_end) ? a : zero;
+                    if (bl.act != DASS_ACT_NONE) {
+                        const f32x4 o = bn_affine(yl, gsc, gsh);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) gz[e] *= act_grad_from_out(o[e], bl.act);
+                    }
+                    bs0 += gz;
+                    bs1 += gz * ((yl - mu) * is);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bsm[e] = fmaxf(bsm[e], fabsf(gz[e]));
+                }
+#pragma unroll
+                for (int j = 0; j < KEEP; ++j)
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) win[r][j] = win[r][j + STRIDE];
             }
-            if (i + PF < SEG) issue(i + PF, slot);
-            f32x4 a = zero;
+        }
+    }
+    }  // c < C
+    if constexpr (BNS) {
+        // the 16 strip lanes of a channel group fold through LDS, then one f64 atomic per channel and workgroup (as the conv kernels do)
+        __shared__ float red[3][16][64 + 4];
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
+        for (int e = 0; e < 4; ++e) {
+            red[0][pl][cq * 4 + e] = bs0[e];
+            red[1][pl][cq * 4 + e] = bs1[e];
+            red[2][pl][cq * 4 + e] = bsm[e];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 3 * 64; i += 256) {
+            const int which = i >> 6, cl = i & 63, cc = blockIdx.x * 64 + cl;
+            if (cc >= C) continue;
+            if (which < 2) {
+                float v = 0.f;
 #pragma unroll
-                for (int s2 = 0; s2 < 3; ++s2) a += win[FLIP ? 2 - r : r][(FLIP ? 2 - s2 : s2) * DIL] * wv[r * 3 + s2];
-            if (o0 + i < OW) *reinterpret_cast<f32x4 *>(op + i * ldo) = a;
+                for (int q = 0; q < 16; ++q) v += red[which][q][cl];
+                unsafeAtomicAdd(bl.sums + (long)which * C + cc, (double)v);
+            } else {
+                float v = 0.f;
 #pragma unroll
-            for (int j = 0; j < KEEP; ++j)
-#pragma unroll
-                for (int r = 0; r < 3; ++r) win[r][j] = win[r][j + STRIDE];
+                for (int q = 0; q < 16; ++q) v = fmaxf(v, red[2][q][cl]);
+                if (!(v >= 0.f)) v = __uint_as_float(0x7f800000u);  // NaN: an infinite bound
+                unsigned *slot = reinterpret_cast<unsigned *>(bl.sums + 2 * (long)C) + cc;
+                if (__float_as_uint(v) > *reinterpret_cast<volatile unsigned *>(slot)) atomicMax(slot, __float_as_uint(v));
+            }
         }
     }
 }
 
 // 1: launched; 0: outside the specialisation
-template <bool FLIP>
+template <bool FLIP, bool BNS = false>
 static int launch_dw_strip(const float *in, long ldi, const float *w, float *out, long ldo, int N, int IH, int IW, int C, int OH, int OW, int stride,
-                           int pad, int dil, hipStream_t st) {
+                           int pad, int dil, hipStream_t st, const DwBnLink bl = DwBnLink{}) {
     const char *e = getenv("DASS_DW_STRIP");
     if (e && e[0] == '0') return 0;
     if (!(dil == 1 || dil == 2) || !(stride == 1 || stride == 2) || (FLIP && stride != 1)) return 0;
     if ((long)N * IH * IW * ldi >= (1l << 31) || (long)N * OH * OW * ldo >= (1l << 31)) return 0;
-    const int cblocks = (C + 63) / 64, nsegw = (OW + 15) / 16;
+    const int cblocks = (C + 63) / 64, nsegw = (OW + 15) / 16, seg = (OW + nsegw - 1) / nsegw;
     const long nstrips = (long)N * OH * nsegw;
     long gy = (2048 + cblocks - 1) / cblocks;
     if (gy > (nstrips + 15) / 16) gy = (nstrips + 15) / 16;
     const dim3 grid(cblocks, (unsigned)(gy < 1 ? 1 : gy));
-#define DASS_DW_CS(D, S)                                                                                                              \
-    DASS_LAUNCH((dw_conv_strip_kernel<D, S, FLIP>), grid, dim3(256), 0, st, in, (int)ldi, w, out, (int)ldo, IH, IW, C, OH, OW, pad, nsegw, \
-                (int)nstrips)
+#define DASS_DW_CS(D, S)                                                                                                                   \
+    DASS_LAUNCH((dw_conv_strip_kernel<D, S, FLIP, BNS>), grid, dim3(256), 0, st, in, (int)ldi, w, out, (int)ldo, IH, IW, C, OH, OW, pad, nsegw, \
+                (int)nstrips, seg, bl)
     if (dil == 1 && stride == 1) DASS_DW_CS(1, 1);
     else if (dil == 2 && stride == 1) DASS_DW_CS(2, 1);
     else if constexpr (!FLIP) {
@@ -343,8 +408,8 @@ static int launch_dw_strip(const float *in, long ldi, const float *w, float *out
 template <int DIL, int STRIDE>
 __global__ __launch_bounds__(256) void dw_bwd_weight_strip_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ dy, int lddy,
                                                                   float *__restrict__ dw, int H, int W, int C, int OH, int OW, int pad,
-                                                                  int nsegw, int nstrips) {
-    constexpr int SEG = 16, WW = 2 * DIL + 1, KEEP = WW - STRIDE;
+                                                                  int nsegw, int nstrips, int seg) {
+    constexpr int WW = 2 * DIL + 1, KEEP = WW - STRIDE;  // (seg: outputs per strip = ceil(OW / nsegw) <= 16)
     static_assert(KEEP >= 1, "window");
     __shared__ float red[16][9][64 + 4];
     const int cq = threadIdx.x & 15, pl = threadIdx.x >> 4;
@@ -357,7 +422,8 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_strip_kernel(const float *_
         for (int strip = blockIdx.y * 16 + pl; strip < nstrips; strip += gridDim.y * 16) {
             const int row = strip / nsegw, sg = strip - row * nsegw;  // (one division pair per 16 pixels)
             const int n = row / OH, oh = row - n * OH;
-            const int ow0 = sg * SEG, ix0 = ow0 * STRIDE - pad;
+            const int ow0 = sg * seg, ix0 = ow0 * STRIDE - pad;
+            const int o_end = ow0 + seg < OW ? ow0 + seg : OW;
             const float *xr[3];
             bool rok[3];
 #pragma unroll
@@ -384,7 +450,7 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_strip_kernel(const float *_
             // (raw loads from clamped addresses here; the select-to-zero of invalid taps happens where the value is USED -- a select
             //  next to its load makes the compiler wait for the load on the spot)
             auto issue = [&](int i, int slot) {
-                const bool live = ow0 + i < OW;
+                const bool live = ow0 + i < o_end;
                 ng[slot] = *reinterpret_cast<const f32x4 *>(dyp + (live ? i : 0) * lddy);
 #pragma unroll
                 for (int j = 0; j < STRIDE; ++j) {
@@ -396,25 +462,27 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_strip_kernel(const float *_
             };
 #pragma unroll
             for (int i = 0; i < PF; ++i) issue(i, i);
+            for (int i0 = 0; i0 < seg; i0 += PF) {
 #pragma unroll
-            for (int i = 0; i < SEG; ++i) {
-                const int slot = i % PF;
-                const f32x4 g = (ow0 + i < OW) ? ng[slot] : zero;
+                for (int u = 0; u < PF; ++u) {  // (slot u: the ring index stays a compile-time constant)
+                    const int i = i0 + u;
+                    const f32x4 g = (ow0 + i < o_end) ? ng[u] : zero;
 #pragma unroll
-                for (int j = 0; j < STRIDE; ++j) {
-                    const bool cok = (unsigned)(ix0 + i * STRIDE + KEEP + j) < (unsigned)W;
+                    for (int j = 0; j < STRIDE; ++j) {
+                        const bool cok = (unsigned)(ix0 + i * STRIDE + KEEP + j) < (unsigned)W;
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) win[r][KEEP + j] = (rok[r] & cok) ? nc[slot][j][r] : zero;
+                        for (int r = 0; r < 3; ++r) win[r][KEEP + j] = (rok[r] & cok) ? nc[u][j][r] : zero;
+                    }
+                    issue(i + PF, u);  // (past the strip: clamped addresses, values never used)
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int s2 = 0; s2 < 3; ++s2) a[r * 3 + s2] += g * win[r][s2 * DIL];
+#pragma unroll
+                    for (int j = 0; j < KEEP; ++j)
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) win[r][j] = win[r][j + STRIDE];
                 }
-                if (i + PF < SEG) issue(i + PF, slot);
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int s2 = 0; s2 < 3; ++s2) a[r * 3 + s2] += g * win[r][s2 * DIL];
-#pragma unroll
-                for (int j = 0; j < KEEP; ++j)
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) win[r][j] = win[r][j + STRIDE];
             }
         }
     }
@@ -740,6 +808,26 @@ extern "C" int dass_dwconv3x3_bwd_data(const void *dy, int64_t lddy, const float
     return DASS_OK;
 }
 
+/* dass_dwconv3x3_bwd_data whose result dx [N*H*W][C] IS the gradient d_out of the conv + BN (+ act) layer that produced the depthwise
+ * conv's input (MobileNetV2: the expand 1x1 of an inverted-residual block, models/backbone/mobilenet.py:52-58): the launch also adds that
+ * layer's BN-backward sums into bn_sums ([2][C] f64 + C floats, zeroed by the caller), as dass_conv2d_x3_dgrad_bnstats does for dense convs.
+ * f32, stride 1, dilation 1 or 2, lddx == C; DASS_ERR_UNSUPPORTED otherwise (the caller runs the two passes). */
+extern "C" int dass_dwconv3x3_bwd_data_bnstats(const void *dy, int64_t lddy, const float *w, void *dx, int64_t lddx, int N, int H, int W, int C,
+                                               int OH, int OW, int stride, int pad, int dil, const float *bn_y, const float *bn_mean,
+                                               const float *bn_invstd, const float *gate_scale, const float *gate_shift, int bn_act,
+                                               double *bn_sums, void *stream) {
+    const void *x_ = dy;
+    const void *y_ = dx;
+    if (!DW_ARGS_OK || !w || lddx % 4 || lddy % 4 || !bn_y || !bn_mean || !bn_invstd || !bn_sums) return DASS_ERR_ARG;
+    if (bn_act != DASS_ACT_NONE && (!gate_scale || !gate_shift)) return DASS_ERR_ARG;
+    if (stride != 1 || 2 * dil - pad < 0 || lddx != C) return DASS_ERR_UNSUPPORTED;
+    DwBnLink bl{bn_y, bn_mean, bn_invstd, gate_scale, gate_shift, bn_sums, bn_act};
+    if (!launch_dw_strip<true, true>((const float *)dy, lddy, w, (float *)dx, lddx, N, OH, OW, C, H, W, 1, 2 * dil - pad, dil, (hipStream_t)stream, bl))
+        return DASS_ERR_UNSUPPORTED;
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
 extern "C" int dass_dwconv3x3_bwd_weight(const void *x, int64_t ldx, const void *dy, int64_t lddy, float *dw, int N,
                                          int H, int W, int C, int OH, int OW, int stride, int pad, int dil, int dtype,
                                          void *stream) {
@@ -761,7 +849,7 @@ extern "C" int dass_dwconv3x3_bwd_weight(const void *x, int64_t ldx, const void 
     if (dtype == DASS_F32 && strip_on && (dil == 1 || dil == 2) && (stride == 1 || stride == 2) && (long)N * H * W * ldx < (1l << 31) &&
         M * lddy < (1l << 31)) {
         // strips of 16 output pixels of one row; ~8 blocks per CU, every thread several strips
-        const int nsegw = (OW + 15) / 16;
+        const int nsegw = (OW + 15) / 16, seg = (OW + nsegw - 1) / nsegw;
         const long nstrips = (long)N * OH * nsegw;
         const long tgt = getenv("DASS_DW_GY") ? atol(getenv("DASS_DW_GY")) : 512;
         long gy = (tgt + cblocks - 1) / cblocks;
@@ -769,7 +857,7 @@ extern "C" int dass_dwconv3x3_bwd_weight(const void *x, int64_t ldx, const void 
         const dim3 g2(cblocks, (unsigned)(gy < 1 ? 1 : gy));
 #define DASS_DW_STRIP(D, S)                                                                                                              \
     DASS_LAUNCH((dw_bwd_weight_strip_kernel<D, S>), g2, dim3(256), 0, st, (const float *)x, (int)ldx, (const float *)dy, (int)lddy, dw, H, W, \
-                C, OH, OW, pad, nsegw, (int)nstrips)
+                C, OH, OW, pad, nsegw, (int)nstrips, seg)
         if (dil == 1 && stride == 1) DASS_DW_STRIP(1, 1);
         else if (dil == 1) DASS_DW_STRIP(1, 2);
         else if (stride == 1) DASS_DW_STRIP(2, 1);

@@ -316,6 +316,7 @@ class BnBwdLink:
         self.dx = None
 
 
+_DW_BN_LINK = os.environ.get("DASS_DW_BN_LINK", "1") == "1"  # ... also in a depthwise conv's input-gradient launch (MobileNetV2 expand layers)
 _BN_LINK = os.environ.get("DASS_BN_LINK", "1") == "1"  # BN-backward sums ride in the epilogue of the next layer's input-gradient launch
 bn_link_counts = {"asked": 0, "fused": 0, "used": 0}    # launches asked to carry sums / that did / sums a layer's backward took over
 
@@ -323,6 +324,11 @@ bn_link_counts = {"asked": 0, "fused": 0, "used": 0}    # launches asked to carr
 def set_bn_link(on):
     global _BN_LINK
     _BN_LINK = bool(on)
+
+
+def set_dw_bn_link(on):
+    global _DW_BN_LINK
+    _DW_BN_LINK = bool(on)
 
 
 def conv_x3_dgrad_bnstats(dy3, w_t, dx, dims, link, residual=None, ldr=0):
@@ -1100,9 +1106,11 @@ class _ConvBnAct(torch.autograd.Function):
                     in_link = None
                 else:
                     in_link.claimed = True
-                    if (spec.depthwise or image_input or spec.stride != 1 or in_link.k != c or in_link.m != n * h * w or c != c_in
+                    if (image_input or spec.stride != 1 or in_link.k != c or in_link.m != n * h * w or c != c_in
                             or getattr(spec, "rowtap", False)):
                         in_link = None
+                    elif spec.depthwise and (not _DW_BN_LINK or dt != torch.float32 or spec.dil not in (1, 2) or in_link.gates is not None):
+                        in_link = None  # (the depthwise input-gradient kernel carries the sums at stride 1, dilation 1 / 2, gate from y_raw)
         if need_grad:
             ctx.in_link = in_link
             ctx.spec = spec
@@ -1259,8 +1267,25 @@ class _ConvBnAct(torch.autograd.Function):
             wdw = _dw_weight(weight)
             if ctx.needs_input_grad[0]:
                 dx = new_act(n, c, h, w, dt, dev)
-                check(lib.dass_dwconv3x3_bwd_data(_p(dy), lddy, _p(wdw), _p(dx), c, n, h, w, c, oh, ow, spec.stride,
-                                                  spec.pad, spec.dil, _dt(dx), _stream()), "dass_dwconv3x3_bwd_data")
+                link = getattr(ctx, "in_link", None)
+                fused = False
+                if link is not None and not link.dead and d_fork is None and ctx.x_dtype == dx.dtype and lddy % 4 == 0:
+                    # dx is the d_out of the layer that produced this conv's input (MobileNetV2: the expand 1x1 + BN + ReLU6): its
+                    # BN-backward sums ride in this launch (no separate dass_bn_bwd_reduce_sums pass over dx and that layer's conv output)
+                    sums = _bn_sums(c, dev)
+                    rc = lib.dass_dwconv3x3_bwd_data_bnstats(_p(dy), lddy, _p(wdw), _p(dx), c, n, h, w, c, oh, ow, spec.stride, spec.pad, spec.dil,
+                                                             _p(link.y_raw), _p(link.mean), _p(link.invstd), _p(link.gsc), _p(link.gsh), link.act,
+                                                             _p(sums), _stream())
+                    bn_link_counts["asked"] += 1
+                    if rc == 0:
+                        fused = True
+                        bn_link_counts["fused"] += 1
+                        link.sums, link.dx_ptr, link.dx = sums, dx.data_ptr(), dx
+                    elif rc != 3:  # (DASS_ERR_UNSUPPORTED: outside the kernel's specialisation -- the two passes below)
+                        check(rc, "dass_dwconv3x3_bwd_data_bnstats")
+                if not fused:
+                    check(lib.dass_dwconv3x3_bwd_data(_p(dy), lddy, _p(wdw), _p(dx), c, n, h, w, c, oh, ow, spec.stride,
+                                                      spec.pad, spec.dil, _dt(dx), _stream()), "dass_dwconv3x3_bwd_data")
             if ctx.needs_input_grad[1]:
                 dwf = torch.empty((c, 9), dtype=torch.float32, device=dev)
                 check(lib.dass_dwconv3x3_bwd_weight(_p(xs), ldx, _p(dy), lddy, _p(dwf), n, h, w, c, oh, ow,

@@ -135,6 +135,16 @@ int dass_dwconv3x3_bwd_data(const void *dy, int64_t lddy, const float *w, void *
 int dass_dwconv3x3_bwd_weight(const void *x, int64_t ldx, const void *dy, int64_t lddy, float *dw,
                               int N, int H, int W, int C, int OH, int OW,
                               int stride, int pad, int dil, int dtype, void *stream);
+/* dass_dwconv3x3_bwd_data (f32, stride 1, dilation 1 or 2, lddx == C) whose result dx [N*H*W][C] IS the gradient d_out of the
+ * conv + BN (+ act) layer that produced the depthwise conv's input -- MobileNetV2's expand 1x1 of an inverted-residual block
+ * (models/backbone/mobilenet.py:52-58).  The launch also adds THAT layer's BN-backward sums (sum dz, sum dz xhat, max |dz|; dz = dx *
+ * act'(fma(bn_y, gate_scale, gate_shift))) into bn_sums ([2][C] f64 + C floats, zeroed by the caller) -- what dass_bn_bwd_reduce_sums
+ * computes in a pass of its own over dx and bn_y [N*H*W][C]; the depthwise counterpart of dass_conv2d_x3_dgrad_bnstats.
+ * DASS_ERR_UNSUPPORTED for any other stride / dilation / row pitch: the caller runs the two passes. */
+int dass_dwconv3x3_bwd_data_bnstats(const void *dy, int64_t lddy, const float *w, void *dx, int64_t lddx,
+                                    int N, int H, int W, int C, int OH, int OW, int stride, int pad, int dil,
+                                    const float *bn_y, const float *bn_mean, const float *bn_invstd,
+                                    const float *gate_scale, const float *gate_shift, int bn_act, double *bn_sums, void *stream);
 
 /* ---------------------------------------------------------------- batch norm (+ReLU/ReLU6, residual, Dropout2d scale)
  * Replaces F.batch_norm at every batchnorm(...) site + the ReLU that follows it. */

@@ -6,6 +6,7 @@ import ctypes
 import os
 import time
 
+import numpy as np
 import pytest
 import torch
 
@@ -209,3 +210,87 @@ def test_depthwise_forward_and_input_gradient_strip_kernels(shape):
     assert ey <= 1e-5 and ex <= 1e-5
     assert torch.equal(res["1"][0], res["0"][0])
     assert torch.equal(res["1"][1], res["0"][1])
+
+
+def test_depthwise_input_gradient_carries_the_expand_layers_bn_sums():
+    """dass_dwconv3x3_bwd_data_bnstats: one train step of DeepLab-MobileNetV2 with the BN-backward sums of every expand 1x1 riding in the
+    depthwise conv's input-gradient launch, against the same step with the separate reduce pass (ops.set_dw_bn_link(False)): same loss,
+    every gradient within 2e-5 of its largest value (the sums are added in a different order), and the launches did carry them"""
+    from dass_hip import ops
+    from models.deeplab import DeepLab
+    from oracle import deeplab_cpu as O
+    from utils.loss import SegmentationLosses
+
+    keep = ops.f32_mma()
+    try:
+        ops.set_compute_dtype(torch.float32)
+        ops.set_f32_mma("f16x3")
+        om = O.ODeepLab("mobilenet", 16, 21)
+        O.fill_state_dict(om, seed=5, randomize_bn_stats=False)
+        x, lab = O.synthetic_batch(4, 97, 97, 21, first_index=900)
+        m1, m2 = O.dropout_masks(4, 1, seed=6)
+        res = {}
+        for on in (True, False):
+            ops.set_dw_bn_link(on)
+            pm = DeepLab(backbone="mobilenet", output_stride=16, num_classes=21, sync_bn=False, pretrained=False)
+            pm.load_state_dict(om.state_dict())
+            pm = pm.cuda().train()
+            before = dict(ops.bn_link_counts)
+            loss = SegmentationLosses(cuda=True).build_loss("ce")(pm(x.cuda(), dropout_masks=(m1[0].cuda(), m2[0].cuda())), lab.cuda())
+            loss.backward()
+            torch.cuda.synchronize()
+            res[on] = (loss.item(), {k: p.grad.double().cpu() for k, p in pm.named_parameters()},
+                       {k: ops.bn_link_counts[k] - before[k] for k in before})
+        print("link counts with the depthwise link:", res[True][2], "without:", res[False][2])
+        assert res[True][0] == res[False][0]
+        assert res[True][2]["used"] >= res[False][2]["used"] + 10   # MobileNetV2 at os16: 14 stride-1 depthwise convs behind an expand layer
+        worst = max(((res[True][1][k] - res[False][1][k]).abs().max().item() / max(res[False][1][k].abs().max().item(), 1e-12), k) for k in res[True][1])
+        print("largest gradient difference %.2e (%s)" % worst)
+        assert worst[0] <= 2e-5, worst
+    finally:
+        ops.set_dw_bn_link(True)
+        ops.set_f32_mma(keep)
+
+
+@pytest.mark.parametrize("shape", [(2, 33, 33, 96, 1, 1), (3, 33, 33, 576, 1, 2), (4, 49, 49, 32, 1, 1), (2, 17, 40, 144, 1, 1)])
+@pytest.mark.parametrize("act", [0, 2])
+def test_depthwise_bnstats_kernel_vs_f64(shape, act):
+    """dass_dwconv3x3_bwd_data_bnstats at kernel level: dx equals dass_dwconv3x3_bwd_data bit for bit, and the three per-channel sums
+    (sum dz, sum dz xhat, max |dz|) equal an f64 evaluation of the same dx to 1e-5 of their largest value (act 2 = ReLU6 gate from
+    fma(y, scale, shift), act 0 = no activation)"""
+    from dass_hip._lib import lib
+
+    n, h, w, c, stride, dil = shape
+    pad = dil
+    g = torch.Generator().manual_seed(11)
+    dy = torch.randn(n, h, w, c, generator=g)
+    wt = torch.randn(c, 9, generator=g)
+    y = torch.randn(n, h, w, c, generator=g) * 2 + 1
+    mean, invstd = torch.randn(c, generator=g) * 0.1 + 1, torch.rand(c, generator=g) + 0.5
+    sc, sh = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    d = lambda t: t.cuda()
+    dyd, wd, yd, md, isd, scd, shd = d(dy), d(wt), d(y), d(mean), d(invstd), d(sc), d(sh)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dx0 = torch.empty((n, h, w, c), device="cuda")
+    dx1 = torch.empty((n, h, w, c), device="cuda")
+    sums = torch.zeros((2 * c + (c + 1) // 2,), dtype=torch.float64, device="cuda")
+    assert lib.dass_dwconv3x3_bwd_data(_p(dyd), c, _p(wd), _p(dx0), c, n, h, w, c, h, w, stride, pad, dil, 0, st) == 0
+    assert lib.dass_dwconv3x3_bwd_data_bnstats(_p(dyd), c, _p(wd), _p(dx1), c, n, h, w, c, h, w, stride, pad, dil, _p(yd), _p(md), _p(isd),
+                                               _p(scd), _p(shd), act, _p(sums), st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dx0, dx1)
+    dxr = dx0.cpu().double().reshape(-1, c)
+    yr = y.double().reshape(-1, c)
+    o = torch.from_numpy(np.float32(yr.numpy())).float() * sc + sh   # (the gate is taken from the f32 fma, as the forward computed it)
+    o = torch.addcmul(sh, y.reshape(-1, c), sc)
+    gate = ((o > 0) & (o < 6)).double() if act == 2 else torch.ones_like(yr)
+    dz = dxr * gate
+    xhat = (yr - mean.double()) * invstd.double()
+    ref = torch.stack([dz.sum(0), (dz * xhat).sum(0)])
+    got = sums[:2 * c].reshape(2, c).cpu()
+    mx = sums[2 * c:].view(torch.float32)[:c].cpu()
+    for i, name in enumerate(("sum dz", "sum dz xhat")):
+        err = (got[i] - ref[i]).abs().max().item() / ref[i].abs().max().item()
+        print(shape, act, name, "%.2e" % err)
+        assert err <= 1e-5, (name, err)
+    assert (mx.double() - dz.abs().max(0).values).abs().max().item() <= 1e-6 * dz.abs().max().item()
