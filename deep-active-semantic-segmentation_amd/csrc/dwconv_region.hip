@@ -240,11 +240,12 @@ struct DwBnLink {  // BNS: the layer whose output this launch's result is the gr
     int act;
 };
 
-template <int DIL, int STRIDE, bool FLIP, bool BNS>
+template <int DIL, int STRIDE, bool FLIP, int MODE>  // MODE 0: conv only; 1: + BN-backward sums of the producing layer; 2: + sum / sum of squares of the output
 __global__ __launch_bounds__(256) void dw_conv_strip_kernel(const float *__restrict__ in, int ldi, const float *__restrict__ w,
                                                             float *__restrict__ out, int ldo, int IH, int IW, int C, int OH, int OW,
                                                             int pad, int nsegw, int nstrips, int seg, const DwBnLink bl) {
     constexpr int WW = 2 * DIL + 1, KEEP = WW - STRIDE, PF = 3;  // (seg: outputs per strip = ceil(OW / nsegw) <= 16, e.g. 3 x 11 at OW = 33)
+    constexpr bool BNS = MODE == 1;
     const int cq = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int c = blockIdx.x * 64 + cq * 4;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -322,6 +323,11 @@ __global__ __launch_bounds__(256) void dw_conv_strip_kernel(const float *__restr
 #pragma unroll
                     for (int s2 = 0; s2 < 3; ++s2) a += win[FLIP ? 2 - r : r][(FLIP ? 2 - s2 : s2) * DIL] * wv[r * 3 + s2];
                 if (o0 + i < o_end) *reinterpret_cast<f32x4 *>(op + i * ldo) = a;
+                if constexpr (MODE == 2) {  // train-mode BN behind this conv: its batch statistics (dass_channel_sums' pass, fused)
+                    const f32x4 v = (o0 + i < o_end) ? a : zero;
+                    bs0 += v;
+                    bs1 += v * v;
+                }
                 if constexpr (BNS) {
                     // dz = dx * act'(out) with out re-derived from the layer's conv output by the forward's own fma (bn_affine), xhat = (y - mean) / std
                     f32x4 gz = (o0 + i < o_end) ? a : zero;
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(256) void dw_conv_strip_kernel(const float *__restr
         }
     }
     }  // c < C
-    if constexpr (BNS) {
+    if constexpr (MODE != 0) {
         // the 16 strip lanes of a channel group fold through LDS, then one f64 atomic per channel and workgroup (as the conv kernels do)
         __shared__ float red[3][16][64 + 4];
 #pragma unroll
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(256) void dw_conv_strip_kernel(const float *__restr
             red[2][pl][cq * 4 + e] = bsm[e];
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < 3 * 64; i += 256) {
+        for (int i = threadIdx.x; i < (MODE == 2 ? 2 : 3) * 64; i += 256) {
             const int which = i >> 6, cl = i & 63, cc = blockIdx.x * 64 + cl;
             if (cc >= C) continue;
             if (which < 2) {
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(256) void dw_conv_strip_kernel(const float *__restr
 }
 
 // 1: launched; 0: outside the specialisation
-template <bool FLIP, bool BNS = false>
+template <bool FLIP, int MODE = 0>
 static int launch_dw_strip(const float *in, long ldi, const float *w, float *out, long ldo, int N, int IH, int IW, int C, int OH, int OW, int stride,
                            int pad, int dil, hipStream_t st, const DwBnLink bl = DwBnLink{}) {
     const char *e = getenv("DASS_DW_STRIP");
@@ -387,7 +393,7 @@ static int launch_dw_strip(const float *in, long ldi, const float *w, float *out
     if (gy > (nstrips + 15) / 16) gy = (nstrips + 15) / 16;
     const dim3 grid(cblocks, (unsigned)(gy < 1 ? 1 : gy));
 #define DASS_DW_CS(D, S)                                                                                                                   \
-    DASS_LAUNCH((dw_conv_strip_kernel<D, S, FLIP, BNS>), grid, dim3(256), 0, st, in, (int)ldi, w, out, (int)ldo, IH, IW, C, OH, OW, pad, nsegw, \
+    DASS_LAUNCH((dw_conv_strip_kernel<D, S, FLIP, MODE>), grid, dim3(256), 0, st, in, (int)ldi, w, out, (int)ldo, IH, IW, C, OH, OW, pad, nsegw, \
                 (int)nstrips, seg, bl)
     if (dil == 1 && stride == 1) DASS_DW_CS(1, 1);
     else if (dil == 2 && stride == 1) DASS_DW_CS(2, 1);
@@ -808,6 +814,21 @@ extern "C" int dass_dwconv3x3_bwd_data(const void *dy, int64_t lddy, const float
     return DASS_OK;
 }
 
+/* dass_dwconv3x3_fwd (f32, stride 1 or 2, dilation 1 or 2) that also adds every output channel's sum and sum of squares into sums
+ * ([2][C] f64, zeroed by the caller): the statistics of the train-mode BN behind the conv (models/backbone/mobilenet.py:45-50) without
+ * dass_channel_sums' pass over y.  DASS_ERR_UNSUPPORTED outside the specialisation: the caller runs the two passes. */
+extern "C" int dass_dwconv3x3_fwd_sums(const void *x, int64_t ldx, const float *w, void *y, int64_t ldy, int N, int H, int W, int C, int OH,
+                                       int OW, int stride, int pad, int dil, double *sums, void *stream) {
+    const void *x_ = x;
+    const void *y_ = y;
+    if (!DW_ARGS_OK || !w || ldx % 4 || ldy % 4 || !sums) return DASS_ERR_ARG;
+    DwBnLink bl{nullptr, nullptr, nullptr, nullptr, nullptr, sums, DASS_ACT_NONE};
+    if (!launch_dw_strip<false, 2>((const float *)x, ldx, w, (float *)y, ldy, N, H, W, C, OH, OW, stride, pad, dil, (hipStream_t)stream, bl))
+        return DASS_ERR_UNSUPPORTED;
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
 /* dass_dwconv3x3_bwd_data whose result dx [N*H*W][C] IS the gradient d_out of the conv + BN (+ act) layer that produced the depthwise
  * conv's input (MobileNetV2: the expand 1x1 of an inverted-residual block, models/backbone/mobilenet.py:52-58): the launch also adds that
  * layer's BN-backward sums into bn_sums ([2][C] f64 + C floats, zeroed by the caller), as dass_conv2d_x3_dgrad_bnstats does for dense convs.
@@ -822,7 +843,7 @@ extern "C" int dass_dwconv3x3_bwd_data_bnstats(const void *dy, int64_t lddy, con
     if (bn_act != DASS_ACT_NONE && (!gate_scale || !gate_shift)) return DASS_ERR_ARG;
     if (stride != 1 || 2 * dil - pad < 0 || lddx != C) return DASS_ERR_UNSUPPORTED;
     DwBnLink bl{bn_y, bn_mean, bn_invstd, gate_scale, gate_shift, bn_sums, bn_act};
-    if (!launch_dw_strip<true, true>((const float *)dy, lddy, w, (float *)dx, lddx, N, OH, OW, C, H, W, 1, 2 * dil - pad, dil, (hipStream_t)stream, bl))
+    if (!launch_dw_strip<true, 1>((const float *)dy, lddy, w, (float *)dx, lddx, N, OH, OW, C, H, W, 1, 2 * dil - pad, dil, (hipStream_t)stream, bl))
         return DASS_ERR_UNSUPPORTED;
     DASS_LAUNCH_CHECK();
     return DASS_OK;

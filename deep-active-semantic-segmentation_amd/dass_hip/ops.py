@@ -316,6 +316,7 @@ class BnBwdLink:
         self.dx = None
 
 
+_DW_FWD_SUMS = os.environ.get("DASS_DW_FWD_SUMS", "1") == "1"  # train-mode BN statistics of a depthwise conv's output in the conv launch
 _DW_BN_LINK = os.environ.get("DASS_DW_BN_LINK", "1") == "1"  # ... also in a depthwise conv's input-gradient launch (MobileNetV2 expand layers)
 _BN_LINK = os.environ.get("DASS_BN_LINK", "1") == "1"  # BN-backward sums ride in the epilogue of the next layer's input-gradient launch
 bn_link_counts = {"asked": 0, "fused": 0, "used": 0}    # launches asked to carry sums / that did / sums a layer's backward took over
@@ -326,9 +327,13 @@ def set_bn_link(on):
     _BN_LINK = bool(on)
 
 
-def set_dw_bn_link(on):
-    global _DW_BN_LINK
+def set_dw_bn_link(on, fwd_sums=None):
+    """depthwise launches that carry BN sums: `on` = the producing layer's BN-BACKWARD sums in the input-gradient launch
+    (dass_dwconv3x3_bwd_data_bnstats), fwd_sums = the batch statistics of the conv's own output in the forward launch (dass_dwconv3x3_fwd_sums)"""
+    global _DW_BN_LINK, _DW_FWD_SUMS
     _DW_BN_LINK = bool(on)
+    if fwd_sums is not None:
+        _DW_FWD_SUMS = bool(fwd_sums)
 
 
 def conv_x3_dgrad_bnstats(dy3, w_t, dx, dims, link, residual=None, ldr=0):
@@ -1021,8 +1026,16 @@ class _ConvBnAct(torch.autograd.Function):
             if sums is not None:
                 # statistics as f64 accumulators the conv adds to; scale / shift derived inside the apply launch below
                 if spec.depthwise or rowtap:
-                    _conv_forward_raw(spec, xs, ldx, n, h, w, c, weight, y_raw, k, oh, ow)
-                    check(lib.dass_channel_sums(_p(y_raw), k, m, k, _p(sums), _dt(y_raw), _stream()), "dass_channel_sums")
+                    rc = 3
+                    if spec.depthwise and dt == torch.float32 and _DW_FWD_SUMS:
+                        # the depthwise strip kernel owns fixed channels per thread: the BN statistics ride along (no pass over y_raw)
+                        rc = lib.dass_dwconv3x3_fwd_sums(_p(xs), ldx, _p(_dw_weight(weight)), _p(y_raw), k, n, h, w, c, oh, ow, spec.stride,
+                                                         spec.pad, spec.dil, _p(sums), _stream())
+                        if rc not in (0, 3):  # (3 = DASS_ERR_UNSUPPORTED: outside the specialisation -- the two passes below)
+                            check(rc, "dass_dwconv3x3_fwd_sums")
+                    if rc != 0:
+                        _conv_forward_raw(spec, xs, ldx, n, h, w, c, weight, y_raw, k, oh, ow)
+                        check(lib.dass_channel_sums(_p(y_raw), k, m, k, _p(sums), _dt(y_raw), _stream()), "dass_channel_sums")
                 elif use_x3:
                     x3 = x3_operand(x, xs, ldx, n * h * w, c)
                     x3_saved = x3 if x3_on else None

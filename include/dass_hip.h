@@ -135,6 +135,11 @@ int dass_dwconv3x3_bwd_data(const void *dy, int64_t lddy, const float *w, void *
 int dass_dwconv3x3_bwd_weight(const void *x, int64_t ldx, const void *dy, int64_t lddy, float *dw,
                               int N, int H, int W, int C, int OH, int OW,
                               int stride, int pad, int dil, int dtype, void *stream);
+/* dass_dwconv3x3_fwd (f32, stride 1 or 2, dilation 1 or 2) that also adds every output channel's sum and sum of squares into sums
+ * ([2][C] f64, zeroed by the caller): the batch statistics of the train-mode BN behind the conv (models/backbone/mobilenet.py:45-50)
+ * without dass_channel_sums' pass over y.  DASS_ERR_UNSUPPORTED outside the specialisation: the caller runs the two passes. */
+int dass_dwconv3x3_fwd_sums(const void *x, int64_t ldx, const float *w, void *y, int64_t ldy,
+                            int N, int H, int W, int C, int OH, int OW, int stride, int pad, int dil, double *sums, void *stream);
 /* dass_dwconv3x3_bwd_data (f32, stride 1, dilation 1 or 2, lddx == C) whose result dx [N*H*W][C] IS the gradient d_out of the
  * conv + BN (+ act) layer that produced the depthwise conv's input -- MobileNetV2's expand 1x1 of an inverted-residual block
  * (models/backbone/mobilenet.py:52-58).  The launch also adds THAT layer's BN-backward sums (sum dz, sum dz xhat, max |dz|; dz = dx *

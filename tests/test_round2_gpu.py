@@ -79,11 +79,11 @@ def test_hip_sgd_refreshes_weight_operands(engine):
     assert abs(lt[0] - lh[0]) <= 1e-6 * abs(lt[0]) + 1e-6
     # step 2 sees the step-1 update (a stale operand would reproduce the step-1 loss exactly); by step 3 the two
     # optimizers' rounding (fused kernel vs foreach passes) has been amplified by the net, so that bound is loose
-    assert abs(lt[1] - lt[0]) > 1e-3 * abs(lt[0]), lt
+    assert abs(lt[1] - lt[0]) > 1e-5 * abs(lt[0]), lt   # (a stale operand repeats the loss EXACTLY; an honest step moved it by 3e-4 here)
     assert abs(lt[1] - lh[1]) <= 0.05 * tol * abs(lt[1]), (lt, lh)
     # step 3: chaotic amplification of the optimizers' last-bit differences reaches percents of the loss on this 65x65 /
     # batch-2 net (seen: 1.8 %); what a stale operand would do -- leave the loss where it was -- is still excluded
-    assert abs(lt[2] - lh[2]) <= 0.05 * abs(lt[2]) and abs(lh[2] - lh[1]) > 1e-3 * abs(lh[1]), (lt, lh)
+    assert abs(lt[2] - lh[2]) <= 0.05 * abs(lt[2]) and abs(lh[2] - lh[1]) > 1e-5 * abs(lh[1]), (lt, lh)
     print(engine, "losses torch", lt, "hip", lh)
     # (the logits of the two trajectories are NOT compared: train-mode BN over 5x5 maps at batch 2 amplifies the optimizers'
     # rounding differences chaotically; the cache-freshness check above is the bit-exact deep-copy comparison)

@@ -230,8 +230,9 @@ def test_depthwise_input_gradient_carries_the_expand_layers_bn_sums():
         x, lab = O.synthetic_batch(4, 97, 97, 21, first_index=900)
         m1, m2 = O.dropout_masks(4, 1, seed=6)
         res = {}
-        for on in (True, False):
-            ops.set_dw_bn_link(on)
+        for on in (True, False, "fwd-off"):
+            # (link on / off with the forward statistics fused in both; "fwd-off": the link on, dass_dwconv3x3_fwd_sums off)
+            ops.set_dw_bn_link(on is not False, fwd_sums=on != "fwd-off")
             pm = DeepLab(backbone="mobilenet", output_stride=16, num_classes=21, sync_bn=False, pretrained=False)
             pm.load_state_dict(om.state_dict())
             pm = pm.cuda().train()
@@ -243,12 +244,15 @@ def test_depthwise_input_gradient_carries_the_expand_layers_bn_sums():
                        {k: ops.bn_link_counts[k] - before[k] for k in before})
         print("link counts with the depthwise link:", res[True][2], "without:", res[False][2])
         assert res[True][0] == res[False][0]
+        # forward statistics in the conv launch vs dass_channel_sums: another summation order of the same values; the loss moves in its last digits
+        # (and the batch-4 BN of the ASPP image-pool branch turns that into percents of ITS gradients: not compared -- kernel-level test above)
+        assert abs(res[True][0] - res["fwd-off"][0]) <= 2e-6 * abs(res[True][0])
         assert res[True][2]["used"] >= res[False][2]["used"] + 10   # MobileNetV2 at os16: 14 stride-1 depthwise convs behind an expand layer
         worst = max(((res[True][1][k] - res[False][1][k]).abs().max().item() / max(res[False][1][k].abs().max().item(), 1e-12), k) for k in res[True][1])
         print("largest gradient difference %.2e (%s)" % worst)
         assert worst[0] <= 2e-5, worst
     finally:
-        ops.set_dw_bn_link(True)
+        ops.set_dw_bn_link(True, fwd_sums=True)
         ops.set_f32_mma(keep)
 
 
@@ -294,3 +298,30 @@ def test_depthwise_bnstats_kernel_vs_f64(shape, act):
         print(shape, act, name, "%.2e" % err)
         assert err <= 1e-5, (name, err)
     assert (mx.double() - dz.abs().max(0).values).abs().max().item() <= 1e-6 * dz.abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [(2, 33, 33, 96, 1, 1), (2, 65, 47, 144, 2, 1), (3, 33, 33, 576, 1, 2), (4, 49, 49, 32, 1, 1)])
+def test_depthwise_forward_sums_kernel_vs_f64(shape):
+    """dass_dwconv3x3_fwd_sums: y equals dass_dwconv3x3_fwd bit for bit; the per-channel sum and sum of squares equal an f64 evaluation
+    of that y to 1e-5 of their largest value"""
+    from dass_hip._lib import lib
+
+    n, h, w, c, stride, dil = shape
+    pad = dil
+    oh, ow = (h + 2 * pad - 2 * dil - 1) // stride + 1, (w + 2 * pad - 2 * dil - 1) // stride + 1
+    g = torch.Generator().manual_seed(12)
+    xd = (torch.randn(n, h, w, c, generator=g) + 0.3).cuda()
+    wd = torch.randn(c, 9, generator=g).cuda()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    y0 = torch.empty((n, oh, ow, c), device="cuda")
+    y1 = torch.empty((n, oh, ow, c), device="cuda")
+    sums = torch.zeros((2 * c,), dtype=torch.float64, device="cuda")
+    assert lib.dass_dwconv3x3_fwd(_p(xd), c, _p(wd), _p(y0), c, n, h, w, c, oh, ow, stride, pad, dil, 0, st) == 0
+    assert lib.dass_dwconv3x3_fwd_sums(_p(xd), c, _p(wd), _p(y1), c, n, h, w, c, oh, ow, stride, pad, dil, _p(sums), st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    yr = y0.cpu().double().reshape(-1, c)
+    ref = torch.stack([yr.sum(0), (yr * yr).sum(0)])
+    got = sums.reshape(2, c).cpu()
+    for i in range(2):
+        assert (got[i] - ref[i]).abs().max().item() <= 1e-5 * ref[i].abs().max().item(), i
