@@ -1265,6 +1265,17 @@ extern "C" int dass_x3_magic(int d, unsigned *mul, int *shift) {
  * schedule + fix-up pass).  Diagnostic only (bench.py attributes in-step launch times to tile classes with it); host state, no stream */
 extern "C" int dass_x3_last_pick(void) { return g_last_pick; }
 
+/* workgroups of the whole-tile kernels the runtime keeps resident per CU (tools / DESIGN: bytes in flight per CU = this x the ring):
+ * which = 0: 64x64, 1: 128x64, 2: 256x128 (two-part engine, M16 MFMAs) */
+extern "C" int dass_x3_resident_workgroups(int which) {
+    int n = 0;
+    hipError_t e;
+    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_x3_kernel<64, 64, 2, 2, 2, true, 2, true>, 256, 0);
+    else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_x3_kernel<128, 64, 4, 1, 2, true, 2, true>, 256, 0);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_x3_kernel<256, 128, 4, 2, 2, true, 2, true>, 512, 0);
+    return e == hipSuccess ? n : -1;
+}
+
 extern "C" int dass_x3_force_tile(int tile) {
     g_x3_force = tile < 0 ? 0 : tile;
     return DASS_OK;

@@ -447,6 +447,9 @@ int dass_x3_force_tile(int tile);
  * specialisation) | 1 (stream-K schedule + fix-up pass).  Host state only (no device work); bench.py's in-step roofline uses it
  * to attribute launch times to tile classes.  No reference counterpart (the reference's convs are ATen calls). */
 int dass_x3_last_pick(void);
+/* workgroups of a whole-tile kernel resident per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor): which = 0: 64x64, 1: 128x64,
+ * 2: 256x128 tiles of the two-part engine -- the bytes a CU keeps in flight are this times the kernel's LDS ring */
+int dass_x3_resident_workgroups(int which);
 /* Measurement infrastructure (csrc/prof.hip; bench.py's in-step `roofline`, SURVEY.md 8d "measured live inside bench.py with HIP
  * events ... on the stream the kernel is launched on").  Between dass_prof_begin() and dass_prof_end() EVERY kernel this library
  * launches carries a start / stop event pair bound to that one dispatch (hipExtLaunchKernelGGL), on the stream of the launch:

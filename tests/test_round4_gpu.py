@@ -283,6 +283,12 @@ def test_graphed_train_step_follows_the_eager_trajectory(engine):
             pm.eval()
             with torch.no_grad():
                 logits = pm(xd).float().cpu()
+                # the sharp check for stale operand caches after replays (which step the optimizer behind autograd's back): a deep copy has
+                # new parameter objects, no cache entry can match them, and it must compute the same logits bit for bit
+                import copy
+
+                fresh = copy.deepcopy(pm).eval()
+                assert torch.equal(logits, fresh(xd).float().cpu()), mode
             runs[mode] = (losses, {k: v.detach().float().cpu().clone() for k, v in pm.state_dict().items()}, logits)
         le, lg = runs["eager"][0], runs["graph"][0]
         print(engine, "eager", ["%.5f" % v for v in le], "graph", ["%.5f" % v for v in lg])
@@ -308,6 +314,7 @@ def test_graphed_train_step_follows_the_eager_trajectory(engine):
         noise = rms(ref - runs["eager2"][2]) / rms(ref)
         dmax = (ref - runs["graph"][2]).abs().max().item() / ref.abs().max().item()
         print(engine, "eval logits: graph vs eager rms %.3e (max %.3e), eager vs eager rms %.3e" % (dl, dmax, noise))
-        assert dl <= max(1e-2 if engine == "f16x3" else 5e-2, 4 * noise), (dl, noise)
+        # (trajectory-level bound only: two eager runs of this 129^2 / batch-4 step differ by 1e-3 ... 1e-2 (f16x3) and 3e-2 ... 1.5e-1 (bf16x1) in RMS)
+        assert dl <= max(3e-2 if engine == "f16x3" else 1e-1, 4 * noise), (dl, noise)
     finally:
         ops.set_f32_mma(keep)

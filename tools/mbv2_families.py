@@ -28,6 +28,8 @@ where = ""
 if after is not None:
     marks = [r[0] for r in cur.execute("select start from kernels where %s like ? order by start" % name_col, ("%" + after[0] + "%",))]
     where = " where start > %d" % marks[after[1] - 1]
+if steps <= 0:  # 0: count the steps in the window (one ce_fwd_kernel launch per train step)
+    steps = float(cur.execute("select count(*) from kernels%s%s like '%%ce_fwd_kernel%%'" % (where, (" and " if where else " where ") + name_col)).fetchone()[0]) or 1.0
 rows = cur.execute("select %s, count(*), sum(end - start) from kernels%s group by %s" % (name_col, where, name_col)).fetchall()
 
 
@@ -74,7 +76,11 @@ fam_of = [("dw_fwd", "depthwise fwd"), ("dw_bwd_data", "depthwise input gradient
 tot, total = {}, 0.0
 for name, n, t in rows:
     name = re.sub(r"\(anonymous namespace\)::", "", name)
-    fam = next((f for key, f in fam_of if key in name), "other (splits, loss, pooling, resampling, optimizer, torch fills)")
+    strip = re.search(r"dw_conv_strip_kernel<\d+, \d+, (true|false)", name)   # (round 4: forward and input gradient are one kernel, FLIP = third argument)
+    if strip:
+        fam = "depthwise input gradient" if strip.group(1) == "true" else "depthwise fwd"
+    else:
+        fam = next((f for key, f in fam_of if key in name), "other (splits, loss, pooling, resampling, optimizer, torch fills)")
     tot[fam] = tot.get(fam, 0.0) + t / 1e6 / steps
     total += t / 1e6 / steps
 print("DeepLab-MobileNetV2 %d-class %dx%d batch %d train step: %.2f ms of kernels per step" % (classes, size, size, batch, total))

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 mkdir -p "$OUT"
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -- python3 bench.py --steps 10 --warmup 3 $FLAGS > "$OUT/trace_bench.json" 2> "$OUT/trace_bench.err"
 DB=$(find "$OUT/trace" -name "*_results.db" | head -1)
-python3 tools/rocpd_stats.py "$DB" 10 48 --after sgd_multi 18 > "$OUT/train_summary.md"
+python3 tools/rocpd_stats.py "$DB" 0 48 --after sgd_multi 18 > "$OUT/train_summary.md"
 echo "trace done: $DB"
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -- python3 bench.py --steps 2 --warmup 2 $FLAGS > "$OUT/pmc_$C.json" 2> "$OUT/pmc_$C.err"

@@ -24,6 +24,8 @@ where = ""
 if after is not None:
     marks = [r[0] for r in cur.execute("select start from kernels where %s like ? order by start" % name_col, ("%" + after[0] + "%",))]
     where = " where start > %d" % marks[after[1] - 1]
+if steps <= 0:  # 0: count the steps in the window (one ce_fwd_kernel launch per train step)
+    steps = float(cur.execute("select count(*) from kernels%s%s like '%%ce_fwd_kernel%%'" % (where, (" and " if where else " where ") + name_col)).fetchone()[0]) or 1.0
 rows = cur.execute("select %s, count(*), sum(end - start), avg(end - start) from kernels%s group by %s order by 3 desc" % (name_col, where, name_col)).fetchall()
 total = sum(r[2] for r in rows)
 print("total kernel time %.1f ms = %.2f ms/step" % (total / 1e6, total / 1e6 / steps))
