@@ -28,8 +28,11 @@ __global__ __launch_bounds__(256) void colstat_kernel(const T *__restrict__ x, l
     const int tid = threadIdx.x;
     const int cx = tid & 15, ry = tid >> 4;
     const int k = blockIdx.y * 64 + cx * 4;
-    const long r0 = (long)blockIdx.x * SLAB;
-    long r1 = r0 + SLAB;
+    // rows per block from the grid: SLAB (128) on the partial-row paths (grid.x = dass_stat_rows(M)); the f64-atomic paths launch
+    // fewer, longer blocks (stat_blocks) -- one block per 128 rows ended in 1041 atomics per channel on the layer-1 tensors
+    const long slab = ((M + gridDim.x - 1) / gridDim.x + 15) / 16 * 16;
+    const long r0 = (long)blockIdx.x * slab;
+    long r1 = r0 + slab;
     if (r1 > M) r1 = M;
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
     if (k < K) {
@@ -658,6 +661,15 @@ bool ok4(int K, int64_t a, int64_t b = 4, int64_t c = 4, int64_t d = 4) {
 }  // namespace
 
 extern "C" int dass_stat_rows(int64_t M) { return (int)((M + SLAB - 1) / SLAB); }
+// row blocks of a colstat launch that ends in f64 atomics: ~1024 blocks in all, at least 128 rows each
+static unsigned stat_blocks(long M, int K) {
+    const long cols = (K + 63) / 64;
+    static const long target = getenv("DASS_STAT_BLOCKS") ? atol(getenv("DASS_STAT_BLOCKS")) : 1024;  // (tuning knob: 512 / 1024 / 2048 / 4096 measured 0.83 / 0.79 / 0.93 / 1.07 ms per R101 step)
+    long want = (target + cols - 1) / cols;
+    const long most = (M + SLAB - 1) / SLAB;
+    if (want > most) want = most;
+    return (unsigned)(want < 1 ? 1 : want);
+}
 
 extern "C" int dass_channel_stats(const void *x, int64_t ldx, int64_t M, int K, float *partial, int dtype,
                                   void *stream) {
@@ -849,7 +861,7 @@ extern "C" int dass_colsum(const void *x, int64_t ldx, int64_t M, int K, float *
 // dass_set_deterministic callers keep the partial-row entry points.
 extern "C" int dass_channel_sums(const void *x, int64_t ldx, int64_t M, int K, double *sums, int dtype, void *stream) {
     if (!x || !sums || M <= 0 || !ok4(K, ldx)) return DASS_ERR_ARG;
-    dim3 grid((unsigned)dass_stat_rows(M), (unsigned)((K + 63) / 64));
+    dim3 grid(stat_blocks(M, K), (unsigned)((K + 63) / 64));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DASS_F32)
         DASS_LAUNCH((colstat_kernel<float, 0>), grid, dim3(256), 0, st, (const float *)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr,
@@ -901,7 +913,7 @@ extern "C" int dass_bn_bwd_reduce_sums(const void *dout, int64_t lddo, const voi
     if (!dout || !x || !mean || !invstd || !sums || M <= 0 || !ok4(K, lddo, out ? ldo : 4, ldx) || rows_per_image <= 0) return DASS_ERR_ARG;
     if (!out && !gates && (!gate_scale || !gate_shift || dtype != DASS_F32)) return DASS_ERR_ARG;
     if (gates && (nc_scale || gates_bytes < M * (K / 4))) return DASS_ERR_ARG;
-    dim3 grid((unsigned)dass_stat_rows(M), (unsigned)((K + 63) / 64));
+    dim3 grid(stat_blocks(M, K), (unsigned)((K + 63) / 64));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DASS_F32)
         DASS_LAUNCH((colstat_kernel<float, 1>), grid, dim3(256), 0, st, (const float *)x, ldx, (const float *)dout, lddo,
