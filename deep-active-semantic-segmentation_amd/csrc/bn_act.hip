@@ -643,9 +643,9 @@ __global__ void bn_rows_bwd_kernel(const float *__restrict__ g, const float *__r
 
 // 1-D grid for the BN backward apply kernel over M rows of K channels (256 threads, one thread per 4 channels): when it can, a
 // thread count that is a multiple of K / 4, so that every thread keeps one channel group for all its rows (bn_bwd_apply_kernel)
-static inline int bn_grid(int64_t M, int K) {
+static inline int bn_grid(int64_t M, int K, int rows_per_thread = 1) {
     const int64_t kv = K / 4;
-    int64_t g = dass_grid_1d(M * kv, 256);
+    int64_t g = dass_grid_1d((M * kv + rows_per_thread - 1) / rows_per_thread, 256);
     if (kv <= 0) return (int)g;
     int64_t a = kv, b = 256;
     while (b) { const int64_t t = a % b; a = b; b = t; }
@@ -888,6 +888,8 @@ extern "C" int dass_bn_apply_train(const void *x, int64_t ldx, void *out, int64_
     if (gates && gates_bytes < M * (K / 4)) return DASS_ERR_ARG;  // one byte per 4-channel group of every row
     const int parts = dass_get_x3_parts();
     if (out3 && parts == 2 && residual && !residual_bound) return DASS_ERR_ARG;  // the output's bound needs the residual's
+    // (one vector per thread up to the 2048-block cap: fewer, longer blocks -- tried at 8 / 16 vectors per thread to amortise the per-block
+    //  scale / shift prologue -- ran this kernel 7 % / 29 % SLOWER: its row loop keeps one load in flight per thread)
     const int grid = dass_grid_1d(M * (K / 4), 256);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DASS_F32)
@@ -942,7 +944,10 @@ extern "C" int dass_bn_bwd_apply_sums(const void *dout, int64_t lddo, const void
     if (gates && (nc_scale || gates_bytes < M * (K / 4))) return DASS_ERR_ARG;
     if (dres && lddr % 4) return DASS_ERR_ARG;
     if (dx3 && (dtype != DASS_F32 || ((uintptr_t)dx3 & 15))) return DASS_ERR_ARG;
-    const int grid = bn_grid(M, K);
+    // (a thread of the lean kernel gets >= DASS_BN_RPT rows: at one row per thread -- the 8712 x 256 tensors under the 2048-block cap --
+    //  the per-block prologue, the tensor bound over all K channels + a barrier, outweighs the row itself)
+    static const int rpt = getenv("DASS_BN_RPT") ? atoi(getenv("DASS_BN_RPT")) : 8;  // (1 / 2 / 4 / 8: 3.6+ / 3.56 / 3.45 / 3.38 ms per R101 step)
+    const int grid = bn_grid(M, K, rpt > 0 ? rpt : 1);
     const float inv_count = (float)(1.0 / count);
     hipStream_t st = (hipStream_t)stream;
     const char *fast_env = getenv("DASS_BN_BWD_FAST");  // (read per call: the tests flip it between two launches)
