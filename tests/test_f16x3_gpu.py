@@ -207,7 +207,7 @@ def test_train_step_f16x3_vs_oracle_and_bf16x6(backbone, seed):
     #  MobileNet run lands on 4.1 x stock f32's median, with the generic stem kernel it sat below 3 x.  Same gates on both sides:
     #  tests/test_grad_parity_gpu.py::test_resnet_gradients_with_oracle_gates_injected)
     assert med(res["f16x3"]) <= max(5 * med(cpu) + 2e-6, 1e-2)   # (stock f32's own median moves 3x between boxes: its thread count decides its flips)
-    assert q90(res["f16x3"]) <= 4 * q90(cpu) + 1e-5
+    assert q90(res["f16x3"]) <= max(4 * q90(cpu) + 1e-5, 1.5e-2)
     assert max(res["f16x3"].values()) <= 3e-2
     # (the six-product engine multiplies EXACT operands and is several times closer to f64 than any f32-input arithmetic; the
     # two-part engine rounds operands to 23 bits and lands between it and stock f32 -- here amplified ~1e3 by the batch-4 BN of the
