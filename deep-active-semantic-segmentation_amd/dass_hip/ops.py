@@ -131,8 +131,18 @@ def extra_streams(dev, n):
     """up to n more HIP streams on `dev` for independent batches (core_set._features); none when DASS_MC_PIPELINE=0"""
     if n <= 0 or os.environ.get("DASS_MC_PIPELINE", "1") != "1" or torch.cuda.is_current_stream_capturing():
         return []
-    key = ("lanes", dev.index if dev.index is not None else torch.cuda.current_device())
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = ("lanes", idx)
     sts = _mc_side.setdefault(key, [])
+    if len(sts) < n and os.environ.get("DASS_LANES_REUSE", "1") == "1":
+        # side streams this process already has (the MC passes' streams, the weight gradients' side stream) are idle while batches are
+        # dealt over lanes, and which hardware queue the runtime gives a NEW stream depends on how many were created before it: a lane
+        # that lands on the caller's queue runs nothing concurrently (core-set features 1390 vs 1120 pool img/s, DESIGN 0.R4)
+        for k2 in (idx, ("prefix", idx), ("wgrad", idx)):
+            v = _mc_side.get(k2)
+            for st in (v if isinstance(v, list) else [v] if v is not None else []):
+                if len(sts) < n and all(st is not t for t in sts):
+                    sts.append(st)
     while len(sts) < n:
         sts.append(torch.cuda.Stream(device=dev))
     return sts[:n]
