@@ -1073,12 +1073,20 @@ __global__ __launch_bounds__(256) void weight_split3_batch_kernel(const long *__
                                                                   long total_tiles, int parts) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-    for (long tl = blockIdx.x; tl < total_tiles; tl += gridDim.x) {
-        int lo = 0, hi = n - 1;
+    // a block owns a CONTIGUOUS range of tiles: one binary search for its first tile, then the table index only moves forward (the
+    // grid-stride form searched the table for every tile: ~8 dependent loads in front of each 4 KB of weights, 1.7 TB/s in all)
+    const long per_block = (total_tiles + gridDim.x - 1) / gridDim.x;
+    const long tl_beg = (long)blockIdx.x * per_block, tl_end = tl_beg + per_block < total_tiles ? tl_beg + per_block : total_tiles;
+    int lo = 0;
+    if (tl_beg < tl_end) {
+        int hi = n - 1;
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
-            if (start[mid] <= tl) lo = mid; else hi = mid - 1;
+            if (start[mid] <= tl_beg) lo = mid; else hi = mid - 1;
         }
+    }
+    for (long tl = tl_beg; tl < tl_end; ++tl) {
+        while (lo + 1 < n && start[lo + 1] <= tl) ++lo;
         const long *d = desc + 8 * lo;
         const float *src = reinterpret_cast<const float *>(d[0]);
         bf16_t *dst = reinterpret_cast<bf16_t *>(d[1]);
@@ -1136,44 +1144,86 @@ __global__ __launch_bounds__(256) void weight_split2_batch_kernel(const long *__
     __shared__ float tile[32][33];
     __shared__ float red[4];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-    for (long tl = blockIdx.x; tl < total_tiles; tl += gridDim.x) {
-        int lo = 0, hi = n - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (start[mid] <= tl) lo = mid; else hi = mid - 1;
-        }
-        const long *d = desc + 8 * lo;
-        const float *src = reinterpret_cast<const float *>(d[0]);
-        char *dst = reinterpret_cast<char *>(d[1]);
-        const int K = (int)d[2], R = (int)d[3], S = (int)d[4], Csrc = (int)d[5], Cdst = (int)d[6], mode = (int)d[7];
-        const int rows = mode == 0 ? K : Csrc, red_n = mode == 0 ? Cdst : K, taps = R * S, cch = (red_n + 31) / 32;
-        unsigned *tr = reinterpret_cast<unsigned *>(dst + (long)rows * taps * cch * 128);
-        long q = tl - start[lo];
-        const int cc = (int)(q % cch);
-        q /= cch;
-        const int t = (int)(q % taps);
-        const int rb = (int)(q / taps);  // row block
-        const int r = t / S, s2 = t - r * S;
-        __syncthreads();  // previous tile fully consumed
-        float mx = 0.f;
+    // A block owns a CONTIGUOUS range of 32 x 32 tiles: one binary search for its first tile, after that the table index only moves forward
+    // and the table row stays in registers while the tiles belong to one tensor; the loads of tile i + 1 are issued before tile i is
+    // transposed through LDS and stored.  (The grid-stride form re-read the table and searched it for every tile -- two dependent
+    // global round trips in front of each 4 KB of weights -- and had one tile in flight per block: 1.7 TB/s over the 1 GB a step's refresh moves.)
+    const long per_block = (total_tiles + gridDim.x - 1) / gridDim.x;
+    const long tl_beg = (long)blockIdx.x * per_block, tl_end = tl_beg + per_block < total_tiles ? tl_beg + per_block : total_tiles;
+    if (tl_beg >= tl_end) return;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (start[mid] <= tl_beg) lo = mid; else hi = mid - 1;
+    }
+    struct Ent {
+        const float *src;
+        char *dst;
+        int K, R, S, Csrc, mode, rows, taps, cch;
+        long st0, st1;
+    } ent;
+    auto load_ent = [&](int i) {
+        const long *d = desc + 8 * i;
+        ent.src = reinterpret_cast<const float *>(d[0]);
+        ent.dst = reinterpret_cast<char *>(d[1]);
+        ent.K = (int)d[2]; ent.R = (int)d[3]; ent.S = (int)d[4]; ent.Csrc = (int)d[5]; ent.mode = (int)d[7];
+        const int Cdst = (int)d[6];
+        ent.rows = ent.mode == 0 ? ent.K : ent.Csrc;
+        ent.taps = ent.R * ent.S;
+        ent.cch = ((ent.mode == 0 ? Cdst : ent.K) + 31) / 32;
+        ent.st0 = start[i];
+        ent.st1 = i + 1 < n ? start[i + 1] : total_tiles;
+    };
+    load_ent(lo);
+    struct Dec {
+        char *dst;
+        int rows, taps, cch, cc, t, rb;
+        bool first;
+    };
+    // decode tile tl (advancing the table row if needed) and issue its four loads per thread; values land in tile[][] order: v[p] belongs
+    // to tile[ty + 8 p][tx] (mode 0) or tile[tx][ty + 8 p] (mode 1: the source is read along the operand row, stored transposed)
+    auto fetch = [&](long tl, Dec &dc, float (&v)[4], int &mode) {
+        while (tl >= ent.st1) load_ent(++lo);
+        long q = tl - ent.st0;
+        dc.first = q == 0;
+        dc.cc = (int)(q % ent.cch);
+        q /= ent.cch;
+        dc.t = (int)(q % ent.taps);
+        dc.rb = (int)(q / ent.taps);
+        dc.dst = ent.dst; dc.rows = ent.rows; dc.taps = ent.taps; dc.cch = ent.cch;
+        mode = ent.mode;
+        const int r = dc.t / ent.S, s2 = dc.t - r * ent.S;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int y = ty + 8 * p;
-            float v = 0.f;
-            if (mode == 0) {
-                const int row = rb * 32 + y, e = cc * 32 + tx;
-                if (row < rows && e < Csrc) v = src[(((long)row * R + r) * S + s2) * Csrc + e];
-                tile[y][tx] = v;
+            long idx;
+            bool ok;
+            if (ent.mode == 0) {
+                const int row = dc.rb * 32 + y, e = dc.cc * 32 + tx;
+                ok = row < ent.rows && e < ent.Csrc;
+                idx = (((long)row * ent.R + r) * ent.S + s2) * ent.Csrc + e;
             } else {
-                const int e = cc * 32 + y, row = rb * 32 + tx;
-                if (e < K && row < rows) v = src[(((long)e * R + (R - 1 - r)) * S + (S - 1 - s2)) * Csrc + row];
-                tile[tx][y] = v;
+                const int e = dc.cc * 32 + y, row = dc.rb * 32 + tx;
+                ok = e < ent.K && row < ent.rows;
+                idx = (((long)e * ent.R + (ent.R - 1 - r)) * ent.S + (ent.S - 1 - s2)) * ent.Csrc + row;
             }
-            mx = fmaxf(mx, fabsf(v));
+            const float x = ent.src[ok ? idx : 0];  // (clamped address + select: no branch around the load)
+            v[p] = ok ? x : 0.f;
         }
+    };
+    Dec cur, nxt;
+    float vc[4], vn[4];
+    int mode_c = 0, mode_n = 0;
+    fetch(tl_beg, cur, vc, mode_c);
+    for (long tl = tl_beg; tl < tl_end; ++tl) {
+        const bool more = tl + 1 < tl_end;
+        if (more) fetch(tl + 1, nxt, vn, mode_n);
+        unsigned *tr = reinterpret_cast<unsigned *>(cur.dst + (long)cur.rows * cur.taps * cur.cch * 128);
         if (amax_only) {
+            float mx = fmaxf(fmaxf(fabsf(vc[0]), fabsf(vc[1])), fmaxf(fabsf(vc[2]), fabsf(vc[3])));
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            __syncthreads();  // (red[] of the previous tile consumed)
             if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
             __syncthreads();
             if (threadIdx.x == 0) {
@@ -1181,21 +1231,39 @@ __global__ __launch_bounds__(256) void weight_split2_batch_kernel(const long *__
                 if (!(mx >= 0.f)) mx = __uint_as_float(0x7f800000u);
                 atomicMax(tr + 1, __float_as_uint(mx));
             }
-            continue;
-        }
-        const float scale = x3_scale_of(__uint_as_float(tr[1]));
-        if (tl == start[lo] && threadIdx.x == 0) tr[0] = __float_as_uint(x3_inv_of(scale));
-        __syncthreads();
+        } else {
+            __syncthreads();  // previous tile fully consumed
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int y = ty + 8 * p, row = rb * 32 + y;
-            if (row >= rows) continue;
-            const float v = tile[y][tx] * scale;
-            const _Float16 h = (_Float16)v;
-            const _Float16 l = (_Float16)(v - (float)h);
-            _Float16 *o = reinterpret_cast<_Float16 *>(dst) + (((long)row * taps + t) * cch + cc) * 64 + tx;
-            o[0] = h;
-            o[32] = l;
+            for (int p = 0; p < 4; ++p) {
+                if (mode_c == 0) tile[ty + 8 * p][tx] = vc[p];
+                else tile[tx][ty + 8 * p] = vc[p];
+            }
+            const float scale = x3_scale_of(__uint_as_float(tr[1]));
+            if (cur.first && threadIdx.x == 0) tr[0] = __float_as_uint(x3_inv_of(scale));
+            __syncthreads();
+            {   // 8 threads per operand row, four values each: one 8-byte store of high parts, one of low parts (was 2-byte stores)
+                const int c4 = threadIdx.x & 7, y = threadIdx.x >> 3, row = cur.rb * 32 + y;
+                if (row < cur.rows) {
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                    h4 hi4, lo4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = tile[y][4 * c4 + j] * scale;
+                        const _Float16 h = (_Float16)v;
+                        hi4[j] = h;
+                        lo4[j] = (_Float16)(v - (float)h);
+                    }
+                    _Float16 *o = reinterpret_cast<_Float16 *>(cur.dst) + (((long)row * cur.taps + cur.t) * cur.cch + cur.cc) * 64 + 4 * c4;
+                    *reinterpret_cast<h4 *>(o) = hi4;
+                    *reinterpret_cast<h4 *>(o + 32) = lo4;
+                }
+            }
+        }
+        if (more) {
+            cur = nxt;
+            mode_c = mode_n;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) vc[p] = vn[p];
         }
     }
 }
