@@ -400,8 +400,14 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
     if use_graph:
         from dass_hip.graph import GraphedStep
 
+        def capturable_step():
+            # (DASS_BENCH_GRAPH_FAULT=1: a fault injected INSIDE the capture, to rehearse the fallback below on a real GPU)
+            if os.environ.get("DASS_BENCH_GRAPH_FAULT") == "1" and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("injected capture fault (DASS_BENCH_GRAPH_FAULT=1)")
+            return train_step()
+
         try:
-            timed_step = GraphedStep(train_step, warmup=2)   # zero_grad + forward + loss + backward + SGD as ONE graph launch
+            timed_step = GraphedStep(capturable_step, warmup=2)   # zero_grad + forward + loss + backward + SGD as ONE graph launch
             for _ in range(2):
                 timed_step()
             torch.cuda.synchronize()

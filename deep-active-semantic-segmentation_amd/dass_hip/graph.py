@@ -8,8 +8,9 @@ What makes the library's step capturable (each of these is host-side state that 
     (ops.graph_capture_begin), so their memsets are graph nodes and every replay starts from zeros;
   * the grouped weight-gradient launch stages its problem table in pinned host memory that a captured copy node reads at every replay:
     slots used inside a capture are never recycled (csrc/wgrad_x3.hip);
-  * the chunked weight gradients stay on the caller's stream while capturing (ops._wgrad_flush), nothing synchronises or allocates
-    through the driver, and the launch profile (csrc/prof.hip) must be closed.
+  * the side stream of the chunked weight gradients joins the capture through its fork event and re-joins at the next flush
+    (ops._wgrad_flush; DASS_WGRAD_SIDE_CAPTURE=0: one stream inside the graph), nothing synchronises or allocates through the
+    driver, and the launch profile (csrc/prof.hip) must be closed.
 The captured step reads its inputs from the tensors the callable closed over: copy new batches INTO them (static inputs), as with any
 CUDA graph.  Reference loop: active_train.py:103-107."""
 import torch
