@@ -389,7 +389,9 @@ static int launch_dw_strip(const float *in, long ldi, const float *w, float *out
     if ((long)N * IH * IW * ldi >= (1l << 31) || (long)N * OH * OW * ldo >= (1l << 31)) return 0;
     const int cblocks = (C + 63) / 64, nsegw = (OW + 15) / 16, seg = (OW + nsegw - 1) / nsegw;
     const long nstrips = (long)N * OH * nsegw;
-    long gy = (2048 + cblocks - 1) / cblocks;
+    // (launches that end in per-channel atomics -- MODE 1 / 2 -- get fewer, longer blocks: DASS_DW_SUM_BLOCKS)
+    static const long sum_target = getenv("DASS_DW_SUM_BLOCKS") ? atol(getenv("DASS_DW_SUM_BLOCKS")) : 2048;
+    long gy = ((MODE != 0 ? sum_target : 2048) + cblocks - 1) / cblocks;
     if (gy > (nstrips + 15) / 16) gy = (nstrips + 15) / 16;
     const dim3 grid(cblocks, (unsigned)(gy < 1 ? 1 : gy));
 #define DASS_DW_CS(D, S)                                                                                                                   \
