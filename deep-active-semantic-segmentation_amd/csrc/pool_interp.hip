@@ -324,6 +324,57 @@ __global__ void bilinear_bwd_nchw_kernel(const float *__restrict__ dy, T *__rest
     }
 }
 
+// The same gather for the network's own case -- logits 129 -> 513 (193 -> 769): OH - 1 = 4 (IH - 1), align_corners -- where the source
+// coordinate of output o is exactly o / 4: input pixel i gathers outputs 4 i - 3 .. 4 i + 3 with weights 1 - |d| / 4.  The general kernel
+// derives every tap's weight from lerp_of / lerp_weight and issues 49 scalar loads behind two skip tests; here the weights are constants
+// and a thread reads each of its <= 7 rows as two 16-byte loads (rows of 513 floats are only dword-aligned: packed struct).  Products are
+// added in the general kernel's order (rows ascending, columns ascending, zero-weight taps skipped); where the compiler contracts a multiply-add
+// into an fma differs, so the two agree to the last bits, not bit for bit (tests/test_stem_gpu.py: 1e-6, and 1e-5 against f64 autograd).
+struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
+
+template <typename T>
+__global__ void bilinear_bwd_nchw_r4_kernel(const float *__restrict__ dy, T *__restrict__ dx, long lddx, int N, int IH, int IW, int C,
+                                            int OH, int OW) {
+    const long total = (long)N * C * IH * IW;
+    const long ohw = (long)OH * OW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ix = (int)(i % IW);
+        long t = i / IW;
+        const int iy = (int)(t % IH);
+        t /= IH;
+        const int c = (int)(t % C);
+        const long n = t / C;
+        const float *plane = dy + (n * C + c) * ohw;
+        const bool left = ix > 0, right = ix < IW - 1;
+        float g = 0.f;
+#pragma unroll
+        for (int d = -3; d <= 3; ++d) {
+            const int oy = 4 * iy + d;
+            if (oy < 0 || oy >= OH) continue;
+            const float wy = 1.f - 0.25f * (float)(d < 0 ? -d : d);
+            const float *rowp = plane + (long)oy * OW + 4 * ix;
+            f4u a = {{0.f, 0.f, 0.f, 0.f}}, b = a;
+            if (left) a = *reinterpret_cast<const f4u *>(rowp - 4);
+            if (right) b = *reinterpret_cast<const f4u *>(rowp);
+            else b.v[0] = rowp[0];
+            float row = 0.f;
+            if (left) {
+                row += a.v[1] * 0.25f;
+                row += a.v[2] * 0.5f;
+                row += a.v[3] * 0.75f;
+            }
+            row += b.v[0] * 1.f;
+            if (right) {
+                row += b.v[1] * 0.75f;
+                row += b.v[2] * 0.5f;
+                row += b.v[3] * 0.25f;
+            }
+            g += row * wy;
+        }
+        Elem<T>::st(dx + ((n * IH + iy) * IW + ix) * lddx + c, g);
+    }
+}
+
 }  // namespace
 
 #define DASS_DISPATCH(DT, KERNEL_F32, KERNEL_BF16) \
@@ -465,6 +516,12 @@ extern "C" int dass_bilinear_bwd(const void *dy, int64_t lddy, void *dx, int64_t
     hipStream_t st = (hipStream_t)stream;
     if (dy_nchw) {
         const int grid = dass_grid_1d((long)N * C * IH * IW, 256);
+        const char *r4 = getenv("DASS_BILINEAR_R4");  // (0: the general gather, for A/B tests)
+        if (IH > 1 && IW > 1 && OH - 1 == 4 * (IH - 1) && OW - 1 == 4 * (IW - 1) && !(r4 && r4[0] == '0')) {
+            DASS_DISPATCH(dtype,
+                          DASS_LAUNCH(bilinear_bwd_nchw_r4_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)dy, (float *)dx, lddx, N, IH, IW, C, OH, OW),
+                          DASS_LAUNCH(bilinear_bwd_nchw_r4_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const float *)dy, (bf16_t *)dx, lddx, N, IH, IW, C, OH, OW))
+        }
         DASS_DISPATCH(dtype,
                       DASS_LAUNCH(bilinear_bwd_nchw_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)dy, (float *)dx, lddx, N, IH, IW, C, OH, OW, sh, sw),
                       DASS_LAUNCH(bilinear_bwd_nchw_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const float *)dy, (bf16_t *)dx, lddx, N, IH, IW, C, OH, OW, sh, sw))

@@ -325,3 +325,38 @@ def test_depthwise_forward_sums_kernel_vs_f64(shape):
     got = sums.reshape(2, c).cpu()
     for i in range(2):
         assert (got[i] - ref[i]).abs().max().item() <= 1e-5 * ref[i].abs().max().item(), i
+
+
+@pytest.mark.parametrize("shape", [(2, 19, 33, 33), (1, 21, 129, 129), (3, 4, 5, 9), (2, 19, 2, 2)])
+def test_bilinear_backward_ratio4_kernel_equals_general_gather(shape):
+    """dass_bilinear_bwd, NCHW gradient of the x4 align_corners upsampling of the logits (deeplab.py:45: 129 -> 513): the constant-weight
+    kernel against the general gather (DASS_BILINEAR_R4=0) to the last bits (1e-6), and against autograd of F.interpolate in f64 (1e-5 of the largest value)"""
+    from dass_hip._lib import lib
+
+    n, c, ih, iw = shape
+    oh, ow = 4 * (ih - 1) + 1, 4 * (iw - 1) + 1
+    g = torch.Generator().manual_seed(21)
+    dy = torch.randn(n, c, oh, ow, generator=g)
+    dyd = dy.cuda()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    cp = (c + 3) // 4 * 4
+    out = {}
+    keep = os.environ.get("DASS_BILINEAR_R4")
+    try:
+        for mode in ("1", "0"):
+            os.environ["DASS_BILINEAR_R4"] = mode
+            dx = torch.zeros((n, ih, iw, cp), device="cuda")
+            assert lib.dass_bilinear_bwd(_p(dyd), 0, _p(dx), cp, n, ih, iw, c, oh, ow, 1, 0, st) == 0
+            torch.cuda.synchronize()
+            out[mode] = dx.cpu()
+    finally:
+        if keep is None:
+            os.environ.pop("DASS_BILINEAR_R4", None)
+        else:
+            os.environ["DASS_BILINEAR_R4"] = keep
+    # (same products in the same order; where the compiler contracts a multiply-add into an fma differs between the two kernels: last-bit differences)
+    assert (out["1"] - out["0"]).abs().max().item() <= 1e-6 * out["0"].abs().max().item()
+    x = torch.zeros(n, c, ih, iw, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.interpolate(x, size=(oh, ow), mode="bilinear", align_corners=True).backward(dy.double())
+    got = out["1"][..., :c].permute(0, 3, 1, 2).double()
+    assert (got - x.grad).abs().max().item() <= 1e-5 * x.grad.abs().max().item()
