@@ -10,7 +10,8 @@ A "step" is one pass of the hot path over one synthetic batch: zero_grad -> forw
 (the configuration BASELINE.json's metric is quoted on).  Inputs are generated
 from per-image seeds and are resident in HBM before the timed region.  W untimed warm-up steps, then
 EXACTLY K timed steps between barrier + synchronize; the max over ranks is reported by rank 0 as ONE
-JSON line.  The headline (`value`, `dtype`) is the f32 PARITY mode -- the mode every parity test runs in
+JSON line of < 4 KB (`compact_line`); every table behind it (per-kernel, per-pass, per-mode) goes to `bench_detail.json` (under gpurun_out/
+when that directory exists, else the repo root) and the progress log to stderr.  The headline (`value`, `dtype`) is the f32 PARITY mode -- the mode every parity test runs in
 (f32 tensors end to end, logits within 1e-3 of the reference, argmax bit-exact).  Its dense convs run the "f16x3" engine
 (`config.f32_mma`): every operand tensor is scaled by a power of two and split into two f16 parts (23 significant bits), three
 MFMA products per f32 product on the f16 pipe, f32 accumulation (dass_hip/ops.py:set_f32_mma) -- the f32 product to 2^-22, and
@@ -21,15 +22,13 @@ line; a WORLD_SIZE that contradicts --gpus is an error.  The same line carries
                 per rank (config D's per-GPU share of the 2975-image pool is 372),
   core_set    : config E -- pooled decoder features of the same pool shard (images/s) and the k-center greedy selection
                 (k = 125, 50 pre-selected) on a [2975, 2736] feature matrix (seconds),
-  roofline    : `frac` / `achieved` = the conv launches of the TIMED train step itself: after the timed region three more steps
-                run with HIP events around every conv / weight-gradient entry point of the C-ABI, recorded on the stream each
-                launch goes to (dass_hip/_lib.py:KernelTimer); achieved = algorithmic conv FLOPs of the step / the SUM of those
-                launch durations (launches on the main and the side stream overlap: summed, as in a rocprofv3 kernel table --
-                profiles/r04_train_summary.md is that table for the same command), `by_kernel` splits it by entry point and tile
-                class, `dominant` is the class with the most time.  `isolated` keeps the former microbenchmark (every layer shape
-                launched back to back on an idle chip: a ceiling, not what the step achieves), `best_launch` the single best-case
-                launch (decoder 3x3 304->256 @129^2), `sustained` the same fractions against the MFMA rate the chip actually holds
-                under an all-CU MFMA load (profiles/r02_clock_probe.json), `train_step_frac` the whole step against the peak,
+  roofline    : `kernel` / `achieved` / `frac` = the DOMINANT conv kernel of the TIMED train step, named by its symbol (the one a rocprofv3
+                kernel table names): after the timed region three more steps run with a start / stop HIP event pair bound to every dispatch
+                of the library, on the stream it is launched on (dass_hip/_lib.py:KernelTimer); achieved = algorithmic GFLOP of that kernel's
+                launches / the sum of their durations (= GFLOP per launch / average launch duration), peak = the dense MFMA peak of the
+                engine per algorithmic flop, `traffic` = its HBM bytes per launch from the committed --pmc passes.  `conv_family_frac` is the
+                same quotient over every conv / weight-gradient launch, `train_step_frac` the whole step against the peak, `t_lb_ms` /
+                `mixed_frac` SURVEY 8(d)'s mixed per-layer bound sum max(FLOPs / peak, bytes / 8 TB/s) and its share of the measured step,
   cpu_baseline: the CPU oracle (stock PyTorch fp32 restatement, oracle/) timed on this box's host cores on bounded
                 samples (rank 0, N=1 only): (i) train steps, (ii) 10-pass MC-dropout the reference way (T full forwards)
                 and with the deterministic prefix hoisted, (iii) core-set features + sklearn fp64 k-center on the SAME
@@ -58,8 +57,9 @@ PEAK_NOTE = {"f32": "f32 MFMA dense", "bf16x6": "bf16 MFMA dense 2500 / 6 produc
              "bf16x3": "bf16 MFMA dense 2500 / 3 products per f32 product",
              "f16x3": "f16 MFMA dense 2500 / 3 products per f32 product (two scaled f16 parts per operand)", "bf16": "bf16 MFMA dense",
              "bf16x1": "bf16 MFMA dense (one bf16 part per operand, one product: a perf engine on f32 tensors, not parity-grade)"}
-TRAIN_GFLOP_PER_IMAGE = 556.9  # 3 x 92.81 GMAC x 2 (R101 os16 513^2)
-MC_GFLOP_PER_IMAGE = 573.6     # 2 x (71.26 + 10 x 21.55) GMAC, T=10
+HBM_PEAK_TBS = 8.0
+DETAIL_FILE = "bench_detail.json"
+LINE_LIMIT = 4096  # the driver keeps ~8 KB of stdout: the final JSON line stays below half of that (tests/test_cpu.py)
 
 
 def parse():
@@ -118,9 +118,9 @@ class Env(object):
     pass
 
 
-def r101_conv_layers(batch, size):
+def r101_conv_layers(batch, size, blocks3=23):
     """(count, N, H, W, C, K, ksize, stride, pad, dil) of every groups=1 conv of DeepLab-R101 os16, stem excluded
-    (3 input channels: a separate row-tap kernel, 0.7 % of the FLOPs)"""
+    (3 input channels: a separate row-tap kernel, 0.7 % of the FLOPs) and without the 19-class classifier; blocks3 = 6: ResNet-50"""
     s2 = (size + 1) // 2
     s4 = (s2 + 1) // 2
     s8 = (s4 + 1) // 2
@@ -131,7 +131,7 @@ def r101_conv_layers(batch, size):
             (1, b, s4, s4, 256, 128, 1, 1, 0, 1), (1, b, s4, s4, 128, 128, 3, 2, 1, 1), (1, b, s4, s4, 256, 512, 1, 2, 0, 1),
             (3, b, s8, s8, 512, 128, 1, 1, 0, 1), (3, b, s8, s8, 128, 128, 3, 1, 1, 1), (4, b, s8, s8, 128, 512, 1, 1, 0, 1),
             (1, b, s8, s8, 512, 256, 1, 1, 0, 1), (1, b, s8, s8, 256, 256, 3, 2, 1, 1), (1, b, s8, s8, 512, 1024, 1, 2, 0, 1),
-            (22, b, s16, s16, 1024, 256, 1, 1, 0, 1), (22, b, s16, s16, 256, 256, 3, 1, 1, 1), (23, b, s16, s16, 256, 1024, 1, 1, 0, 1),
+            (blocks3 - 1, b, s16, s16, 1024, 256, 1, 1, 0, 1), (blocks3 - 1, b, s16, s16, 256, 256, 3, 1, 1, 1), (blocks3, b, s16, s16, 256, 1024, 1, 1, 0, 1),
             (1, b, s16, s16, 1024, 512, 1, 1, 0, 1), (2, b, s16, s16, 2048, 512, 1, 1, 0, 1), (1, b, s16, s16, 512, 512, 3, 1, 2, 2),
             (1, b, s16, s16, 512, 512, 3, 1, 4, 4), (1, b, s16, s16, 512, 512, 3, 1, 8, 8), (3, b, s16, s16, 512, 2048, 1, 1, 0, 1),
             (1, b, s16, s16, 1024, 2048, 1, 1, 0, 1),
@@ -178,6 +178,98 @@ def mobilenet_train_bytes(batch, size, classes):
     conv_e += batch * (24 + 48) * low_h * low_h + batch * (304 + 256) * low_h * low_h + batch * 512 * low_h * low_h + batch * (256 + classes) * low_h * low_h
     bn_e += batch * (48 + 512) * low_h * low_h
     return 3 * conv_e * 4 + 4 * bn_e * 4, conv_e, bn_e
+
+
+def _out(h, k, s, p, d):
+    return (h + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+def mobilenet_gmac(size, classes):
+    """forward GMAC per image of DeepLab-MobileNetV2 os16 (27.07 at 513^2, 21 classes)"""
+    h = _out(size, 3, 2, 1, 1)
+    m = h * h * 32 * 27
+    cin, cur, rate, low_h = 32, 2, 1, None
+    for t, c, n, s_ in [(1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1)]:
+        if cur == 16:
+            stride, dil = 1, rate
+            rate *= s_
+        else:
+            stride, dil = s_, 1
+            cur *= s_
+        for i in range(n):
+            st = stride if i == 0 else 1
+            hid, hp = cin * t, h + 2 * dil
+            if t != 1:
+                m += hp * hp * cin * hid
+            ho = _out(hp, 3, st, 0, dil)
+            m += ho * ho * hid * 9 + ho * ho * hid * c
+            cin, h = c, ho
+        if c == 24:
+            low_h = h
+    m += h * h * 320 * 256 * 28 + 320 * 256 + h * h * 1280 * 256
+    return (m + low_h * low_h * (24 * 48 + 304 * 256 * 9 + 256 * 256 * 9 + 256 * classes)) / 1e9
+
+
+def work_model(backbone, size, classes, T=10):
+    """ALGORITHMIC work per image, derived from --backbone / --size / --classes (SURVEY.md 8d's figures at its sizes: R101 513^2
+    92.81 GMAC forward = 556.9 GFLOP per trained image, 769^2: 1233.8; MobileNetV2 513^2 21 classes: 162.4; MC-dropout = prefix once
+    + T x last_conv tail = 573.6 GFLOP at R101 513^2 T=10; core-set features = the prefix = 142.5)"""
+    s4 = ((size + 1) // 2 + 1) // 2
+    tail = s4 * s4 * (304 * 256 * 9 + 256 * 256 * 9 + 256 * classes) / 1e9
+    if backbone == "mobilenet":
+        fwd = mobilenet_gmac(size, classes)
+    else:
+        s2 = (size + 1) // 2
+        fwd = s2 * s2 * 64 * 147 / 1e9 + s4 * s4 * 256 * classes / 1e9
+        for cnt, n, h, w, c, k, ks, st, pad, dil in r101_conv_layers(1, size, 6 if backbone == "resnet" else 23):
+            oh = _out(h, ks, st, pad, dil)
+            fwd += cnt * oh * oh * k * ks * ks * c / 1e9
+    return {"forward_gflop": 2 * fwd, "train_gflop": 6 * fwd, "mc_gflop": 2 * ((fwd - tail) + T * tail), "coreset_gflop": 2 * (fwd - tail)}
+
+
+def mixed_roofline(args, peak_tflops):
+    """SURVEY.md 8(d)'s bounding roofline of one train step: t_lb = sum over layers and passes of max(FLOPs / peak_MFMA, bytes / peak_HBM).
+    Per conv layer three passes (forward, input gradient, weight gradient), each 2 M K R S C FLOP against (E_in + E_out) x 4 B + the
+    weights; per train-mode BN tensor four passes of 2 x 4 B per element (SURVEY 8d "BN train traffic 2 x (2 x elems)").  f32 tensors.
+    -> {t_lb_ms, conv_ms, bn_ms, conv_gb, bn_gb, mfma_bound_layers, layers}"""
+    b, size = args.batch, args.size
+    if args.backbone == "mobilenet":
+        nbytes, conv_e, bn_e = mobilenet_train_bytes(b, size, args.classes)
+        # depthwise / pointwise layers are HBM-bound one and all at these widths except the ASPP / decoder 3x3s: price the whole net
+        # by bytes and add the MFMA time of the dense 3x3 layers where it exceeds their bytes
+        h16, h4 = ((((size + 1) // 2 + 1) // 2 + 1) // 2 + 1) // 2, ((size + 1) // 2 + 1) // 2
+        dense = [(3, b * h16 * h16, 320 * 9, 256), (1, b * h4 * h4, 304 * 9, 256), (1, b * h4 * h4, 256 * 9, 256)]
+        extra, nm = 0.0, 0
+        for cnt, m, red, k in dense:
+            t_f = 2.0 * m * red * k / (peak_tflops * 1e12)
+            t_b = (m * (red // 9 + k) * 4.0 + red * k * 4.0) / (HBM_PEAK_TBS * 1e12)
+            if t_f > t_b:
+                extra += 3 * cnt * (t_f - t_b)
+                nm += cnt
+        conv_ms = 3 * conv_e * 4 / (HBM_PEAK_TBS * 1e9) + extra * 1e3
+        bn_ms = 4 * bn_e * 4 / (HBM_PEAK_TBS * 1e9)
+        return {"t_lb_ms": round(conv_ms + bn_ms, 3), "conv_ms": round(conv_ms, 3), "bn_ms": round(bn_ms, 3), "conv_gb": round(3 * conv_e * 4 / 1e9, 2),
+                "bn_gb": round(4 * bn_e * 4 / 1e9, 2), "mfma_bound_layers": nm, "layers": 61}
+    s2 = (size + 1) // 2
+    s4 = (s2 + 1) // 2
+    layers = [(1, b, size, size, 3, 64, 7, 2, 3, 1)] + r101_conv_layers(b, size, 6 if args.backbone == "resnet" else 23) + [(1, b, s4, s4, 256, args.classes, 1, 1, 0, 1)]
+    conv_s = conv_b = bn_e = 0.0
+    nm = nl = 0
+    for cnt, n, h, w, c, k, ks, st, pad, dil in layers:
+        oh = _out(h, ks, st, pad, dil)
+        flops = 2.0 * n * oh * oh * k * ks * ks * c
+        nbytes = (n * h * h * c + n * oh * oh * k + k * ks * ks * c) * 4.0
+        t_f, t_b = flops / (peak_tflops * 1e12), nbytes / (HBM_PEAK_TBS * 1e12)
+        conv_s += 3 * cnt * max(t_f, t_b)
+        conv_b += 3 * cnt * nbytes
+        nm += cnt * (t_f > t_b)
+        nl += cnt
+        if k != args.classes:
+            bn_e += cnt * n * oh * oh * k
+    bn_b = 4 * bn_e * 4.0
+    return {"t_lb_ms": round((conv_s + bn_b / (HBM_PEAK_TBS * 1e12)) * 1e3, 3), "conv_ms": round(conv_s * 1e3, 3),
+            "bn_ms": round(bn_b / (HBM_PEAK_TBS * 1e9), 3), "conv_gb": round(conv_b / 1e9, 2), "bn_gb": round(bn_b / 1e9, 2),
+            "mfma_bound_layers": nm, "layers": nl}
 
 
 def conv_aggregate(args, ops, tdt):
@@ -292,6 +384,7 @@ def step_conv_times(train_step, reps=3):
             train_step()
         torch.cuda.synchronize()
         kernels, calls = kt.results()
+        call_kernel_ms = {id(c[4]): [k[1] for k in kernels[i0:i1]] for c, (_, _, _, i0, i1) in zip(calls, kt.calls)}
     by, bn = {}, {}
     for name, tag, work, ms, knames in calls:
         d = bn if name in BN_ENTRY_POINTS else by
@@ -308,16 +401,35 @@ def step_conv_times(train_step, reps=3):
                 for k, v in bn.items()]
     bn_table.sort(key=lambda r: -r["ms_per_step"])
     conv = [c for c in calls if c[0] not in BN_ENTRY_POINTS]
+
+    def short_name(kname):
+        return re.sub(r"^void ", "", re.sub(r"\(anonymous namespace\)::", "", kname)).split("(")[0].replace(", ", ",")
+
+    # the same conv calls by KERNEL SYMBOL: a call's GFLOP and time go to the kernel that took most of the call's time (its fix-up /
+    # phase launches ride along), so that "dominant" names what a rocprofv3 kernel table names
+    sym = {}
+    for name, tag, work, ms, knames in conv:
+        durs = {}
+        for kn, kms in zip(knames, call_kernel_ms[id(knames)]):
+            durs[kn] = durs.get(kn, 0.0) + kms
+        main = short_name(max(durs, key=durs.get)) if durs else name
+        e = sym.setdefault(main, [0, 0.0, 0.0])
+        e[0] += 1
+        e[1] += work
+        e[2] += ms
+    sym_table = [{"kernel": k, "launches_per_step": round(v[0] / reps, 1), "gflop_per_step": round(v[1] / reps, 1), "ms_per_step": round(v[2] / reps, 3),
+                  "avg_us": round(1e3 * v[2] / v[0], 1), "gflop_per_launch": round(v[1] / v[0], 3), "tflops": round(v[1] / v[2], 1) if v[2] > 0 else None}
+                 for k, v in sym.items()]
+    sym_table.sort(key=lambda r: -r["ms_per_step"])
     kt_by = {}
     for kname, ms, grid, stream in kernels:
-        short = re.sub(r"\(anonymous namespace\)::", "", kname)
-        short = re.sub(r"^void ", "", short).split("(")[0]
-        e = kt_by.setdefault(short, [0, 0.0])
+        e = kt_by.setdefault(short_name(kname), [0, 0.0])
         e[0] += 1
         e[1] += ms
     ktable = [{"kernel": k, "launches_per_step": round(v[0] / reps, 1), "ms_per_step": round(v[1] / reps, 3), "avg_us": round(1e3 * v[1] / v[0], 1)}
               for k, v in sorted(kt_by.items(), key=lambda kv: -kv[1][1])]
     return {"gflop": sum(c[2] for c in conv) / reps, "ms": sum(c[3] for c in conv) / reps, "launches": len(conv) / reps, "table": table,
+            "by_symbol": sym_table,
             "bn": bn_table, "bn_ms": sum(r["ms_per_step"] for r in bn_table), "bn_gb": sum(r["gb_per_step"] for r in bn_table),
             "kernels": ktable[:16], "kernel_ms": sum(k[1] for k in kernels) / reps, "kernel_launches": len(kernels) / reps,
             "streams": len({k[3] for k in kernels})}
@@ -333,6 +445,7 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
     from dass_hip.dist import GradientAverager, average_gradients
 
     rank, world, dev, dist = env.rank, env.world, env.dev, env.dist
+    wm = work_model(args.backbone, args.size, args.classes, args.mc_steps)
     ops.set_compute_dtype(torch.float32 if dtype_name == "f32" else torch.bfloat16)
     engine = mma if dtype_name == "f32" else "bf16"
     ops.set_f32_mma(mma)
@@ -466,7 +579,7 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
                      "pool_note": "per-rank pool = config D's 8-GPU share (2975 / 8 = 372, rounded up to whole batches); throughput is per image, "
                                   "so one GPU scores the whole 2975-image pool in 2975 / value seconds",
                      "scoring_batch": b, "seconds": round(dts, 4), "selected": len(selected),
-                     "frac_of_mfma_peak": round(pool_ips * MC_GFLOP_PER_IMAGE / 1e3 / (MFMA_PEAK_TFLOPS[engine] * world), 4),
+                     "frac_of_mfma_peak": round(pool_ips * wm["mc_gflop"] / 1e3 / (MFMA_PEAK_TFLOPS[engine] * world), 4),
                      "sharding": "contiguous key shards per rank + RCCL all_gather of per-image scores" if world > 1 else "single rank"}
 
         # -------------------------------------------------------------- config E: core-set features + k-center greedy
@@ -506,7 +619,7 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
                                           "picks": [int(i) for i in picks.tolist()],
                                           "hbm_gb_per_s": round(175 * 2975 * 2736 * 4 / dtk / 1e9, 1)},
                               "selection_2975_pool_seconds_at_this_gpu_count": round(2975.0 / feat_ips + dtk, 3),
-                              "frac_of_mfma_peak": round(feat_ips * 142.5 / 1e3 / (MFMA_PEAK_TFLOPS[engine] * world), 4)}
+                              "frac_of_mfma_peak": round(feat_ips * wm["coreset_gflop"] / 1e3 / (MFMA_PEAK_TFLOPS[engine] * world), 4)}
 
     b = args.batch  # (the scoring legs may have used --mc-batch)
     # ------------------------------------------------------------------ roofline of the dominant kernel
@@ -520,9 +633,11 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
         gbs = nbytes / (res["ms_per_step"] * 1e-3) / 1e9
         res["roofline"] = {"bound": "hbm", "kernel": "whole train step (61 conv layers: depthwise 3x3, pointwise 1x1, BN passes)", "achieved": round(gbs, 1),
                            "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": None,
-                           "algorithmic_bytes_per_step": nbytes,
+                           "algorithmic_bytes_per_step": nbytes, "mixed": dict(mixed_roofline(args, MFMA_PEAK_TFLOPS[engine]), frac_of_step=None),
+                           "train_step_frac": round(res["train_ips"] * wm["train_gflop"] / 1e3 / (MFMA_PEAK_TFLOPS[engine] * world), 4),
                            "note": "f32 tensors; 3 x (in + out) x 4 B per conv layer and pass + 4 BN passes per train-mode BN tensor (SURVEY 8d); "
-                                   "per-family kernel times: profiles/r03_train_C_mbv2_summary.md"}
+                                   "per-family kernel times: profiles/r04_train_C_mbv2_summary.md"}
+        res["roofline"]["mixed"]["frac_of_step"] = round(res["roofline"]["mixed"]["t_lb_ms"] / res["ms_per_step"], 4)
     elif rank == 0 and inst is not None:
         tdt = torch.bfloat16 if engine == "bf16" else torch.float32
         n_, h_, c_, k_ = b, (s + 3) // 4, 304, 256  # decoder.last_conv.0: 3x3 304->256 @129^2, the largest single layer
@@ -591,34 +706,54 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
                          "best_launch_frac": round(achieved / speak, 4),
                          "note": "bf16 MFMA rate at the shader clock the chip holds with all 256 CUs in an LDS-fed MFMA loop "
                                  "(tools/clock_probe.py, profiles/r02_clock_probe.json); the nominal peak assumes 2.4 GHz"}
-        dom = inst["table"][0]
+        dom = inst["by_symbol"][0]
+        mixed = mixed_roofline(args, peak)
+        mixed["frac_of_step"] = round(mixed["t_lb_ms"] / res["ms_per_step"], 4)
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this command (tools/pmc_bytes.py ->
+        # profiles/r05_pmc_dominant.json: {engine: {kernel symbol: bytes per launch}}); null when no pass exists for this engine / kernel
+        dom_traffic, dfile = None, os.path.join(ROOT, "profiles", "r05_pmc_dominant.json")
+        if os.path.exists(dfile):
+            dom_traffic = json.load(open(dfile)).get(engine, {}).get(dom["kernel"])
+        dom_ach = dom["tflops"] or 0.0
+        log("[%s] dominant kernel by symbol: %s, %.1f launches x %.1f us = %.2f ms/step, %.1f TFLOP/s = %.3f of %.1f; mixed roofline bound of the step %.2f ms "
+            "(conv %.2f + BN %.2f) = %.3f of the measured step" % (dtype_name, dom["kernel"], dom["launches_per_step"], dom["avg_us"], dom["ms_per_step"],
+                                                                   dom_ach, dom_ach / peak, peak, mixed["t_lb_ms"], mixed["conv_ms"], mixed["bn_ms"], mixed["frac_of_step"]))
         res["roofline"] = {"bound": "mfma",
-                           "kernel": "every conv / weight-gradient kernel of the train step itself (3 steps after the timed region with a start / stop "
-                                     "HIP event pair bound to each dispatch on its own stream, csrc/prof.hip; durations of overlapping launches summed, "
-                                     "as in the rocprofv3 kernel table profiles/r04_train_summary.md)",
-                           "achieved": round(in_step, 2), "peak": peak, "peak_note": PEAK_NOTE[engine], "unit": "TFLOP/s",
-                           "frac": round(in_step / peak, 4), "traffic": traffic,
-                           "traffic_note": "HBM bytes of the best_launch shape from the committed rocprofv3 --pmc passes (%s)" % os.path.basename(tfile),
+                           "kernel": dom["kernel"],
+                           "kernel_note": "the conv kernel SYMBOL with the most time in the train step itself (3 steps after the timed region with a start / "
+                                          "stop HIP event pair bound to each dispatch on its own stream, csrc/prof.hip); achieved = the algorithmic GFLOP of "
+                                          "its launches / the sum of their durations = GFLOP per launch / average launch duration",
+                           "achieved": round(dom_ach, 2), "peak": peak, "peak_note": PEAK_NOTE[engine], "unit": "TFLOP/s",
+                           "frac": round(dom_ach / peak, 4), "traffic": dom_traffic,
+                           "traffic_note": "HBM bytes per launch of the dominant kernel (FETCH_SIZE / WRITE_SIZE passes, profiles/r05_pmc_dominant.json)",
+                           "dominant": {"kernel": dom["kernel"], "launches_per_step": dom["launches_per_step"], "ms_per_step": dom["ms_per_step"],
+                                        "avg_us": dom["avg_us"], "gflop_per_launch": dom["gflop_per_launch"], "achieved": dom["tflops"],
+                                        "frac": round(dom_ach / peak, 4)},
+                           "conv_family": {"note": "every conv / weight-gradient launch of the step, durations of overlapping launches summed as in the rocprofv3 "
+                                                   "kernel table (profiles/r05_train_summary.md)",
+                                           "achieved": round(in_step, 2), "frac": round(in_step / peak, 4)},
+                           "mixed": mixed,
+                           "best_launch_traffic": traffic,
+                           "best_launch_traffic_note": "HBM bytes of the best_launch shape from the committed rocprofv3 --pmc passes (%s)" % os.path.basename(tfile),
                            "conv_ms_per_step": round(inst["ms"], 3), "conv_gflop_per_step": round(inst["gflop"], 1),
                            "conv_launches_per_step": round(inst["launches"], 1),
                            "conv_ceiling_ms_per_step": round(inst["gflop"] / peak, 3),
+                           "by_symbol": inst["by_symbol"],
                            "by_kernel": inst["table"],
                            "bn_passes": {"note": "train-mode BN apply / backward passes of the same steps: ALGORITHMIC bytes (every [M][K] tensor a call "
                                                  "reads or writes, 4 B per element; gate bits 1 B per 4) / kernel time, against HBM3E 8 TB/s; counter "
-                                                 "bytes: profiles/r04_pmc_bn.txt",
+                                                 "bytes: profiles/r05_pmc_bytes.txt (r04_pmc_bytes.txt for round 4)",
                                          "ms_per_step": round(inst["bn_ms"], 3), "gb_per_step": round(inst["bn_gb"], 3),
                                          "tb_per_s": round(inst["bn_gb"] / max(inst["bn_ms"], 1e-9), 3), "passes": inst["bn"]},
                            "step_kernels": {"kernel_ms_per_step": round(inst["kernel_ms"], 3), "launches_per_step": round(inst["kernel_launches"], 1),
                                             "streams": inst["streams"], "top": inst["kernels"]},
-                           "dominant": {"kernel": dom["kernel"], "ms_per_step": dom["ms_per_step"], "avg_us": dom["avg_us"],
-                                        "achieved": dom["tflops"], "frac": round(dom["tflops"] / peak, 4) if dom["tflops"] else None},
                            "isolated": {"note": "every layer shape launched 5x back to back on an idle chip, operands prepared outside the timing: a "
                                                 "ceiling for the kernels, NOT what the step achieves",
                                         "achieved": agg["achieved"], "frac": round(agg["achieved"] / peak, 4), "conv_ms_per_step": agg["ms_per_step"],
                                         "conv_gflop_per_step": agg["gflop"],
                                         "split_ms": {"fwd": agg["fwd_ms"], "dgrad": agg["dgrad_ms"], "wgrad": agg["wgrad_ms"]}},
                            "best_launch": best, "sustained": sustained,
-                           "train_step_frac": round(res["train_ips"] * TRAIN_GFLOP_PER_IMAGE / 1e3 / (peak * world), 4)}
+                           "train_step_frac": round(res["train_ips"] * wm["train_gflop"] / 1e3 / (peak * world), 4)}
     del model, optimizer
     torch.cuda.empty_cache()
     return res
@@ -796,6 +931,97 @@ def cpu_baseline(args):
     return out
 
 
+
+
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None} if isinstance(d, dict) else None
+
+
+def _compact_roofline(r):
+    if not isinstance(r, dict):
+        return None
+    out = _pick(r, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "train_step_frac")
+    out.setdefault("traffic", None)
+    if isinstance(r.get("dominant"), dict):
+        out["dominant"] = _pick(r["dominant"], "kernel", "launches_per_step", "avg_us", "ms_per_step", "gflop_per_launch", "frac")
+    if isinstance(r.get("conv_family"), dict):
+        out["conv_family_frac"] = r["conv_family"].get("frac")
+    if isinstance(r.get("mixed"), dict):
+        out["t_lb_ms"] = r["mixed"].get("t_lb_ms")
+        out["mixed_frac"] = r["mixed"].get("frac_of_step")
+    if isinstance(r.get("bn_passes"), dict):
+        out["bn"] = {"ms_per_step": r["bn_passes"].get("ms_per_step"), "tb_per_s": r["bn_passes"].get("tb_per_s")}
+    return out
+
+
+def compact_line(full):
+    """the ONE JSON line rank 0 prints: the headline keys of the driver's contract, `roofline` and `cpu_baseline` with their contract
+    keys, one number per informational leg -- below LINE_LIMIT bytes whatever the tables hold (they go to DETAIL_FILE: `full`)."""
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                     "vs_baseline", "dtype", "data")}
+    line["config"] = _pick(full.get("config") or {}, "workload", "global_batch", "parallelism", "bn", "f32_mma", "hip_graph", "final_loss")
+    mc = full.get("mc_dropout")
+    line["mc_dropout"] = _pick(mc, "value", "unit", "T", "pool_images", "scoring_batch", "frac_of_mfma_peak") if mc else None
+    cs = full.get("core_set")
+    if cs:
+        line["core_set"] = _pick(cs, "value", "unit", "frac_of_mfma_peak")
+        kc = cs.get("kcenter") or {}
+        line["core_set"]["kcenter_s"] = kc.get("seconds")
+        line["core_set"]["picks_equal_sklearn"] = kc.get("picks_equal_sklearn_on_same_matrix")
+    else:
+        line["core_set"] = None
+    pr = full.get("pool_reader")
+    line["pool_reader"] = {"value": pr.get("value"), "unit": pr.get("unit"), "cpu_1core": (pr.get("cpu_reference_style") or {}).get("value")} if pr else None
+    line["roofline"] = _compact_roofline(full.get("roofline"))
+    cpu = full.get("cpu_baseline")
+    if cpu:
+        c = _pick(cpu, "value", "unit", "cores", "kind")
+        c["sample"] = str(cpu.get("sample", ""))[:160]
+        c["mc_dropout_reference"] = (cpu.get("mc_dropout_reference") or {}).get("value")
+        c["mc_dropout_hoisted"] = (cpu.get("mc_dropout_hoisted") or {}).get("value")
+        c["core_set_features"] = (cpu.get("core_set") or {}).get("feature_images_per_s")
+        c["kcenter_s"] = (cpu.get("core_set") or {}).get("kcenter_seconds")
+        c["config0_unet"] = _pick(cpu.get("config0_unet") or {}, "value", "loss_decreases")
+        line["cpu_baseline"] = c
+    else:
+        line["cpu_baseline"] = None
+    modes = {}
+    for name in ("f32_mfma_mode", "bf16x1_perf_mode", "bf16_perf_mode", "f32_parity_mode"):
+        m = full.get(name)
+        if not isinstance(m, dict):
+            continue
+        if "error" in m:
+            modes[name] = {"error": str(m["error"])[:120]}
+            continue
+        r = m.get("roofline") or {}
+        modes[name] = {"train": m.get("train_images_per_s"), "graph": m.get("hip_graph"), "mc": (m.get("mc_dropout") or {}).get("value"),
+                       "core_set": (m.get("core_set") or {}).get("value"), "dominant_frac": r.get("frac"), "train_step_frac": r.get("train_step_frac"),
+                       "mixed_frac": (r.get("mixed") or {}).get("frac_of_step")}
+    line["modes"] = modes or None
+    line["detail"] = full.get("detail")
+    text = json.dumps(line)
+    if len(text) >= LINE_LIMIT:  # never let a long string cost the driver its line: drop the optional parts, longest first
+        for k in ("modes", "pool_reader", "core_set", "detail"):
+            line[k] = None
+            if len(json.dumps(line)) < LINE_LIMIT:
+                break
+    return line
+
+
+def write_detail(full):
+    """every table of the run (by_symbol / by_kernel, bn_passes, step kernels, per-mode rooflines, the CPU legs): gpurun_out/ when present
+    (it is merged back from the GPU box), else the repo root; -> the path written, relative to the repo root"""
+    d = os.path.join(ROOT, "gpurun_out")
+    path = os.path.join(d if os.path.isdir(d) else ROOT, DETAIL_FILE)
+    try:
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+        return os.path.relpath(path, ROOT)
+    except OSError as exc:
+        log("could not write %s: %r" % (path, exc))
+        return None
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a torchrun environment: start N ranks (one per GPU) through torch.distributed.run as a
     CHILD process -- this parent has not touched the GPU and never does -- relay its output, exit with its code"""
@@ -915,7 +1141,12 @@ def main():
                           "note": notes[name]}
         for name, err in failed.items():
             line[name] = {"error": err}
-        print(json.dumps(line))
+        line["detail"] = write_detail(line)
+        log("full tables: %s (%d bytes as one line)" % (line["detail"], len(json.dumps(line))))
+        short = json.dumps(compact_line(line))
+        assert len(short) < LINE_LIMIT, len(short)
+        sys.stderr.flush()
+        print(short, flush=True)
     if env.dist is not None:
         env.dist.destroy_process_group()
 

