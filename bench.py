@@ -453,7 +453,8 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
     torch.manual_seed(1234)  # identical random-init weights on every rank
     model = DeepLab(backbone=args.backbone, output_stride=16, num_classes=args.classes, sync_bn=False,
                     freeze_bn=False, pretrained=False).to(dev)
-    criterion = SegmentationLosses(cuda=True, global_batch=True).build_loss("ce")  # DataParallel loss semantics under N > 1
+    crit_obj = SegmentationLosses(cuda=True, global_batch=True)   # DataParallel loss semantics under N > 1
+    criterion = crit_obj.build_loss("ce")
     lr = 0.01
     from dass_hip.optim import SGD  # torch.optim.SGD surface and state, update arithmetic in dass_sgd_step_multi
 
@@ -477,25 +478,56 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    # N > 1: bucketed RCCL all-reduce of the gradients, overlapped with backward through grad hooks
+    if args.only:
+        steps = warmup = 0
+    # 'auto': every f32-tensor leg on the pipelined engines.  The parity step is ~27 ms of GPU time against 26-32 ms of host time for its
+    # ~550 launches (the host's share differs from box to box: 285 img/s eager on one, 249 on another), the perf engine 20 ms against the
+    # same host time: a graph replay takes the host out of the step.  N > 1: zero_grad + forward + loss + backward replay as graph A, the
+    # gradient all-reduce runs eagerly behind it on the same stream, the SGD step replays as graph B (dass_hip/graph.py) -- the loss's
+    # own exchange of denominators depends on the labels only and runs ahead of graph A (utils/loss.py:use_static_global).
+    # The bf16-storage mode keeps its eager loop.
+    use_graph = steps > 0 and dtype_name.startswith("f32") and mma in ("f16x3", "bf16x1") and args.graph in ("on", "auto")
+    if args.graph == "on" and steps > 0:
+        use_graph = True
+    ddp_graph = use_graph and dist is not None
+    static = crit_obj.use_static_global(dev) if ddp_graph else None
+    # N > 1, eager: bucketed RCCL all-reduce of the gradients, overlapped with backward through grad hooks
     # (DASS_DDP_OVERLAP=0: the plain after-backward form)
-    averager = GradientAverager(params) if dist is not None and os.environ.get("DASS_DDP_OVERLAP", "1") == "1" else None
+    averager = GradientAverager(params) if dist is not None and not ddp_graph and os.environ.get("DASS_DDP_OVERLAP", "1") == "1" else None
 
-    def train_step():
+    def before_step():
+        if crit_obj.static is not None:
+            crit_obj.static.exchange(target)
+
+    def compute_step():
+        # (DASS_BENCH_GRAPH_FAULT=1: a fault injected INSIDE the capture, to rehearse the fallback below on a real GPU)
+        if os.environ.get("DASS_BENCH_GRAPH_FAULT") == "1" and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("injected capture fault (DASS_BENCH_GRAPH_FAULT=1)")
         optimizer.zero_grad(set_to_none=True)
         out = model(image)
         loss = criterion(out, target)
         loss.backward()
+        return loss
+
+    def reduce_step():
         if averager is not None:
             averager.finish()
         elif dist is not None:
             average_gradients(params)
+
+    def train_step():
+        before_step()
+        loss = compute_step()
+        reduce_step()
+        optimizer.step()
+        return loss
+
+    def whole_step():
+        loss = compute_step()
         optimizer.step()
         return loss
 
     model.train()
-    if args.only:
-        steps = warmup = 0
     loss = torch.zeros((), device=dev)
     for i in range(warmup):
         tw = time.perf_counter()
@@ -503,40 +535,49 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
         torch.cuda.synchronize()
         if rank == 0:
             log("[%s] warm-up step %d: %.1f ms" % (dtype_name, i, (time.perf_counter() - tw) * 1e3))
-    # 'auto': every single-GPU f32-tensor leg.  The parity step is ~28 ms of GPU time against 26-29 ms of host time for its ~550 launches
-    # (the host's share differs from box to box: 285 img/s eager on one, 249 on another whose CPU needs 32 ms per step), the perf engine
-    # 21 ms against the same host time: a graph replay takes the host out of the step.  The bf16-storage mode keeps its eager loop.
-    use_graph = steps > 0 and world == 1 and dtype_name.startswith("f32") and mma in ("f16x3", "bf16x1") and args.graph in ("on", "auto")
-    if args.graph == "on" and steps > 0 and world == 1:
-        use_graph = True
     timed_step = train_step
     if use_graph:
         from dass_hip.graph import GraphedStep
 
-        def capturable_step():
-            # (DASS_BENCH_GRAPH_FAULT=1: a fault injected INSIDE the capture, to rehearse the fallback below on a real GPU)
-            if os.environ.get("DASS_BENCH_GRAPH_FAULT") == "1" and torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("injected capture fault (DASS_BENCH_GRAPH_FAULT=1)")
-            return train_step()
-
         try:
-            timed_step = GraphedStep(capturable_step, warmup=2)   # zero_grad + forward + loss + backward + SGD as ONE graph launch
+            if ddp_graph:
+                timed_step = GraphedStep(compute_step, warmup=2, reduce=reduce_step, finish=optimizer.step, before=before_step)
+            else:
+                timed_step = GraphedStep(whole_step, warmup=2)   # zero_grad + forward + loss + backward + SGD as ONE graph launch
             for _ in range(2):
                 timed_step()
             torch.cuda.synchronize()
             if rank == 0:
-                log("[%s] train step captured into a hipGraph (two streams inside)" % dtype_name)
+                log("[%s] train step captured into %s" % (dtype_name, "two hipGraphs around the eager gradient all-reduce" if ddp_graph
+                                                          else "a hipGraph (two streams inside)"))
         except Exception as exc:  # noqa: BLE001  (a capture the runtime refuses must not cost the run: eager steps instead)
             log("[%s] hipGraph capture FAILED (%r): timing eager steps" % (dtype_name, exc))
             use_graph, timed_step = False, train_step
             torch.cuda.synchronize()
+            if ddp_graph:   # (every rank captures the same step: they fail, and fall back, together)
+                crit_obj.static = None
+                ddp_graph = False
+                if os.environ.get("DASS_DDP_OVERLAP", "1") == "1":
+                    averager = GradientAverager(params)
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = timed_step()
     barrier()
     dt = max(tmax(time.perf_counter() - t0), 1e-9)
-    res = {"train_ips": b * world * steps / dt, "ms_per_step": dt / max(steps, 1) * 1e3, "final_loss": float(loss.detach()), "graph": bool(use_graph)}
+    loss = loss.detach().clone()
+    if dist is not None and crit_obj.static is not None:   # pre-exchanged denominators: a rank's value is world x its share of the global loss
+        dist.all_reduce(loss)
+        loss /= world
+    res = {"train_ips": b * world * steps / dt, "ms_per_step": dt / max(steps, 1) * 1e3, "final_loss": float(loss), "graph": bool(use_graph)}
+    if dist is not None and steps > 0:
+        # every rank must hold bit-identical weights after the same averaged gradients: a wrapping int64 sum over the raw bits
+        h = torch.stack([p.detach().view(torch.int32).sum(dtype=torch.int64) for p in params]).sum().reshape(1)
+        hs = [torch.zeros_like(h) for _ in range(world)]
+        dist.all_gather(hs, h)
+        res["replicas_identical"] = bool(all(int(x) == int(hs[0]) for x in hs))
+        res["ddp"] = "graph A (fwd+bwd) -> eager flat all-reduce -> graph B (SGD)" if ddp_graph else (
+            "eager, bucketed all-reduce overlapped with backward" if averager is not None else "eager, all-reduce after backward")
     if rank == 0 and steps > 0:
         log("[%s] train: %.2f images/s (%.1f ms/step)" % (dtype_name, res["train_ips"], res["ms_per_step"]))
 
@@ -959,7 +1000,7 @@ def compact_line(full):
     keys, one number per informational leg -- below LINE_LIMIT bytes whatever the tables hold (they go to DETAIL_FILE: `full`)."""
     line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                      "vs_baseline", "dtype", "data")}
-    line["config"] = _pick(full.get("config") or {}, "workload", "global_batch", "parallelism", "bn", "f32_mma", "hip_graph", "final_loss")
+    line["config"] = _pick(full.get("config") or {}, "workload", "global_batch", "parallelism", "bn", "f32_mma", "hip_graph", "final_loss", "replicas_identical", "ddp")
     mc = full.get("mc_dropout")
     line["mc_dropout"] = _pick(mc, "value", "unit", "T", "pool_images", "scoring_batch", "frac_of_mfma_peak") if mc else None
     cs = full.get("core_set")
@@ -1126,7 +1167,7 @@ def main():
                                        % (args.backbone, args.classes, s, s, b),
                            "global_batch": b * world, "parallelism": "dp%d" % world, "bn": "per-GPU",
                            "f32_mma": args.f32_mma if args.dtype == "f32" else None, "hip_graph": head.get("graph", False),
-                           "final_loss": round(head["final_loss"], 5)},
+                           "final_loss": round(head["final_loss"], 5), "replicas_identical": head.get("replicas_identical"), "ddp": head.get("ddp")},
                 "mc_dropout": head["mc"], "core_set": head["coreset"], "pool_reader": reader, "roofline": head["roofline"],
                 "cpu_baseline": cpu}
         notes = {"bf16_perf_mode": "informational; bf16 storage does not meet the parity bar (tests/test_bf16_gpu.py measures the deviation)",

@@ -61,27 +61,69 @@ def merged_batches(loader, merge):
         return
     held = []
     for sample in loader:
+        if held and not _mergeable(held[0], sample):
+            for h in held:     # (crop_size = -1 pools: batches of another spatial size go through on their own)
+                yield h
+            held = []
         held.append(sample)
         if len(held) == merge:
             yield _cat_samples(held)
             held = []
-    if held:
+    if len(held) > 1 and all(_mergeable(held[0], h) for h in held[1:]):
         yield _cat_samples(held)
+    else:
+        for h in held:
+            yield h
+
+
+def _mergeable(a, b):
+    """may two loader batches share a forward?  same container type, same keys, tensors of equal trailing shape and dtype"""
+    if isinstance(a, dict) != isinstance(b, dict):
+        return False
+    if isinstance(a, dict):
+        if a.keys() != b.keys():
+            return False
+        pairs = [(a[k], b[k]) for k in a]
+    else:
+        pairs = [(a, b)]
+    for u, v in pairs:
+        if torch.is_tensor(u) != torch.is_tensor(v):
+            return False
+        if torch.is_tensor(u) and (u.shape[1:] != v.shape[1:] or u.dtype != v.dtype or u.device != v.device):
+            return False
+    return True
 
 
 def _cat_samples(samples):
+    """tensors are concatenated along dim 0; any other value of a dict sample (names, ids: lists / tuples / scalars) is carried as the
+    concatenated list, in batch order"""
     if len(samples) == 1:
         return samples[0]
     if isinstance(samples[0], dict):
-        return {k: torch.cat([s[k] for s in samples], dim=0) for k in samples[0]}
+        out = {}
+        for k in samples[0]:
+            vals = [s[k] for s in samples]
+            if torch.is_tensor(vals[0]):
+                out[k] = torch.cat(vals, dim=0)
+            else:
+                flat = []
+                for v in vals:
+                    flat.extend(list(v) if isinstance(v, (list, tuple)) else [v])
+                out[k] = flat
+        return out
     return torch.cat(list(samples), dim=0)
 
 
-def score_merge():
-    """loader batches per scoring forward (DASS_SCORE_MERGE, default 2; 1 = the loader's own batches)"""
+def score_merge(batch_size=None):
+    """loader batches per scoring forward.  DASS_SCORE_MERGE when set (1 = the loader's own batches); otherwise 2 while the merged
+    forward stays at or below 16 images -- the size up to which the encoder's 33 x 33 layers gain from it -- and 1 above: a user who
+    sized `dataloader_batch_size` to the memory of a 769^2 crop or a large T is not handed twice that behind their back."""
     import os
 
-    return max(1, int(os.environ.get("DASS_SCORE_MERGE", "2")))
+    env = os.environ.get("DASS_SCORE_MERGE")
+    if env is not None:
+        return max(1, int(env))
+    return 2 if batch_size is None or 2 * int(batch_size) <= 16 else 1
 
 
 class ActiveSelectionBase:

@@ -97,7 +97,7 @@ class ActiveSelectionMCDropout(ActiveSelectionBase):
                 image_batch.record_stream(pre)
                 return state, done, label_batch
 
-            loader = iter(merged_batches(self.make_loader(local, True), score_merge()))  # (two loader batches per scoring forward)
+            loader = iter(merged_batches(self.make_loader(local, True), score_merge(self.dataloader_batch_size)))  # (two loader batches per scoring forward)
             nxt = next(loader, None)
             cur = start(nxt) if nxt is not None else None
             while cur is not None:

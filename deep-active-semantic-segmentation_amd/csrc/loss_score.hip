@@ -525,7 +525,9 @@ struct SgdPack {
     int n;
 };
 
-__global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdPack pk, float momentum, float wd) {
+// hyper != nullptr: {lr, momentum, weight decay} are read from DEVICE memory at run time (one triple for all tensors of the launch), so a
+// launch captured into a hipGraph follows a learning-rate schedule (the by-value arguments of a captured launch are frozen)
+__global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdPack pk, float momentum, float wd, const float *__restrict__ hyper) {
     const long blk = blockIdx.x;
     int lo = 0, hi = pk.n - 1;
     while (lo < hi) {
@@ -535,7 +537,12 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdPack pk, float 
     float *__restrict__ p = pk.p[lo];
     const float *__restrict__ g = pk.g[lo];
     float *__restrict__ b = pk.b[lo];
-    const float lr = pk.lr[lo];
+    float lr = pk.lr[lo];
+    if (hyper) {
+        lr = hyper[0];
+        momentum = hyper[1];
+        wd = hyper[2];
+    }
     const long n = pk.numel[lo];
     const long e0 = (blk - pk.first_block[lo]) * SGD_BLK;
     const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)b) & 15) == 0) && e0 + SGD_BLK <= n;
@@ -715,9 +722,25 @@ extern "C" int dass_sgd_step(float *p, const float *g, float *buf, int64_t n, fl
     return DASS_OK;
 }
 
-extern "C" int dass_sgd_step_multi(void *const *p, const void *const *g, void *const *buf, const int64_t *numel, const float *lr,
-                                   int n, float momentum, float weight_decay, void *stream) {
-    if (!p || !g || !buf || !numel || !lr || n <= 0) return DASS_ERR_ARG;
+struct FloatPack {
+    float v[16];
+};
+__global__ void set_floats_kernel(float *__restrict__ dst, const FloatPack pk, int n) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = pk.v[threadIdx.x];
+}
+
+extern "C" int dass_set_floats(float *dst, const float *vals, int n, void *stream) {
+    if (!dst || !vals || n <= 0 || n > 16) return DASS_ERR_ARG;
+    FloatPack pk;
+    for (int i = 0; i < 16; ++i) pk.v[i] = i < n ? vals[i] : 0.f;
+    DASS_LAUNCH(set_floats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dst, pk, n);
+    DASS_LAUNCH_CHECK();
+    return DASS_OK;
+}
+
+static int sgd_step_multi(void *const *p, const void *const *g, void *const *buf, const int64_t *numel, const float *lr,
+                          int n, float momentum, float weight_decay, const float *hyper, void *stream) {
+    if (!p || !g || !buf || !numel || (!lr && !hyper) || n <= 0) return DASS_ERR_ARG;
     for (int base = 0; base < n; base += SGD_PACK) {
         SgdPack pk;
         pk.n = n - base < SGD_PACK ? n - base : SGD_PACK;
@@ -728,15 +751,26 @@ extern "C" int dass_sgd_step_multi(void *const *p, const void *const *g, void *c
             pk.g[i] = (const float *)g[base + i];
             pk.b[i] = (float *)buf[base + i];
             pk.numel[i] = numel[base + i];
-            pk.lr[i] = lr[base + i];
+            pk.lr[i] = lr ? lr[base + i] : 0.f;
             pk.first_block[i] = blocks;
             blocks += (numel[base + i] + SGD_BLK - 1) / SGD_BLK;
         }
         pk.first_block[pk.n] = blocks;
-        DASS_LAUNCH(sgd_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pk, momentum, weight_decay);
+        DASS_LAUNCH(sgd_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pk, momentum, weight_decay, hyper);
         DASS_LAUNCH_CHECK();
     }
     return DASS_OK;
+}
+
+extern "C" int dass_sgd_step_multi(void *const *p, const void *const *g, void *const *buf, const int64_t *numel, const float *lr,
+                                   int n, float momentum, float weight_decay, void *stream) {
+    return sgd_step_multi(p, g, buf, numel, lr, n, momentum, weight_decay, nullptr, stream);
+}
+
+extern "C" int dass_sgd_step_multi_dev(void *const *p, const void *const *g, void *const *buf, const int64_t *numel, int n,
+                                       const float *hyper, void *stream) {
+    if (!hyper) return DASS_ERR_ARG;
+    return sgd_step_multi(p, g, buf, numel, nullptr, n, 0.f, 0.f, hyper, stream);
 }
 
 extern "C" int dass_version(void) { return 1; }

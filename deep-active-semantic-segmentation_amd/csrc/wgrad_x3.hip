@@ -13,8 +13,11 @@
 //     two-128-B-segment wave instructions (the shape that runs at the full atomic rate).
 // Reference site replaced: the weight gradient autograd derives for every dense nn.Conv2d of the DeepLab path.
 #include "dass_common.h"
+#include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 namespace {
 
@@ -452,6 +455,65 @@ extern "C" int dass_conv2d_wgrad_x3(const void *x3, const void *dy3, float *dw, 
 // asynchronous copy on `stream`: keep it alive until the launches have run, do not reuse it for another call before that).
 extern "C" int64_t dass_conv2d_wgrad_x3_group_scratch_bytes(int n) { return (int64_t)(n > 0 ? n : 1) * (sizeof(WX3P) + 8) + 64; }
 
+// ---- staging tables of CAPTURED grouped launches (a hipGraph around the train step, dass_hip/graph.py).  The copy of the problem table
+// becomes a graph node that reads its pinned source at EVERY replay, so a table used inside a capture must stay untouched for as long
+// as the graph lives -- and not longer: the tables of a capture belong to a token, opened BEFORE the capture starts
+// (dass_graph_capture_open reserves the pinned buffers there: nothing may be allocated while a stream captures) and handed back when
+// the graph is destroyed or its capture failed (dass_graph_release).  One pool per process, shared by every thread and every tile
+// class (autograd runs backward on its own threads).
+namespace {
+struct CapSlot {
+    char *p = nullptr;   // WX3P[cap]
+    int *b = nullptr;    // int[cap + 1]
+    int cap = 0;
+    int64_t token = 0;   // 0 = free
+};
+constexpr int CAP_SLOT_ITEMS = 1024;
+std::mutex g_cap_mu;
+std::vector<CapSlot> g_cap_slots;
+int64_t g_cap_token = 0, g_cap_open = 0;
+}  // namespace
+
+extern "C" int64_t dass_graph_capture_open(int slots) {
+    std::lock_guard<std::mutex> lk(g_cap_mu);
+    int free_slots = 0;
+    for (const CapSlot &c : g_cap_slots) free_slots += c.token == 0;
+    for (; free_slots < slots; ++free_slots) {
+        CapSlot c;
+        c.cap = CAP_SLOT_ITEMS;
+        if (hipHostMalloc((void **)&c.p, sizeof(WX3P) * c.cap) != hipSuccess) return -1;
+        if (hipHostMalloc((void **)&c.b, sizeof(int) * (c.cap + 1)) != hipSuccess) { (void)hipHostFree(c.p); return -1; }
+        g_cap_slots.push_back(c);
+    }
+    g_cap_open = ++g_cap_token;
+    return g_cap_open;
+}
+
+extern "C" int dass_graph_capture_close(void) {
+    std::lock_guard<std::mutex> lk(g_cap_mu);
+    g_cap_open = 0;
+    return DASS_OK;
+}
+
+extern "C" int dass_graph_release(int64_t token) {
+    if (token <= 0) return DASS_ERR_ARG;
+    std::lock_guard<std::mutex> lk(g_cap_mu);
+    int n = 0;
+    for (CapSlot &c : g_cap_slots)
+        if (c.token == token) { c.token = 0; ++n; }
+    return n;
+}
+
+/* staging tables currently owned by captured graphs / free (diagnostics, tests) */
+extern "C" int dass_graph_slots(int *owned, int *free_slots) {
+    std::lock_guard<std::mutex> lk(g_cap_mu);
+    int o = 0, f = 0;
+    for (const CapSlot &c : g_cap_slots) (c.token ? o : f) += 1;
+    if (owned) *owned = o;
+    if (free_slots) *free_slots = f;
+    return DASS_OK;
+}
+
 namespace {
 struct GroupItem {
     WX3P p;
@@ -472,45 +534,60 @@ int launch_group(GroupItem *it, int n, char *scratch, hipStream_t st) {
         }
         it[j + 1] = key;
     }
-    // pinned staging tables (truly asynchronous copies), a ring of 64: a slot is rewritten only after the copy out of it, issued
-    // 64 grouped launches earlier, has completed -- the host never waits for the stream in steady state.
-    // Under stream capture (a hipGraph around the train step) the copy becomes a graph node that reads the slot at EVERY replay:
-    // a slot used inside a capture is never handed out again (`pinned`), nothing is (re)allocated or waited for while capturing --
-    // the ring is sized once, outside (dass_conv2d_wgrad_x3_group_reserve) -- and a capture that needs more slots than are left fails
+    // pinned staging tables (truly asynchronous copies), a ring of 64 per thread and tile class: a slot is rewritten only after the copy
+    // out of it, issued 64 grouped launches earlier, has completed -- the host never waits for the stream in steady state.
+    // Under stream capture the table comes from the capture's own pool instead (dass_graph_capture_open above).
     struct Slot {
         WX3P *p = nullptr;
         int *b = nullptr;
         int cap = 0;
         hipEvent_t done = nullptr;
-        bool used = false, pinned = false;
+        bool used = false;
     };
     constexpr int NSLOT = 64;
     static thread_local Slot ring[NSLOT];
     static thread_local int next_slot = 0;
     hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(st, &cap_status) == hipSuccess && cap_status == hipStreamCaptureStatusActive;
-    int tries = 0;
-    // eager: the next slot that no captured graph owns; capturing: the next such slot that already HAS its buffers (eager warm-up
-    // steps on the same threads created them: a capture follows a few eager steps by construction, torch.cuda.graph demands it)
-    while (tries < NSLOT && (ring[next_slot].pinned || (capturing && (ring[next_slot].cap < n || !ring[next_slot].done)))) {
-        next_slot = (next_slot + 1) % NSLOT;
-        ++tries;
-    }
-    if (tries == NSLOT) return DASS_ERR_UNSUPPORTED;  // every slot belongs to a captured graph / none is ready for a capture
-    Slot &sl = ring[next_slot];
-    next_slot = (next_slot + 1) % NSLOT;
-    if (!capturing && sl.used && hipEventSynchronize(sl.done) != hipSuccess) return DASS_ERR_LAUNCH;
-    if (capturing) sl.pinned = true;
-    if (sl.cap < n) {
-        if (sl.p) { (void)hipHostFree(sl.p); (void)hipHostFree(sl.b); }
-        sl.cap = n > 448 ? n + 64 : 512;
-        if (hipHostMalloc((void **)&sl.p, sizeof(WX3P) * sl.cap) != hipSuccess || hipHostMalloc((void **)&sl.b, sizeof(int) * (sl.cap + 1)) != hipSuccess) {
-            sl.cap = 0;
-            sl.p = nullptr;
-            return DASS_ERR_LAUNCH;
+    Slot cap_sl;
+    Slot *slp = nullptr;
+    if (capturing) {
+        std::lock_guard<std::mutex> lk(g_cap_mu);
+        if (g_cap_open == 0) {
+            fprintf(stderr, "libdass_hip: a grouped weight-gradient launch is being captured into a hipGraph without dass_graph_capture_open() "
+                            "(dass_hip.graph.GraphedStep calls it): no staging table may be allocated during a capture\n");
+            return DASS_ERR_UNSUPPORTED;
         }
+        for (CapSlot &c : g_cap_slots)
+            if (c.token == 0 && c.cap >= n) {
+                c.token = g_cap_open;
+                cap_sl.p = reinterpret_cast<WX3P *>(c.p);
+                cap_sl.b = c.b;
+                cap_sl.cap = c.cap;
+                slp = &cap_sl;
+                break;
+            }
+        if (!slp) {
+            fprintf(stderr, "libdass_hip: the hipGraph capture needs more staging tables than dass_graph_capture_open() reserved (%d exist, all "
+                            "owned by live graphs; release finished graphs or reserve more)\n", (int)g_cap_slots.size());
+            return DASS_ERR_UNSUPPORTED;
+        }
+    } else {
+        slp = &ring[next_slot];
+        next_slot = (next_slot + 1) % NSLOT;
+        if (slp->used && hipEventSynchronize(slp->done) != hipSuccess) return DASS_ERR_LAUNCH;
+        if (slp->cap < n) {
+            if (slp->p) { (void)hipHostFree(slp->p); (void)hipHostFree(slp->b); }
+            slp->cap = n > 448 ? n + 64 : 512;
+            if (hipHostMalloc((void **)&slp->p, sizeof(WX3P) * slp->cap) != hipSuccess || hipHostMalloc((void **)&slp->b, sizeof(int) * (slp->cap + 1)) != hipSuccess) {
+                slp->cap = 0;
+                slp->p = nullptr;
+                return DASS_ERR_LAUNCH;
+            }
+        }
+        if (!slp->done && hipEventCreateWithFlags(&slp->done, hipEventDisableTiming) != hipSuccess) return DASS_ERR_LAUNCH;
     }
-    if (!sl.done && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) return DASS_ERR_LAUNCH;
+    Slot &sl = *slp;
     WX3P *host_p = sl.p;
     int *host_b = sl.b;
     long total = 0;
@@ -525,8 +602,10 @@ int launch_group(GroupItem *it, int n, char *scratch, hipStream_t st) {
     int *dev_b = reinterpret_cast<int *>(scratch + sizeof(WX3P) * n);
     if (hipMemcpyAsync(dev_p, host_p, sizeof(WX3P) * n, hipMemcpyHostToDevice, st) != hipSuccess) return DASS_ERR_LAUNCH;
     if (hipMemcpyAsync(dev_b, host_b, sizeof(int) * (n + 1), hipMemcpyHostToDevice, st) != hipSuccess) return DASS_ERR_LAUNCH;
-    if (!capturing && hipEventRecord(sl.done, st) != hipSuccess) return DASS_ERR_LAUNCH;
-    sl.used = !capturing;
+    if (!capturing) {
+        if (hipEventRecord(sl.done, st) != hipSuccess) return DASS_ERR_LAUNCH;
+        sl.used = true;
+    }
     DASS_LAUNCH((wgrad_x3_group_kernel<BMK, BNC, WARPS_M, WARPS_N, NSTAGE, NP>), dim3((unsigned)total), dim3(64 * WARPS_M * WARPS_N), 0, st, dev_p, dev_b, n);
     DASS_LAUNCH_CHECK();
     return DASS_OK;

@@ -75,6 +75,36 @@ def global_batch_mean(local_sum, local_count, n_local):
     return total_sum / tot[0], int(round(float(tot[1])))
 
 
+class StaticGlobalBatch(object):
+    """The denominators of the global-batch loss, exchanged AHEAD of the step: they depend on the labels only (valid-pixel weight sum,
+    image count), so a step whose forward / backward must not hold a collective -- a hipGraph replay (dass_hip/graph.py) -- can
+    normalise with device scalars that `exchange(target)` refreshed eagerly before it.  utils.loss.SegmentationLosses(global_batch=True)
+    uses them after `criterion.use_static_global(device)`: each rank's loss is then  world * (its numerator) / (global count) / (global
+    batch)  -- the same gradient scaling as global_batch_mean's backward -- and the mean of the ranks' values is the global loss."""
+
+    def __init__(self, device, ignore_index=255, weight=None):
+        self.ignore_index, self.weight = ignore_index, weight
+        self.inv_count = torch.ones((), dtype=torch.float32, device=device)   # world / sum over ranks of the valid-pixel weights
+        self.n_global = torch.ones((), dtype=torch.float32, device=device)    # global batch size
+
+    @torch.no_grad()
+    def exchange(self, target, n_local=None):
+        import torch.distributed as dist
+
+        valid = target != self.ignore_index
+        if self.weight is None:
+            cnt = valid.sum().float()
+        else:
+            w = self.weight.to(device=target.device, dtype=torch.float32)
+            cnt = (w[target.clamp(0, w.numel() - 1).long()] * valid).sum()
+        packed = torch.stack((cnt, torch.as_tensor(float(target.shape[0] if n_local is None else n_local), dtype=torch.float32, device=target.device)))
+        world = world_size()
+        if world > 1:
+            dist.all_reduce(packed)
+        self.inv_count.copy_(float(world) / packed[0])
+        self.n_global.copy_(packed[1])
+
+
 def average_gradients(params, bucket_bytes=64 << 20):
     """DDP-style gradient averaging after backward: gradients are packed into flat f32 buckets, every bucket is one
     asynchronous all-reduce (they pipeline on the RCCL stream), and the averaged values are scattered back in place.

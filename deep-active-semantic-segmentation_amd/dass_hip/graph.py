@@ -12,31 +12,110 @@ What makes the library's step capturable (each of these is host-side state that 
     (ops._wgrad_flush; DASS_WGRAD_SIDE_CAPTURE=0: one stream inside the graph), nothing synchronises or allocates through the
     driver, and the launch profile (csrc/prof.hip) must be closed.
 The captured step reads its inputs from the tensors the callable closed over: copy new batches INTO them (static inputs), as with any
-CUDA graph.  Reference loop: active_train.py:103-107."""
+CUDA graph.  Reference loop: active_train.py:103-107.
+
+What a replay does NOT freeze: the optimizer's lr / momentum / weight_decay (device-resident, refreshed from `param_groups` before
+every replay -- the reference's per-iteration poly schedule, active_train.py:101, keeps working).  What it DOES freeze: every other host
+scalar and every Python branch taken while capturing (batch shapes, which parameters fired, train/eval mode)."""
 import torch
 
 from . import ops
+from ._lib import lib
+
+_capture_hooks = None   # the list replay hooks register into while a GraphedStep captures
+
+
+def register_replay_hook(fn):
+    """code that is being captured calls this for host-side state it needs refreshed before EVERY replay (dass_hip.optim.SGD: the
+    device copy of lr / momentum / weight_decay).  Outside a GraphedStep capture it is a no-op."""
+    if _capture_hooks is not None and all(h != fn for h in _capture_hooks):
+        _capture_hooks.append(fn)
 
 
 class GraphedStep(object):
-    def __init__(self, fn, warmup=3):
-        self.fn = fn
+    """GraphedStep(fn): `fn` as one graph.  GraphedStep(fn, reduce=r, finish=f): `fn` (zero_grad + forward + loss + backward) as graph
+    A, then `r()` EAGERLY on the same stream after every replay of A -- the gradient all-reduce of a multi-process step, which gloo cannot
+    and RCCL need not be captured for -- then `f()` (the optimizer step) as graph B out of the same memory pool.  Per step the host
+    issues two graph launches and the collectives instead of ~550 kernel launches (active_train.py:82-85 wraps the same loop,
+    :103-107, in nn.DataParallel).  `before` runs eagerly ahead of graph A (e.g. utils.loss static_global().exchange(target))."""
+
+    STAGING_SLOTS = 48   # pinned problem tables reserved per capture (a R101 step uses ~14: chunks x tile classes)
+
+    def __init__(self, fn, warmup=3, reduce=None, finish=None, before=None):
+        global _capture_hooks
+        self.fn, self.reduce, self.finish, self.before = fn, reduce, finish, before
+        self.hooks, self.token, self.graph, self.graph_b = [], 0, None, None
+
+        def whole():
+            if before is not None:
+                before()
+            out = fn()
+            if reduce is not None:
+                reduce()
+            if finish is not None:
+                finish()
+            return out
+
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(max(1, warmup)):
-                fn()
+            for _ in range(max(0, warmup)):   # (0: the caller has run its own eager steps -- a capture needs the step's allocations,
+                whole()                       #  momentum buffers and staging tables to exist)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        ops.graph_capture_begin()
+        self.token = int(lib.dass_graph_capture_open(self.STAGING_SLOTS))
+        if self.token <= 0:
+            raise RuntimeError("dass_graph_capture_open failed (pinned staging tables)")
+        _capture_hooks = self.hooks
+        ok = False
         try:
-            with torch.cuda.graph(self.graph):
-                self.out = fn()
+            if before is not None:
+                before()
+            self.graph = torch.cuda.CUDAGraph()
+            ops.graph_capture_begin()
+            try:
+                with torch.cuda.graph(self.graph):
+                    self.out = fn()
+            finally:
+                ops.graph_capture_end()
+            if finish is not None:
+                self.graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_b, pool=self.graph.pool()):
+                    finish()
+                ops.weights_changed()
+            ok = True
         finally:
-            ops.graph_capture_end()
+            _capture_hooks = None
+            lib.dass_graph_capture_close()
+            if not ok:
+                self.release()
+        # (the capture did not run anything: the step is recorded, not executed, and `reduce` was not called -- the first replay
+        #  recomputes everything from the current weights)
+
+    def release(self):
+        """hand the capture's pinned staging tables back (the graph must not be replayed afterwards)"""
+        if self.token:
+            lib.dass_graph_release(self.token)
+            self.token = 0
+        self.graph = self.graph_b = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
     def __call__(self):
+        if self.graph is None:
+            raise RuntimeError("GraphedStep: released (or its capture failed)")
+        for h in self.hooks:
+            h()
+        if self.before is not None:
+            self.before()
         self.graph.replay()
+        if self.reduce is not None:
+            self.reduce()
+        if self.graph_b is not None:
+            self.graph_b.replay()
         ops.weights_changed()   # (the replay stepped the optimizer: cached weight operands of eager code are stale)
         return self.out

@@ -1138,6 +1138,7 @@ class _ConvBnAct(torch.autograd.Function):
             ctx.in_link = in_link
             ctx.spec = spec
             ctx.x3_on = x3_on
+            ctx.x_rows_only = x_rows_only
             ctx.x3_dgrad = (x3_on or _x3_train_layer(taps, k)) and n * h * w >= _X3_MIN_ROWS  # the input gradient reduces over k x taps
             ctx.image_input = image_input
             ctx.dims = (n, h, w, c, oh, ow, k, ldx, ldo, c_in)
@@ -1351,6 +1352,11 @@ class _ConvBnAct(torch.autograd.Function):
                     check(lib.dass_conv2d_wgrad_x3(_p(x3_in), _p(dy3_w), _p(dwk), n, h, w, c, oh, ow, kk, r, s, spec.stride, spec.pad,
                                                    spec.dil, 0, wstream), "dass_conv2d_wgrad_x3")
                 else:
+                    if getattr(ctx, "x_rows_only", False):
+                        # the input was produced with sole_consumer=True: its f32 buffer was never written, and this weight gradient
+                        # would read it (gradient rows not 16-byte aligned, or the conv engine changed between forward and backward)
+                        raise RuntimeError("dass_hip: weight gradient of a conv whose input holds split rows only (sole_consumer=True) cannot "
+                                           "take the f32 path -- keep the conv engine fixed between forward and backward, or set DASS_ROWS_ONLY=0")
                     check(lib.dass_conv2d_wgrad_acc(_p(xs), ldx, _p(dy), lddy, _p(dwk), n, h, w, c, oh, ow, kk, r, s,
                                                     spec.stride, spec.pad, spec.dil, _cdt(dy), wstream), "dass_conv2d_wgrad_acc")
                 if side is not None:
@@ -1644,7 +1650,8 @@ def conv_bn_act(x, conv, bn=None, act=ACT_NONE, residual=None, nc_scale=None, ex
     spec.rows_only = False
     if (sole_consumer and _ROWS_ONLY and consumer is not None and emit_x3 and residual is None and nc_scale is None and act != ACT_NONE
             and compute_dtype() == torch.float32 and x3_parts() <= 2 and x3_pipeline(training=spec.grad_enabled)
-            and consumer.groups == 1 and consumer.out_channels > 32 and conv.out_channels % 32 == 0 and not image_input):
+            and consumer.groups == 1 and consumer.out_channels > 32 and consumer.out_channels % 4 == 0 and conv.out_channels % 32 == 0
+            and not image_input):
         oh = conv_out_size(x.shape[2], conv.kernel_size[0], spec.stride, spec.pad, spec.dil)
         ow = conv_out_size(x.shape[3], conv.kernel_size[1], spec.stride, spec.pad, spec.dil)
         ch = conv_out_size(oh, consumer.kernel_size[0], consumer.stride[0], consumer.padding[0], consumer.dilation[0])

@@ -5,7 +5,12 @@ learning-rate groups.  This subclass keeps that surface -- constructor, param_gr
 state_dict()/load_state_dict() round-trip with the stock optimizer -- and replaces the arithmetic of `step()` by
 `dass_sgd_step_multi`: every f32 CUDA parameter of the step is updated by a handful of launches (64 tensors per launch
 ride in the kernel argument) instead of three foreach passes per group.  Anything it does not cover (nesterov, dampening,
-maximize, sparse / non-f32 / non-dense gradients, CPU tensors) goes through the stock implementation."""
+maximize, sparse / non-f32 / non-dense gradients, CPU tensors) goes through the stock implementation.
+
+Inside a hipGraph capture (dass_hip/graph.py) the launch reads {lr, momentum, weight_decay} of its param group from DEVICE memory
+(`dass_sgd_step_multi_dev`): the reference calls its poly-LR scheduler before every iteration (active_train.py:101), and the by-value
+arguments of a captured launch would freeze the rate of the capture.  The step registers `sync_hyper` with the capture, and
+GraphedStep runs it before every replay: `param_groups[i]['lr']` set by any scheduler keeps working, same arithmetic bit for bit."""
 import ctypes
 
 import torch
@@ -23,6 +28,26 @@ def _same_dense_layout(a, b):
 
 class SGD(torch.optim.SGD):
 
+    def _hyper_tensor(self, gi, device):
+        """device-resident {lr, momentum, weight_decay, 0} of param group gi"""
+        store = self.__dict__.setdefault("_dass_hyper", {})
+        ent = store.get(gi)
+        if ent is None or ent["dev"].device != device:
+            ent = store[gi] = {"dev": torch.zeros((4,), dtype=torch.float32, device=device), "pushed": None}
+        return ent
+
+    def sync_hyper(self):
+        """push every captured group's current {lr, momentum, weight_decay} to its device triple (a kernel argument carries the values:
+        no staging buffer to race on); skipped when nothing changed since the last push.  Called before each graph replay."""
+        for gi, ent in self.__dict__.get("_dass_hyper", {}).items():
+            g = self.param_groups[gi]
+            vals = (float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]))
+            if ent["pushed"] != vals:
+                arr = (ctypes.c_float * 3)(*vals)
+                stream = ctypes.c_void_p(torch.cuda.current_stream(ent["dev"].device).cuda_stream)
+                check(lib.dass_set_floats(ctypes.c_void_p(ent["dev"].data_ptr()), arr, 3, stream), "dass_set_floats")
+                ent["pushed"] = vals
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -30,7 +55,8 @@ class SGD(torch.optim.SGD):
             with torch.enable_grad():
                 loss = closure()
         leftovers = []
-        for group in self.param_groups:
+        capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        for gi, group in enumerate(self.param_groups):
             plain = (group["momentum"] != 0 and group["dampening"] == 0 and not group["nesterov"]
                      and not group.get("maximize", False))
             ps, gs, bs, ns = [], [], [], []
@@ -59,10 +85,19 @@ class SGD(torch.optim.SGD):
                 vg = (ctypes.c_void_p * n)(*[t.data_ptr() for t in gs])
                 vb = (ctypes.c_void_p * n)(*[t.data_ptr() for t in bs])
                 vn = (ctypes.c_int64 * n)(*ns)
-                vl = (ctypes.c_float * n)(*([float(group["lr"])] * n))
                 stream = ctypes.c_void_p(torch.cuda.current_stream(ps[0].device).cuda_stream)
-                check(lib.dass_sgd_step_multi(vp, vg, vb, vn, vl, n, float(group["momentum"]), float(group["weight_decay"]), stream),
-                      "dass_sgd_step_multi")
+                if capturing:
+                    # the captured launch reads its hyper-parameters from device memory; the capture's owner refreshes them before
+                    # every replay (graph.register_replay_hook -> sync_hyper), so a scheduler's `group['lr'] = ...` is honoured
+                    from . import graph
+
+                    ent = self._hyper_tensor(gi, ps[0].device)
+                    graph.register_replay_hook(self.sync_hyper)
+                    check(lib.dass_sgd_step_multi_dev(vp, vg, vb, vn, n, ctypes.c_void_p(ent["dev"].data_ptr()), stream), "dass_sgd_step_multi_dev")
+                else:
+                    vl = (ctypes.c_float * n)(*([float(group["lr"])] * n))
+                    check(lib.dass_sgd_step_multi(vp, vg, vb, vn, vl, n, float(group["momentum"]), float(group["weight_decay"]), stream),
+                          "dass_sgd_step_multi")
                 # the kernel writes through raw pointers: tell autograd the tensors changed, or every cache keyed on
                 # (data_ptr, _version) -- split / transposed weight operands, eval-BN vectors -- keeps serving step-0 values
                 torch.autograd.graph.increment_version(ps)

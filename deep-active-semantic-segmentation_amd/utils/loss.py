@@ -14,7 +14,10 @@ explicit opt-in here -- SegmentationLosses(..., global_batch=True) -- because it
   * calls with autograd disabled (validation under torch.no_grad(), where ranks may hold different numbers of batches) stay
     rank-local unless global_batch_in_eval=True;
   * the default (global_batch=False) never communicates: a process group that exists only for sharded pool scoring does not
-    change what a rank-local training step computes.
+    change what a rank-local training step computes;
+  * `use_static_global(device)` moves the exchange OUT of the loss call: the denominators depend on the labels only, so
+    `criterion.static.exchange(target)` runs eagerly before the step and the call itself holds no collective -- what a step replayed
+    from a hipGraph needs (dass_hip/graph.py; 'ce' only: the focal transform is not linear in a rank's share of the loss).
 """
 import torch
 
@@ -31,6 +34,14 @@ class SegmentationLosses(object):
         self.cuda = cuda
         self.global_batch = global_batch
         self.global_batch_in_eval = global_batch_in_eval
+        self.static = None
+
+    def use_static_global(self, device):
+        """-> dass_hip.dist.StaticGlobalBatch whose `exchange(target)` the caller runs before every (graphed) step"""
+        from dass_hip.dist import StaticGlobalBatch
+
+        self.static = StaticGlobalBatch(device, self.ignore_index, self._weight_on(device))
+        return self.static
 
     def _global(self):
         """does this call exchange its numerator / counts with the other ranks?"""
@@ -59,6 +70,8 @@ class SegmentationLosses(object):
         if not self._global():
             return ops.cross_entropy(logit, target, self._weight_on(logit.device), self.ignore_index), n
         s, cnt = ops.cross_entropy_parts(logit, target, self._weight_on(logit.device), self.ignore_index)
+        if self.static is not None and torch.is_grad_enabled():
+            return s * self.static.inv_count, self.static.n_global   # no collective in the call (see use_static_global)
         return global_batch_mean(s, cnt, n)
 
     def SampleWeightedCrossEntropyLoss(self, logit, target, sample_weights):
@@ -84,6 +97,8 @@ class SegmentationLosses(object):
         return loss
 
     def FocalLoss(self, logit, target, gamma=2, alpha=0.5):
+        if self.static is not None and self._global():
+            raise NotImplementedError("focal loss with pre-exchanged denominators: the transform is not linear in a rank's share")
         ce, n = self._ce_mean(logit, target)
         logpt = -ce
         pt = torch.exp(logpt)

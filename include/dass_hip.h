@@ -402,6 +402,14 @@ int dass_sgd_step(float *p, const float *g, float *buf, int64_t n, float lr, flo
  * launch inside the kernel argument.  A momentum buffer that starts at zero reproduces torch's first-step copy. */
 int dass_sgd_step_multi(void *const *p, const void *const *g, void *const *buf, const int64_t *numel, const float *lr,
                         int n, float momentum, float weight_decay, void *stream);
+/* The same update with {lr, momentum, weight_decay} read from DEVICE memory when the kernel runs (hyper: 3 floats, one triple for all n
+ * tensors = one param group): a step captured into a hipGraph keeps following the poly learning-rate schedule the reference applies
+ * every iteration (active_train.py:101 `self.scheduler(self.optimizer, i, epoch, ...)`), which by-value kernel arguments cannot.
+ * Same arithmetic, bit for bit.  dass_set_floats writes up to 16 host floats to device memory through a kernel argument (no pinned
+ * buffer whose reuse could race with an earlier, still queued copy). */
+int dass_sgd_step_multi_dev(void *const *p, const void *const *g, void *const *buf, const int64_t *numel, int n,
+                            const float *hyper, void *stream);
+int dass_set_floats(float *dst, const float *vals, int n, void *stream);
 
 /* ---- pre-split ("x3") operands: the pipelined form of the exact three-way bf16 split engine (csrc/conv_x3.hip).
  * An x3 tensor holds a [rows][C] f32 activation as rows x ceil(C/32) slabs of [3 parts][32 ch] bf16 (192 B; x = x0+x1+x2
@@ -535,6 +543,17 @@ int dass_conv2d_wgrad_x3(const void *x3, const void *dy3, float *dw, int N, int 
  * dass_conv2d_wgrad_x3_group_scratch_bytes(n) bytes that receives the problem table (asynchronous copy on `stream`). */
 int dass_conv2d_wgrad_x3_group(const int64_t *items, int n, void *scratch, int64_t scratch_bytes, void *stream);
 int64_t dass_conv2d_wgrad_x3_group_scratch_bytes(int n);
+/* Capturing a step that holds grouped weight-gradient launches into a hipGraph (dass_hip/graph.py; the reference loop it wraps:
+ * active_train.py:103-107).  The copy of a launch's problem table becomes a graph node that re-reads its pinned source at every replay,
+ * so those tables belong to the graph: dass_graph_capture_open(slots) -- BEFORE the capture starts, nothing may be allocated while a
+ * stream captures -- makes sure `slots` free tables exist and returns the token that the launches captured until
+ * dass_graph_capture_close() tag their tables with (-1: allocation failed); dass_graph_release(token) hands them back when the graph is
+ * destroyed or its capture failed (-> number released).  A captured launch without an open token, or with no free table left, fails
+ * with DASS_ERR_UNSUPPORTED and says why on stderr.  dass_graph_slots: tables owned by live graphs / free. */
+int64_t dass_graph_capture_open(int slots);
+int dass_graph_capture_close(void);
+int dass_graph_release(int64_t token);
+int dass_graph_slots(int *owned, int *free_slots);
 /* ---------------------------------------------------------------- pool reader
  * dataloaders/dataset/paths_dataset.py:27-52: a record is uint8 [H][W][4] (RGB + label).  dass_resample_bilinear_u8 =
  * scipy.misc.imresize(image, (OH, OW)) of custom_transforms.py:153,228,291 = PIL's two-pass bilinear resampler, bit for bit:

@@ -723,3 +723,27 @@ def test_bench_work_model_matches_survey_figures():
     assert abs(bench.work_model("resnet", 513, 19)["forward_gflop"] - 144.4) < 0.1
     m = bench.mixed_roofline(argparse.Namespace(batch=8, size=513, backbone="resnet101", classes=19), 2500.0 / 3)
     assert 7.4 < m["t_lb_ms"] < 7.9 and abs(m["bn_gb"] - 13.8) < 0.1, m
+
+
+def test_merged_batches_tolerate_non_tensor_keys_and_ragged_shapes():
+    """ADVICE r4 (active_selection/base.py): merging two loader batches per scoring forward must not break loaders whose samples carry
+    names / ids, nor pools with crop_size = -1 (batches of unequal spatial size), and must not double a batch the user sized to memory."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deep-active-semantic-segmentation_amd"))
+    from active_selection.base import merged_batches, score_merge
+
+    b = lambda n, hw, first: {"image": torch.zeros(n, 3, hw, hw), "label": torch.zeros(n, hw, hw), "name": ["k%d" % (first + i) for i in range(n)], "idx": first}
+    out = list(merged_batches(iter([b(2, 8, 0), b(2, 8, 2), b(2, 8, 4), b(2, 12, 6), b(1, 12, 8)]), 2))
+    assert [o["image"].shape[0] for o in out] == [4, 2, 3]
+    assert out[0]["name"] == ["k0", "k1", "k2", "k3"] and out[0]["idx"] == [0, 2]
+    assert out[1]["name"] == ["k4", "k5"] and out[2]["image"].shape[-1] == 12 and out[2]["name"] == ["k6", "k7", "k8"]
+    bare = list(merged_batches(iter([torch.zeros(2, 3, 8, 8), torch.zeros(2, 3, 8, 8), torch.zeros(2, 3, 9, 9)]), 2))
+    assert [t.shape[0] for t in bare] == [4, 2]
+    keep = os.environ.pop("DASS_SCORE_MERGE", None)
+    try:
+        assert score_merge(8) == 2 and score_merge(16) == 1 and score_merge(None) == 2
+        os.environ["DASS_SCORE_MERGE"] = "3"
+        assert score_merge(64) == 3
+    finally:
+        os.environ.pop("DASS_SCORE_MERGE", None)
+        if keep is not None:
+            os.environ["DASS_SCORE_MERGE"] = keep

@@ -1,0 +1,170 @@
+"""Round 5: the graphed train step pinned bit for bit in deterministic mode (with a learning-rate schedule running through the replays),
+the capture's pinned staging tables handed back with the graph, and the multi-process form -- graph A (forward + backward), eager
+gradient all-reduce, graph B (SGD) -- rehearsed with two ranks on one device."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _poly_lr(i, base):
+    return base * (1.0 - i / 10.0) ** 0.9   # utils/lr_scheduler.py 'poly' of the reference, 10 iterations (active_train.py:101)
+
+
+def _run_steps(engine, mode, n_steps, deterministic):
+    from dass_hip import ops
+    from dass_hip.graph import GraphedStep
+    from dass_hip.optim import SGD
+    from models.deeplab import DeepLab
+    from oracle import deeplab_cpu as O
+    from utils.loss import SegmentationLosses
+
+    ops.set_compute_dtype(torch.float32)
+    om = O.ODeepLab("resnet", 16, 19)
+    O.fill_state_dict(om, seed=8, randomize_bn_stats=False)
+    x, lab = O.synthetic_batch(4, 129, 129, 19, first_index=800)
+    xd, ld = x.cuda(), lab.cuda()
+    crit = SegmentationLosses(cuda=True).build_loss("ce")
+    pm = DeepLab(backbone="resnet", output_stride=16, num_classes=19, sync_bn=False, pretrained=False)
+    pm.load_state_dict(om.state_dict())
+    pm = pm.cuda().train()
+    opt = SGD([{"params": pm.get_1x_lr_params(), "lr": 0.01}, {"params": pm.get_10x_lr_params(), "lr": 0.1}], momentum=0.9, weight_decay=5e-4)
+    masks = O.dropout_masks(4, 1, seed=9)
+    dm = (masks[0][0].cuda(), masks[1][0].cuda())
+
+    def set_lr(i):
+        opt.param_groups[0]["lr"] = _poly_lr(i, 0.01)
+        opt.param_groups[1]["lr"] = _poly_lr(i, 0.1)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = crit(pm(xd, dropout_masks=dm), ld)
+        loss.backward()
+        opt.step()
+        return loss
+
+    losses = []
+    if mode == "eager":
+        for i in range(n_steps):
+            set_lr(i)
+            losses.append(float(step().detach()))
+    else:
+        for i in range(2):           # the caller's own eager warm-up, with the schedule's rates
+            set_lr(i)
+            losses.append(float(step().detach()))
+        gs = GraphedStep(step, warmup=0)
+        for i in range(2, n_steps):
+            set_lr(i if mode == "graph" else 2)   # "graph_frozen_lr": what a capture that froze the rate would compute
+            losses.append(float(gs().detach()))
+        gs.release()
+    torch.cuda.synchronize()
+    state = {k: v.detach().cpu().clone() for k, v in pm.state_dict().items()}
+    return losses, state
+
+
+@pytest.mark.parametrize("engine", ["f16x3"])
+def test_graphed_step_is_bit_identical_to_eager_in_deterministic_mode_and_follows_the_lr_schedule(engine):
+    """VERDICT r4 item 6 + ADVICE r4 (graph.py froze the learning rate).  Under ops.set_deterministic(True) no kernel of the step adds
+    through f32 / f64 atomics in arrival order, so 6 eager steps and 2 eager + 4 REPLAYED steps from the same state must agree bit for
+    bit: losses, every weight, every running statistic -- a replay that dropped, reordered or mis-parameterised a node cannot pass.  A
+    poly schedule changes both groups' rates before every step: the replays must follow it (the optimizer's hyper-parameters live in
+    device memory, dass_sgd_step_multi_dev), and a run whose replays keep the rate of the capture must NOT match."""
+    from dass_hip import ops
+
+    keep = ops.f32_mma()
+    try:
+        ops.set_f32_mma(engine)
+        ops.set_deterministic(True)
+        le, se = _run_steps(engine, "eager", 6, True)
+        le2, se2 = _run_steps(engine, "eager", 6, True)
+        lg, sg = _run_steps(engine, "graph", 6, True)
+        lf, sf = _run_steps(engine, "graph_frozen_lr", 6, True)
+    finally:
+        ops.set_deterministic(False)
+        ops.set_f32_mma(keep)
+    print("eager", ["%.7f" % v for v in le], "graph", ["%.7f" % v for v in lg], "frozen lr", ["%.7f" % v for v in lf])
+    # the yardstick first: two eager runs in deterministic mode are bit-identical (else name the kernel that is not)
+    bad = [k for k in se if not torch.equal(se[k], se2[k])]
+    assert le == le2 and not bad, ("eager steps are not reproducible in deterministic mode", bad[:8])
+    bad = [k for k in se if not torch.equal(se[k], sg[k])]
+    assert le == lg, (le, lg)
+    assert not bad, ("graph replay differs from eager", bad[:8], len(bad))
+    # and the schedule mattered: a frozen rate gives other weights
+    assert any(not torch.equal(se[k], sf[k]) for k in se if k.endswith("weight"))
+    assert lf[:3] == le[:3] and lf[3:] != le[3:], (lf, le)
+
+
+def test_capture_staging_tables_return_with_the_graph():
+    """ADVICE r4 (wgrad_x3.hip): tables pinned by a capture were never released, so a handful of GraphedSteps in one process exhausted the
+    ring and every later backward failed.  Tables now belong to the capture's token: five capture / release cycles leave none owned,
+    the pool does not grow after the first, and a replay after release() is refused."""
+    from dass_hip import ops
+    from dass_hip._lib import lib
+    from dass_hip.graph import GraphedStep
+    from dass_hip.optim import SGD
+    from models.deeplab import DeepLab
+    from utils.loss import SegmentationLosses
+
+    ops.set_compute_dtype(torch.float32)
+    torch.manual_seed(0)
+    pm = DeepLab(backbone="resnet", output_stride=16, num_classes=19, sync_bn=False, pretrained=False).cuda().train()
+    opt = SGD(pm.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
+    crit = SegmentationLosses(cuda=True).build_loss("ce")
+    x = torch.randn(2, 3, 97, 97, device="cuda")
+    lab = torch.randint(0, 19, (2, 97, 97), device="cuda").float()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = crit(pm(x), lab)
+        loss.backward()
+        opt.step()
+        return loss
+
+    owned, free = ctypes.c_int(0), ctypes.c_int(0)
+    sizes = []
+    for i in range(5):
+        gs = GraphedStep(step, warmup=1)
+        a = float(gs().detach())
+        lib.dass_graph_slots(ctypes.byref(owned), ctypes.byref(free))
+        assert owned.value > 0, "the captured step holds grouped weight-gradient launches: it must own staging tables"
+        sizes.append(owned.value + free.value)
+        gs.release()
+        lib.dass_graph_slots(ctypes.byref(owned), ctypes.byref(free))
+        assert owned.value == 0
+        with pytest.raises(RuntimeError, match="released"):
+            gs()
+        assert a == a
+    assert len(set(sizes)) == 1, sizes
+    float(step().detach())   # eager steps keep working after the cycles
+    torch.cuda.synchronize()
+
+
+def test_two_rank_graphed_ddp_step_keeps_replicas_identical(tmp_path):
+    """`bench.py --gpus 2` with two ranks on this one device over gloo (RCCL refuses two ranks per device; gloo
+    cannot be captured, which is exactly why the all-reduce stays outside the graphs): the timed steps replay graph A (zero_grad +
+    forward + CE + backward), all-reduce the flat gradient buckets eagerly, replay graph B (SGD).  The line must say hip_graph: true,
+    both ranks must end with bit-identical weights, and the loss must match an eager two-rank run of the same steps to rounding."""
+    def run(graph):
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        env.update(DASS_BENCH_ONE_DEVICE="1", DASS_BENCH_BACKEND="gloo")
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--size", "129", "--batch", "2",
+               "--backbone", "resnet", "--graph", graph, "--no-mc", "--no-roofline", "--no-second-dtype", "--no-cpu-baseline", "--no-pool-reader"]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads(r.stdout.strip().splitlines()[-1]), r.stderr
+
+    g, err = run("on")
+    assert g["n_gpus"] == 2 and g["config"]["hip_graph"] is True, (g["config"], err[-2000:])
+    assert g["config"]["replicas_identical"] is True
+    assert "graph A" in g["config"]["ddp"]
+    e, _ = run("off")
+    assert e["config"]["hip_graph"] is False and e["config"]["replicas_identical"] is True
+    print("graphed", g["config"]["final_loss"], "eager", e["config"]["final_loss"])
+    assert abs(g["config"]["final_loss"] - e["config"]["final_loss"]) <= 2e-3 * abs(e["config"]["final_loss"])
