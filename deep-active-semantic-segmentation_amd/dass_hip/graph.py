@@ -39,6 +39,9 @@ class GraphedStep(object):
     issues two graph launches and the collectives instead of ~550 kernel launches (active_train.py:82-85 wraps the same loop,
     :103-107, in nn.DataParallel).  `before` runs eagerly ahead of graph A (e.g. utils.loss static_global().exchange(target))."""
 
+    # warmup: eager steps run before the capture.  At least TWO must have run in the process (here or by the caller) before the first
+    # capture of a model: step one registers every conv weight's split operands as it meets them, step two refreshes them all through
+    # one batched table -- the form a steady-state step, and therefore the capture, uses (its host->device copy cannot be captured).
     STAGING_SLOTS = 48   # pinned problem tables reserved per capture (a R101 step uses ~14: chunks x tile classes)
 
     def __init__(self, fn, warmup=3, reduce=None, finish=None, before=None):

@@ -12,6 +12,7 @@ Inside a hipGraph capture (dass_hip/graph.py) the launch reads {lr, momentum, we
 arguments of a captured launch would freeze the rate of the capture.  The step registers `sync_hyper` with the capture, and
 GraphedStep runs it before every replay: `param_groups[i]['lr']` set by any scheduler keeps working, same arithmetic bit for bit."""
 import ctypes
+import os
 
 import torch
 
@@ -29,10 +30,15 @@ def _same_dense_layout(a, b):
 class SGD(torch.optim.SGD):
 
     def _hyper_tensor(self, gi, device):
-        """device-resident {lr, momentum, weight_decay, 0} of param group gi"""
+        """device-resident {lr, momentum, weight_decay, 0} of param group gi.  Created by the first EAGER step: memory allocated while a
+        stream captures belongs to the graph's pool, and a triple allocated there was overwritten by the replays (measured:
+        tools/graph_det_probe.py, lr read back as 1.0 / garbage) -- a capture without a preceding eager step is refused."""
         store = self.__dict__.setdefault("_dass_hyper", {})
         ent = store.get(gi)
         if ent is None or ent["dev"].device != device:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("dass_hip.optim.SGD: run one eager optimizer.step() before capturing it into a hipGraph "
+                                   "(GraphedStep(warmup >= 1) does)")
             ent = store[gi] = {"dev": torch.zeros((4,), dtype=torch.float32, device=device), "pushed": None}
         return ent
 
@@ -55,7 +61,7 @@ class SGD(torch.optim.SGD):
             with torch.enable_grad():
                 loss = closure()
         leftovers = []
-        capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing() and os.environ.get("DASS_SGD_DEV_HYPER", "1") == "1"
         for gi, group in enumerate(self.param_groups):
             plain = (group["momentum"] != 0 and group["dampening"] == 0 and not group["nesterov"]
                      and not group.get("maximize", False))
@@ -95,6 +101,7 @@ class SGD(torch.optim.SGD):
                     graph.register_replay_hook(self.sync_hyper)
                     check(lib.dass_sgd_step_multi_dev(vp, vg, vb, vn, n, ctypes.c_void_p(ent["dev"].data_ptr()), stream), "dass_sgd_step_multi_dev")
                 else:
+                    self._hyper_tensor(gi, ps[0].device)   # (exists before any capture of this step)
                     vl = (ctypes.c_float * n)(*([float(group["lr"])] * n))
                     check(lib.dass_sgd_step_multi(vp, vg, vb, vn, vl, n, float(group["momentum"]), float(group["weight_decay"]), stream),
                           "dass_sgd_step_multi")
