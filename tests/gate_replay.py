@@ -80,3 +80,138 @@ class GateReplay(object):
         torch.nn.functional.relu = self._orig_relu
         torch.nn.functional.hardtanh = self._orig_ht
         self.ops.conv_bn_act = self._orig_cba
+
+    # ---- the oracle's OWN gates, recorded while it runs with its true ReLU / ReLU6 (same matching rule as replay: by shape, in call order)
+    def record_oracle(self, store):
+        """patches F.relu / F.hardtanh to apply the true function and append (index of the matching HIP gate, oracle gate) to `store`"""
+        rec = self
+        rec.used = [False] * len(rec.gates)
+
+        def match(x):
+            for i, gt in enumerate(rec.gates):
+                if not rec.used[i] and tuple(gt.shape) == tuple(x.shape):
+                    rec.used[i] = True
+                    return i
+            raise AssertionError("no recorded gate of shape %s left" % (tuple(x.shape),))
+
+        def relu(x, inplace=False):
+            store.append((match(x), (x.detach() > 0)))
+            return rec._orig_relu(x)
+
+        def hardtanh(x, min_val=-1.0, max_val=1.0, inplace=False):
+            assert min_val == 0.0 and max_val == 6.0, "only ReLU6 is recorded"
+            store.append((match(x), ((x.detach() > 0) & (x.detach() < 6))))
+            return rec._orig_ht(x, min_val, max_val)
+
+        torch.nn.functional.relu = relu
+        torch.nn.functional.hardtanh = hardtanh
+
+    def flips_against(self, store):
+        """-> (units whose gate differs between the HIP forward and the recorded oracle forward, total units, [(site, flips)])"""
+        tot = flips = 0
+        sites = []
+        for i, g in store:
+            d = int((self.gates[i] != g.cpu()).sum())
+            flips += d
+            tot += g.numel()
+            if d:
+                sites.append((i, d))
+        return flips, tot, sites
+
+
+def gated_step_report(ops, O, S, pm, state_dict, backbone, ncls, x, lab, masks, criterion, stock_true=True):
+    """One train-mode step of the HIP model `pm` (already on the GPU, weights = state_dict) against the oracle, with the comparison
+    DECOMPOSED instead of floored: a ReLU input within rounding of 0 takes the other branch in one of two evaluations, and a
+    flipped unit moves every gradient upstream of it -- that is not rounding error and cannot be bounded by a multiple of it.  So
+      * err_inj  = HIP gradients vs the f64 oracle run with the HIP forward's OWN gates replayed: both sides differentiate the same
+                   piecewise-linear function; this is the rounding error of the HIP backward and is compared, tightly, with
+                   cpu_inj = stock f32 PyTorch under the same gates vs the same f64 gradients;
+      * flips    = units whose gate differs between the HIP forward and the f64 oracle's true-ReLU forward (flips_cpu: the same count
+                   for stock f32 PyTorch): how often the forward lands on the other side of a kink -- a forward-accuracy measure;
+      * flip_eff = f64 gradients with HIP gates vs f64 gradients with true gates: what those flips do, with no rounding involved.
+    err_true (HIP vs f64 true ReLU) <= err_inj + flip_eff by the triangle inequality; it is reported, not bounded."""
+    import numpy as np
+
+    m1, m2 = masks
+    rec = GateReplay(ops)
+    out = {}
+    try:
+        rec.record()
+        loss = criterion(pm(x.cuda(), dropout_masks=(m1.cuda(), m2.cuda())), lab.cuda())
+        loss.backward()
+        rec.stop_recording()
+        out["loss"] = loss.item()
+
+        def fresh(double):
+            o = O.ODeepLab(backbone, 16, ncls)
+            o.load_state_dict(state_dict)
+            return (o.double() if double else o).train()
+
+        # f64, true ReLU, its own gates recorded
+        o64 = fresh(True)
+        store64 = []
+        rec.record_oracle(store64)
+        l64 = S.ce_loss(o64(x.double(), (m1.double(), m2.double())), lab)
+        l64.backward()
+        out["loss64"], out["o64"] = l64.item(), o64
+        out["flips"], out["units"], out["flip_sites"] = rec.flips_against(store64)
+        g_true = {k: p.grad.clone() for k, p in o64.named_parameters()}
+        # f64 with the HIP gates
+        o64i = fresh(True)
+        rec.used = [False] * len(rec.gates)
+        rec.replay()
+        S.ce_loss(o64i(x.double(), (m1.double(), m2.double())), lab).backward()
+        assert all(rec.used)
+        g_inj = {k: p.grad for k, p in o64i.named_parameters()}
+        # stock f32 with the HIP gates (the rounding yardstick)
+        o32i = fresh(False)
+        rec.used = [False] * len(rec.gates)
+        S.ce_loss(o32i(x, (m1, m2)), lab).backward()
+        g32_inj = {k: p.grad.double() for k, p in o32i.named_parameters()}
+        if stock_true:  # stock f32, true ReLU: ITS flips against f64 (the flip-count yardstick)
+            o32 = fresh(False)
+            store32 = []
+            rec.record_oracle(store32)
+            S.ce_loss(o32(x, (m1, m2)), lab).backward()
+            by_site = {i: g for i, g in store64}
+            out["flips_cpu"] = sum(int((by_site[i] != g).sum()) for i, g in store32)
+    finally:
+        rec.restore()
+    out["sites"] = len(rec.gates)
+    floor = 1e-3 * float(np.median([v.norm().item() for v in g_inj.values()]))
+    rel = lambda a, b: (a - b).norm().item() / max(b.norm().item(), floor)  # noqa: E731
+    hip = {k: p.grad.double().cpu() for k, p in pm.named_parameters()}
+    out["bad"] = [k for k, g in hip.items() if not torch.isfinite(g).all()]
+    out["err_inj"] = {k: rel(hip[k], g_inj[k]) for k in g_inj}
+    out["cpu_inj"] = {k: rel(g32_inj[k], g_inj[k]) for k in g_inj}
+    out["err_true"] = {k: rel(hip[k], g_true[k]) for k in g_inj}
+    out["flip_eff"] = {k: rel(g_inj[k], g_true[k]) for k in g_inj}
+    return out
+
+
+def assert_gated_step(rep, tag, downstream=("decoder.", "aspp.aspp"), downstream_bound=3e-4, flip_rate=1e-4):
+    """the bounds every train-step parity test shares (no floors): rounding part within 3x (median) / 4x (90th percentile) / 3x (worst) of
+    stock f32 PyTorch under the same gates, the layers that do not sit upstream of a two-sample BN at the 1e-4 level, and no more gate
+    flips than a few times what stock f32 itself produces"""
+    import numpy as np
+
+    e, c = rep["err_inj"], rep["cpu_inj"]
+    med = lambda d, pre=None: float(np.median([v for k, v in d.items() if pre is None or k.startswith(pre)]))  # noqa: E731
+    q90 = lambda d: float(np.quantile(list(d.values()), 0.9))  # noqa: E731
+    worst = max(e.items(), key=lambda kv: kv[1])
+    cworst = max(c.items(), key=lambda kv: kv[1])
+    tworst = max(rep["err_true"].items(), key=lambda kv: kv[1])
+    print("%s: %d gate sites, %d units; flips vs f64: HIP %d, stock f32 %s (sites %s)" % (tag, rep["sites"], rep["units"], rep["flips"], rep.get("flips_cpu"),
+                                                                                       rep["flip_sites"][:6]))
+    print("   same gates -- rel-L2 vs f64: HIP median %.2e p90 %.2e worst %.2e (%s) | stock f32 median %.2e p90 %.2e worst %.2e (%s)"
+          % (med(e), q90(e), worst[1], worst[0], med(c), q90(c), cworst[1], cworst[0]))
+    print("   true ReLU -- HIP vs f64 median %.2e worst %.2e (%s); of which the flips alone (f64 vs f64) median %.2e worst %.2e"
+          % (med(rep["err_true"]), tworst[1], tworst[0], med(rep["flip_eff"]), max(rep["flip_eff"].values())))
+    assert not rep["bad"], rep["bad"][:5]
+    assert med(e) <= 3 * med(c) + 2e-6, (med(e), med(c))
+    assert q90(e) <= 4 * q90(c) + 1e-5, (q90(e), q90(c))
+    assert worst[1] <= 3 * cworst[1] + 1e-5, (worst, cworst)
+    down = [v for k, v in e.items() if any(k.startswith(d) for d in downstream)]
+    if down:
+        assert max(down) <= downstream_bound, max(down)
+    assert rep["flips"] <= max(4 * (rep.get("flips_cpu") or 0) + 8, flip_rate * rep["units"]), (rep["flips"], rep.get("flips_cpu"), rep["units"])

@@ -163,10 +163,11 @@ def test_f16x3_gradients_vs_f64(case):
 
 @pytest.mark.parametrize("backbone,seed", [("resnet", 31), ("mobilenet", 41)])
 def test_train_step_f16x3_vs_oracle_and_bf16x6(backbone, seed):
-    """one train-mode step (batch statistics): loss against the f64 oracle to 1e-5, every gradient of the f16x3 step within
-    the calibrated distance of stock f32 PyTorch to f64 (as tests/test_grad_parity_gpu.py), and the BN-emitted two-part rows
-    agree with the six-product engine's step to the rounding level (median)"""
+    """one train-mode step (batch statistics): loss against the f64 oracle to 1e-5; the gradients of the f16x3 AND the bf16x6 step
+    against the f64 oracle under each run's own gates, within the multiples of stock f32 PyTorch (same gates) that
+    tests/gate_replay.py:assert_gated_step states -- no floors; gate flips against the f64 forward counted and bounded"""
     from dass_hip import ops
+    from gate_replay import assert_gated_step, gated_step_report
     from models.deeplab import DeepLab
     from oracle import deeplab_cpu as O
     from oracle import selection_cpu as S
@@ -175,44 +176,23 @@ def test_train_step_f16x3_vs_oracle_and_bf16x6(backbone, seed):
     ncls, n, hw = 19, 4, 65
     om = O.ODeepLab(backbone, 16, ncls)
     O.fill_state_dict(om, seed=seed, randomize_bn_stats=False)
-    o64 = O.ODeepLab(backbone, 16, ncls)
-    o64.load_state_dict(om.state_dict())
-    o64 = o64.double().train()
-    om.train()
     x, lab = O.synthetic_batch(n, hw, hw, ncls, first_index=520)
     m1, m2 = O.dropout_masks(n, 1, seed=23)
-    l64 = S.ce_loss(o64(x.double(), (m1[0].double(), m2[0].double())), lab)
-    l64.backward()
-    l32 = S.ce_loss(om(x, (m1[0], m2[0])), lab)
-    l32.backward()
-    g64 = {k: p.grad for k, p in o64.named_parameters()}
-    floor = 1e-3 * float(np.median([v.norm().item() for v in g64.values()]))
-    rel = lambda g, k: (g - g64[k]).norm().item() / max(g64[k].norm().item(), floor)  # noqa: E731
-    cpu = {k: rel(p.grad.double(), k) for k, p in om.named_parameters()}
-    res = {}
+    med = {}
     for engine in ("f16x3", "bf16x6"):
         ops.set_f32_mma(engine)
         pm = DeepLab(backbone=backbone, output_stride=16, num_classes=ncls, sync_bn=False, pretrained=False)
         pm.load_state_dict(om.state_dict())
         pm = pm.cuda().train()
-        loss = SegmentationLosses(cuda=True).build_loss("ce")(pm(x.cuda(), dropout_masks=(m1[0].cuda(), m2[0].cuda())), lab.cuda())
-        loss.backward()
-        assert abs(loss.item() - l64.item()) <= 1e-5 * abs(l64.item()), (engine, loss.item(), l64.item())
-        res[engine] = {k: rel(p.grad.double().cpu(), k) for k, p in pm.named_parameters()}
-    med = lambda d: float(np.median(list(d.values())))  # noqa: E731
-    q90 = lambda d: float(np.quantile(list(d.values()), 0.9))  # noqa: E731
-    print(backbone, "gradient rel-L2 vs f64: f16x3 median %.2e p90 %.2e worst %.2e | bf16x6 median %.2e p90 %.2e | stock f32 median %.2e p90 %.2e"
-          % (med(res["f16x3"]), q90(res["f16x3"]), max(res["f16x3"].values()), med(res["bf16x6"]), q90(res["bf16x6"]), med(cpu), q90(cpu)))
-    # (5 x: which near-zero pre-activations flip differs between any two f32 evaluations of this step; with the exact-f32 stem kernel the
-    #  MobileNet run lands on 4.1 x stock f32's median, with the generic stem kernel it sat below 3 x.  Same gates on both sides:
-    #  tests/test_grad_parity_gpu.py::test_resnet_gradients_with_oracle_gates_injected)
-    assert med(res["f16x3"]) <= max(5 * med(cpu) + 2e-6, 1e-2)   # (stock f32's own median moves 3x between boxes: its thread count decides its flips)
-    assert q90(res["f16x3"]) <= max(4 * q90(cpu) + 1e-5, 1.5e-2)
-    assert max(res["f16x3"].values()) <= 3e-2
+        rep = gated_step_report(ops, O, S, pm, om.state_dict(), backbone, ncls, x, lab, (m1[0], m2[0]), SegmentationLosses(cuda=True).build_loss("ce"))
+        assert abs(rep["loss"] - rep["loss64"]) <= 1e-5 * abs(rep["loss64"]), (engine, rep["loss"], rep["loss64"])
+        # (MobileNet: every block's expand / depthwise BN sits between the ASPP's batch-4 image-pool BN and nothing -- only the decoder
+        #  and the ASPP conv branches are "downstream" in the sense of assert_gated_step)
+        assert_gated_step(rep, "%s %s" % (backbone, engine))
+        med[engine] = float(np.median(list(rep["err_inj"].values())))
     # (the six-product engine multiplies EXACT operands and is several times closer to f64 than any f32-input arithmetic; the
-    # two-part engine rounds operands to 23 bits and lands between it and stock f32 -- here amplified ~1e3 by the batch-4 BN of the
-    # ASPP image-pool branch, which is what this step's backbone gradients measure)
-    print("   f16x3 / bf16x6 median ratio %.1f" % (med(res["f16x3"]) / max(med(res["bf16x6"]), 1e-12)))
+    # two-part engine rounds operands to 23 bits and lands between it and stock f32)
+    print("   f16x3 / bf16x6 median ratio %.1f" % (med["f16x3"] / max(med["bf16x6"], 1e-12)))
 
 
 def test_mc_dropout_votes_f16x3_vs_oracle():
