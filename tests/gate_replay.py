@@ -107,11 +107,19 @@ class GateReplay(object):
         torch.nn.functional.hardtanh = hardtanh
 
     def flips_against(self, store):
-        """-> (units whose gate differs between the HIP forward and the recorded oracle forward, total units, [(site, flips)])"""
+        """-> (units whose gate differs between the HIP forward and the recorded oracle forward, total units, [(site, flips)]).
+        A HIP gate is recorded from the layer's OUTPUT, which at the two Dropout2d sites (aspp.bn1, decoder.last_conv) already carries the
+        mask: a dropped (image, channel) plane reads "all closed" there while the oracle's ReLU, which sits in front of its dropout, is
+        open -- no flip (the plane's gradient is zero on both sides), so planes that are closed throughout on the HIP side are left out."""
         tot = flips = 0
         sites = []
         for i, g in store:
-            d = int((self.gates[i] != g.cpu()).sum())
+            hg, og = self.gates[i], g.cpu()
+            diff = hg != og
+            if diff.dim() == 4:
+                dropped = ~hg.flatten(2).any(-1)            # [N, C]: nothing open in the plane
+                diff = diff & ~dropped[:, :, None, None]
+            d = int(diff.sum())
             flips += d
             tot += g.numel()
             if d:
@@ -174,7 +182,7 @@ def gated_step_report(ops, O, S, pm, state_dict, backbone, ncls, x, lab, masks, 
             rec.record_oracle(store32)
             S.ce_loss(o32(x, (m1, m2)), lab).backward()
             by_site = {i: g for i, g in store64}
-            out["flips_cpu"] = sum(int((by_site[i] != g).sum()) for i, g in store32)
+            out["flips_cpu"] = sum(int((by_site[i] != g).sum()) for i, g in store32)   # (both oracles gate in front of their dropout)
     finally:
         rec.restore()
     out["sites"] = len(rec.gates)
