@@ -86,6 +86,35 @@ __device__ __forceinline__ void dma16(v4i rsrc, unsigned lds, unsigned voff) {
                  : "memory");
 }
 
+// The NP pieces of ONE rowgroup (consecutive 1 KiB pieces in LDS, 64 B apart in memory) behind ONE write of M0: the instruction's
+// immediate offset is added to the LDS address (M0 + offset + 16 * lane) as well as to the memory address (base + voffset +
+// offset), so piece i goes out with offset:1024 i and a per-lane voffset that carries its true source minus 1024 i.  For that
+// difference never to wrap, every descriptor of this kernel starts X3_SRD_BIAS bytes BELOW its operand and every per-lane offset
+// carries + X3_SRD_BIAS (folded into chunk_off).  M0 is not restored: nothing the compiler emits for these kernels reads it (gfx9+ LDS
+// instructions do not), and every statement that needs it writes it itself -- as csrc/wgrad_x3.hip:wdma16x4 (round 4: 330 -> 111
+// instructions per slab there; here 6 SALU instructions less per rowgroup and slab).
+constexpr unsigned X3_SRD_BIAS = 2048;
+template <int NP> __device__ __forceinline__ void dma16_group(v4i rsrc, unsigned lds, unsigned voff) {
+    if constexpr (NP == 1) {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" : : "v"(voff), "s"(lds), "s"(rsrc) : "memory");
+    } else if constexpr (NP == 2) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %0, %3, 0 offen lds\n\t"
+                     "buffer_load_dwordx4 %1, %3, 0 offen offset:1024 lds"
+                     :
+                     : "v"(voff), "v"(voff + 64u - 1024u), "s"(lds), "s"(rsrc)
+                     : "memory");
+    } else {
+        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %0, %4, 0 offen lds\n\t"
+                     "buffer_load_dwordx4 %1, %4, 0 offen offset:1024 lds\n\t"
+                     "buffer_load_dwordx4 %2, %4, 0 offen offset:2048 lds"
+                     :
+                     : "v"(voff), "v"(voff + 64u - 1024u), "v"(voff + 128u - 2048u), "s"(lds), "s"(rsrc)
+                     : "memory");
+    }
+}
+
 __device__ __forceinline__ v4i make_srd(const void *base, unsigned bytes) {
     const unsigned long long a = (unsigned long long)base;
     v4i r;
@@ -214,7 +243,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     if (XE == 12) xt0 = wall_clock64();
     if (XE == 12 && p.R > 0) xa = wall_clock64();
 
-    const v4i rsa = make_srd(p.x3, p.x3_bytes), rsb = make_srd(p.w3, p.w3_bytes);
+    // (descriptors start X3_SRD_BIAS below their operands, every per-lane offset carries + X3_SRD_BIAS through chunk_off: dma16_group)
+    const v4i rsa = make_srd(p.x3 - X3_SRD_BIAS, p.x3_bytes + X3_SRD_BIAS), rsb = make_srd(p.w3 - X3_SRD_BIAS, p.w3_bytes + X3_SRD_BIAS);
     const unsigned smem_base = (unsigned)(size_t)smem;  // LDS byte address of the ring
 
     // ---- loader roles: this lane fetches row r16 = lane >> 2 of each of the wave's RG rowgroups, the 16-B chunk that
@@ -223,7 +253,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
     // {4-11,16-19,28-31} (+32): rows 0-3 / 12-15 of one chunk meet rows 4-11 of the neighbouring chunk, which the swizzle
     // (-(row >> 2)) & 3 keeps on distinct banks; (row >> 2) & 3 -- conflict-free for the 32x32x16 fragment -- is 2-way there)
     const int r16 = lane >> 2;
-    const unsigned chunk_off = (unsigned)(((lane & 3) ^ ((M16 ? 0 - (r16 >> 2) : (r16 >> 2)) & 3)) * 16);
+    const unsigned chunk_off = (unsigned)(((lane & 3) ^ ((M16 ? 0 - (r16 >> 2) : (r16 >> 2)) & 3)) * 16) + X3_SRD_BIAS;
     const int ntaps = p.R * p.S;
     const int ohw = p.OHs * p.OWs;
     const bool phase = SIMPLE ? false : p.o_mul != 1;
@@ -517,15 +547,11 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void conv_x3_kernel(cons
             const bool valid = (vm >> nx_t) & 1ull;
             const unsigned voff = valid ? rbo + nx_a_uni : p.zero_off + chunk_off;
             const unsigned dst = __builtin_amdgcn_readfirstlane(st + q * PG);
-            dma16(rsa, dst, voff);
-            if constexpr (NP >= 2) dma16(rsa, dst + 1024, voff + 64);
-            if constexpr (NP == 3) dma16(rsa, dst + 2048, voff + 128);
+            dma16_group<NP>(rsa, dst, voff);
         } else if (!XE_NO_DMAB) {
             const unsigned voff = rbo + nx_b_uni;
             const unsigned dst = __builtin_amdgcn_readfirstlane(st + A_BYTES + (q - AG) * PG);
-            dma16(rsb, dst, voff);
-            if constexpr (NP >= 2) dma16(rsb, dst + 1024, voff + 64);
-            if constexpr (NP == 3) dma16(rsb, dst + 2048, voff + 128);
+            dma16_group<NP>(rsb, dst, voff);
         }
     };
     bool exp_rd = true;
@@ -1347,7 +1373,7 @@ static int conv_x3_impl(const void *x3, const void *w3, void *y, int64_t ldy, vo
     const long xtr = x3_trailer_off((long)N * H * W, CC, parts), wtr = (long)K * R * S * CC * SB * (per_image ? N : 1);
     const long xbytes = xtr + 16, wbytes = wtr + 16;
     if (per_image && ustride != 1) return DASS_ERR_UNSUPPORTED;
-    if (xbytes >= (1l << 32) || wbytes >= (1l << 32)) return DASS_ERR_UNSUPPORTED;  // 32-bit buffer offsets
+    if (xbytes + X3_SRD_BIAS >= (1l << 32) || wbytes + X3_SRD_BIAS >= (1l << 32)) return DASS_ERR_UNSUPPORTED;  // 32-bit buffer offsets (+ the descriptor bias)
     if (y3 && (K & 3)) return DASS_ERR_ARG;
     if (!y && residual && (ldr & 3)) return DASS_ERR_ARG;
     X3P p;

@@ -8,6 +8,8 @@ import csv, glob, os, re, sys
 from collections import defaultdict
 
 fetch_dir, write_dir, steps = sys.argv[1], sys.argv[2], float(sys.argv[3])
+json_out = sys.argv[4] if len(sys.argv) > 4 else None     # {engine: {kernel symbol: HBM bytes per launch}} for bench.py's roofline.traffic
+engine = sys.argv[5] if len(sys.argv) > 5 else "f16x3"
 
 
 def load(d, counter):
@@ -46,3 +48,26 @@ for k in set(fe) | set(wr):
     rows.append((rd + ww, k, n, rd, ww, t))
 for tot, k, n, rd, ww, t in sorted(rows, reverse=True)[:24]:
     print("| `%s` | %.1f | %.1f | %.1f | %.3f | %s |" % (k[:80], n, rd, ww, t, ("%.2f" % (tot / 1e3 / t)) if t > 0 else "-"))
+
+# ---- per family against SURVEY 8(d)'s algorithmic bytes of config A (R101 513^2 batch 8, f32 tensors): conv 3 x (in + out) x 4 B + weights
+# = 22.55 GB, train-mode BN 4 passes x 4 B x 108 M elements x 8 images = 13.79 GB (bench.py:mixed_roofline computes both)
+fam = defaultdict(float)
+for tot, k, n, rd, ww, t in rows:
+    f = ("conv + weight gradient" if ("conv_x3" in k or "wgrad" in k or "conv_igemm" in k or "rowtap" in k or "conv_wgrad" in k) else
+         "BN family" if (k.startswith("bn_") or "colstat" in k or "sum_n" in k) else "other")
+    fam[f] += tot
+total = sum(fam.values())
+print("\nper family (GB / step): " + ", ".join("%s %.1f" % (k, v / 1e3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])) + "; total %.1f GB" % (total / 1e3))
+print("against the algorithmic bytes of config A: conv %.2fx of 22.55 GB, BN %.2fx of 13.79 GB, step %.2fx of 36.34 GB"
+      % (fam["conv + weight gradient"] / 22550.0, fam["BN family"] / 13790.0, total / 36340.0))
+if json_out:
+    import json
+    per = {}
+    for tot, k, n, rd, ww, t in rows:
+        if n > 0:
+            per[k.replace(", ", ",")] = round(tot * 1e6 / n, 1)
+    old = {}
+    if os.path.exists(json_out):
+        old = json.load(open(json_out))
+    old[engine] = per
+    json.dump(old, open(json_out, "w"), indent=1, sort_keys=True)
