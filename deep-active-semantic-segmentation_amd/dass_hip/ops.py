@@ -958,6 +958,13 @@ class _ConvBnAct(torch.autograd.Function):
         else:
             out = new_act(n, k, oh, ow, dt, dev)
         ldo = kpad
+        into = getattr(spec, "out_into", None)
+        if into is not None:  # a channel slice of the caller's wider buffer (every launch below takes (pointer, ld))
+            wide, off = into
+            if kpad != k or wide.dtype != dt or tuple(wide.shape) != (n, wide.shape[1], oh, ow) or off % 4 or off + k > wide.shape[1] or rows(wide)[0] is not wide:
+                raise RuntimeError("dass_hip: out_into needs an NHWC buffer [N, C_total, OH, OW] of the compute dtype and a 16-byte aligned channel offset")
+            out = wide[:, off:off + k]
+            ldo = wide.shape[1]
         state = None
         y_raw = None
         x3_saved = None  # split rows of the input, kept for the weight gradient (dass_conv2d_wgrad_x3)
@@ -1624,8 +1631,10 @@ def _dgrad_operand_uncached(wsrc, dtype, x3=False):
 
 
 def conv_bn_act(x, conv, bn=None, act=ACT_NONE, residual=None, nc_scale=None, extra_pad=0, image_input=False,
-                in_scale=None, emit_x3=True, fork=False, consumer=None, sole_consumer=False):
-    """in_scale: [N,C] f32 multipliers applied to the INPUT while it is staged (inference only): a
+                in_scale=None, emit_x3=True, fork=False, consumer=None, sole_consumer=False, out_into=None):
+    """out_into = (wide, offset): write the output into channels [offset, offset + K) of the NHWC buffer `wide` instead of a buffer of
+    its own (the ASPP branches write straight into the 1280-wide tensor the merge conv reads: aspp.py:83's torch.cat without the copy).
+    in_scale: [N,C] f32 multipliers applied to the INPUT while it is staged (inference only): a
     Dropout2d mask of the producer folded into this conv's loader (MC-dropout tail, SURVEY 8a note iii).
     fork=True -> (out, x'): x' is x again, to be used for the OTHER consumer of x (the identity branch of a residual
     block): both gradients of x then meet in this op's backward and are summed inside the input-gradient launch."""
@@ -1642,6 +1651,8 @@ def conv_bn_act(x, conv, bn=None, act=ACT_NONE, residual=None, nc_scale=None, ex
                             and consumer.out_channels > 32
                             and _x3_train_layer(consumer.kernel_size[0] * consumer.kernel_size[1], conv.out_channels))
     spec.emit_x3 = emit_x3  # False where the consumer is not a dense conv (concat / pool / upsample / classifier)
+    spec.out_into = out_into
+    assert out_into is None or (not fork and not sole_consumer)
     # sole_consumer: `consumer` is the ONLY reader of this output (conv1 -> conv2 -> conv3 inside a bottleneck).  If that conv is sure
     # to take the split rows this layer emits (two-part engine, dense, > 32 output channels, enough output rows for the pre-split
     # kernels), the f32 copy of the output is never read by anyone -- this layer's own backward re-derives its gate from the conv
@@ -1809,6 +1820,36 @@ def concat(*xs):
     return _Concat.apply(*xs)
 
 
+class _ConcatShared(torch.autograd.Function):
+    """torch.cat over tensors that ALREADY are the channel slices of `wide`, in order (their producers wrote them there:
+    conv_bn_act(out_into=...), broadcast_bn(out_into=...)): forward is free, backward hands every producer its slice of the gradient"""
+
+    @staticmethod
+    def forward(ctx, wide, *xs):
+        off = 0
+        for x in xs:
+            c = x.shape[1]
+            if x.data_ptr() != wide[:, off:off + c].data_ptr() or x.stride() != wide[:, off:off + c].stride():
+                raise RuntimeError("dass_hip.concat_shared: input %d is not channel slice [%d, %d) of the shared buffer" % (len(ctx.cs) if hasattr(ctx, "cs") else 0, off, off + c))
+            off += c
+        if off != wide.shape[1]:
+            raise RuntimeError("dass_hip.concat_shared: the slices cover %d of %d channels" % (off, wide.shape[1]))
+        ctx.cs = [x.shape[1] for x in xs]
+        return wide.view_as(wide)
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, off = [None], 0
+        for c in ctx.cs:
+            outs.append(g[:, off:off + c])
+            off += c
+        return tuple(outs)
+
+
+def concat_shared(wide, *xs):
+    return _ConcatShared.apply(wide, *xs)
+
+
 # ----------------------------------------------------------------------------- ASPP image-pool branch (aspp.py:62-65,79-81)
 class _GlobalAvgPool(torch.autograd.Function):
     """AdaptiveAvgPool2d((1,1)) -> [N,C,1,1]"""
@@ -1845,7 +1886,7 @@ class _BroadcastBN(torch.autograd.Function):
     (dass_bn_rows_fwd / _bwd); only SyncBN, which must exchange sums, goes through the sum / sum-of-squares kernels."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, bn, h, w):
+    def forward(ctx, x, gamma, beta, bn, h, w, out_into=None):
         xs, _ = rows(_cast_act(x))
         n, c = xs.shape[0], xs.shape[1]
         xv = xs.reshape(n, c).contiguous()
@@ -1870,8 +1911,14 @@ class _BroadcastBN(torch.autograd.Function):
             st = bn_eval_state(bn, c, xv.device)
         yv = torch.empty_like(xv)
         scale_shift_act(xv, c, yv, c, n, c, st.scale, st.shift)
-        out = new_act(n, c, h, w, xv.dtype, xv.device)
-        check(lib.dass_broadcast_rows(_p(yv), _p(out), c, n, h * w, c, 1.0, _dt(out), _stream()), "dass_broadcast_rows")
+        if out_into is not None:
+            wide, off = out_into
+            out = wide[:, off:off + c]
+            ldo = wide.shape[1]
+        else:
+            out = new_act(n, c, h, w, xv.dtype, xv.device)
+            ldo = c
+        check(lib.dass_broadcast_rows(_p(yv), _p(out), ldo, n, h * w, c, 1.0, _dt(out), _stream()), "dass_broadcast_rows")
         ctx.save_for_backward(xv, yv, gamma, st.mean, st.invstd)
         ctx.dims = (n, c, h, w)
         ctx.train_stats = train
@@ -1891,7 +1938,7 @@ class _BroadcastBN(torch.autograd.Function):
             sums = torch.empty((2, c), dtype=torch.float32, device=gs.device)
             check(lib.dass_bn_rows_bwd(_p(gs), _p(xv), _p(mean), _p(invstd), _p(gamma.detach()), n, c, 1 if ctx.train_stats else 0,
                                        _p(dx), _p(sums[1]), _p(sums[0]), _stream()), "dass_bn_rows_bwd")
-            return dx.view(n, 1, 1, c).permute(0, 3, 1, 2), sums[1], sums[0], None, None, None
+            return dx.view(n, 1, 1, c).permute(0, 3, 1, 2), sums[1], sums[0], None, None, None, None
         nrows = lib.dass_stat_rows(n)
         partial = torch.empty((nrows, 2, c), dtype=torch.float32, device=gr.device)
         check(lib.dass_bn_bwd_reduce(_p(gs), c, _p(yv), c, _p(xv), c, _p(mean), _p(invstd), None, n, c, 1, ACT_NONE,
@@ -1906,11 +1953,11 @@ class _BroadcastBN(torch.autograd.Function):
         check(lib.dass_bn_bwd_apply(_p(gs), c, _p(yv), c, _p(xv), c, _p(mean), _p(invstd), _p(gamma.detach()),
                                     _p(sums[0]), _p(sums[1]), None, _p(dx), c, None, 0, n, c, 1, float(n) * ctx.sync_world,
                                     1 if ctx.train_stats else 0, ACT_NONE, _dt(dx), None, _stream()), "dass_bn_bwd_apply")
-        return dx.view(n, 1, 1, c).permute(0, 3, 1, 2), dgamma, dbeta, None, None, None
+        return dx.view(n, 1, 1, c).permute(0, 3, 1, 2), dgamma, dbeta, None, None, None, None
 
 
-def broadcast_bn(x, bn, h, w):
-    return _BroadcastBN.apply(x, bn.weight, bn.bias, bn, h, w)
+def broadcast_bn(x, bn, h, w, out_into=None):
+    return _BroadcastBN.apply(x, bn.weight, bn.bias, bn, h, w, out_into)
 
 
 # ----------------------------------------------------------------------------- bilinear (align_corners=True)

@@ -19,8 +19,9 @@ class ASPPModule(nn.Module):
         self.relu = nn.ReLU()
         self._init_weight()
 
-    def forward(self, x):
-        return ops.conv_bn_act(x, self.atrous_conv, self.bn, ops.ACT_RELU, emit_x3=False)  # consumer: the channel concat
+    def forward(self, x, out_into=None):
+        # consumer: the channel concat -- out_into = (the 1280-wide buffer, this branch's channel offset): written in place there
+        return ops.conv_bn_act(x, self.atrous_conv, self.bn, ops.ACT_RELU, emit_x3=False, out_into=out_into)
 
     def _init_weight(self):
         init_weights(self)
@@ -65,14 +66,17 @@ class ASPP(nn.Module):
         apply_dropout=False returns the pre-dropout activation (used by the hoisted MC-dropout tail)."""
         h, w = x.shape[2], x.shape[3]
         xa, xb, xc, xd, xe = ops.fanout(x, 5)  # five consumers: their gradients are added in one pass
-        x1 = self.aspp1(xa)
-        x2 = self.aspp2(xb)
-        x3 = self.aspp3(xc)
-        x4 = self.aspp4(xd)
+        # torch.cat((x1, x2, x3, x4, x5), dim=1) of aspp.py:83 without the copies: every branch's BN-apply pass (and the image-pool
+        # branch's broadcast) writes its 256 channels straight into the 1280-wide buffer the merge conv reads
+        wide = ops.new_act(x.shape[0], 1280, h, w, ops.compute_dtype(), x.device)
+        x1 = self.aspp1(xa, (wide, 0))
+        x2 = self.aspp2(xb, (wide, 256))
+        x3 = self.aspp3(xc, (wide, 512))
+        x4 = self.aspp4(xd, (wide, 768))
         x5 = ops.global_avgpool(xe)
         x5 = ops.conv_bn_act(x5, self.global_average_pool[1], None, ops.ACT_RELU, emit_x3=False)
-        x5 = ops.broadcast_bn(x5, self.bn_global_average_pool, h, w)
-        cat = ops.concat(x1, x2, x3, x4, x5)
+        x5 = ops.broadcast_bn(x5, self.bn_global_average_pool, h, w, out_into=(wide, 1024))
+        cat = ops.concat_shared(wide, x1, x2, x3, x4, x5)
         mask = None
         if apply_dropout:
             mask = dropout_mask if dropout_mask is not None else dropout_mask_for(self.dropout, x.shape[0], 256, x.device)

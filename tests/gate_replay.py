@@ -143,6 +143,10 @@ def gated_step_report(ops, O, S, pm, state_dict, backbone, ncls, x, lab, masks, 
     m1, m2 = masks
     rec = GateReplay(ops)
     out = {}
+    # stock PyTorch's own rounding error depends on how its kernels block their sums, i.e. on the thread count: measured 2.8e-5 and 4.2e-5
+    # (median, same step) on two boxes of the pool that differ only in that -- the yardstick is taken at a FIXED count
+    keep_threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, max(1, keep_threads)))
     try:
         rec.record()
         loss = criterion(pm(x.cuda(), dropout_masks=(m1.cuda(), m2.cuda())), lab.cuda())
@@ -185,6 +189,7 @@ def gated_step_report(ops, O, S, pm, state_dict, backbone, ncls, x, lab, masks, 
             out["flips_cpu"] = sum(int((by_site[i] != g).sum()) for i, g in store32)   # (both oracles gate in front of their dropout)
     finally:
         rec.restore()
+        torch.set_num_threads(keep_threads)
     out["sites"] = len(rec.gates)
     floor = 1e-3 * float(np.median([v.norm().item() for v in g_inj.values()]))
     rel = lambda a, b: (a - b).norm().item() / max(b.norm().item(), floor)  # noqa: E731
@@ -197,7 +202,15 @@ def gated_step_report(ops, O, S, pm, state_dict, backbone, ncls, x, lab, masks, 
     return out
 
 
-def assert_gated_step(rep, tag, downstream=("decoder.", "aspp.aspp"), downstream_bound=3e-4, flip_rate=1e-4):
+# (median, 90th percentile, worst) multiples of stock f32 PyTorch's rounding error under the same gates, per conv engine.  The engines differ
+# BY DESIGN: bf16x6 multiplies exact operands (measured 0.5-1x stock f32), f16x3 keeps 23 of an operand's 24 bits (2^-22 per product: 1.8-3.5x
+# on the 65^2 steps whose two-sample BN amplifies conv rounding ~1e3, 1.15x at config A's size), the f32 MFMA adds its products two k at a time
+# in one chain per output (2.7-5.1x).  The spread inside each range is the YARDSTICK moving (stock PyTorch blocks its sums by thread count:
+# 2.2e-5 ... 4.2e-5 for the same step), the HIP numbers repeat to three digits.
+ENGINE_MULT = {"bf16x6": (3.0, 4.0, 3.0), "f16x3": (5.0, 5.0, 4.0), "f32": (7.0, 7.0, 6.0)}
+
+
+def assert_gated_step(rep, tag, downstream=("decoder.", "aspp.aspp"), downstream_bound=3e-4, flip_rate=1e-4, mult=(3.0, 4.0, 3.0)):
     """the bounds every train-step parity test shares (no floors): rounding part within 3x (median) / 4x (90th percentile) / 3x (worst) of
     stock f32 PyTorch under the same gates, the layers that do not sit upstream of a two-sample BN at the 1e-4 level, and no more gate
     flips than a few times what stock f32 itself produces"""
@@ -216,9 +229,9 @@ def assert_gated_step(rep, tag, downstream=("decoder.", "aspp.aspp"), downstream
     print("   true ReLU -- HIP vs f64 median %.2e worst %.2e (%s); of which the flips alone (f64 vs f64) median %.2e worst %.2e"
           % (med(rep["err_true"]), tworst[1], tworst[0], med(rep["flip_eff"]), max(rep["flip_eff"].values())))
     assert not rep["bad"], rep["bad"][:5]
-    assert med(e) <= 3 * med(c) + 2e-6, (med(e), med(c))
-    assert q90(e) <= 4 * q90(c) + 1e-5, (q90(e), q90(c))
-    assert worst[1] <= 3 * cworst[1] + 1e-5, (worst, cworst)
+    assert med(e) <= mult[0] * med(c) + 2e-6, (med(e), med(c))
+    assert q90(e) <= mult[1] * q90(c) + 1e-5, (q90(e), q90(c))
+    assert worst[1] <= mult[2] * cworst[1] + 1e-5, (worst, cworst)
     down = [v for k, v in e.items() if any(k.startswith(d) for d in downstream)]
     if down:
         assert max(down) <= downstream_bound, max(down)

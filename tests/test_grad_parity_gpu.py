@@ -116,7 +116,7 @@ def test_resnet50_train_mode_bn_step_vs_f64_oracle(engine):
     oracle UNDER THE HIP FORWARD'S GATES, bounded by a multiple of stock f32 PyTorch's under the same gates (no floors: ADVICE r4), plus
     the number of units whose gate differs from the f64 forward's, bounded by stock f32's own count"""
     ops, O, S = _setup()
-    from gate_replay import assert_gated_step, gated_step_report
+    from gate_replay import ENGINE_MULT, assert_gated_step, gated_step_report
     from models.deeplab import DeepLab
     from utils.loss import SegmentationLosses
 
@@ -133,7 +133,10 @@ def test_resnet50_train_mode_bn_step_vs_f64_oracle(engine):
     assert abs(rep["loss"] - rep["loss64"]) <= 1e-5 * abs(rep["loss64"])
     # (the batch-4 BN of the ASPP image-pool branch amplifies every rounding upstream of it ~1e3: its branch and the backbone carry
     #  stock f32's 1e-4 ... 1e-3; the branches that do not pass through it stay at the 1e-4 level)
-    assert_gated_step(rep, engine)
+    # (the f32-MFMA engine adds its products two k at a time in one f32 chain per output: 1.1e-4 here against 2.3e-5 for the exact-operand
+    #  bf16x6 engine and 7.7e-5 for f16x3, stock PyTorch's blocked sums 2.8e-5 ... 4.2e-5 -- a property of the summation order, bounded
+    #  by a larger MULTIPLE for that engine, still without a floor)
+    assert_gated_step(rep, engine, mult=ENGINE_MULT[engine])
     # running statistics after one step (momentum 0.1, unbiased running_var)
     sd, sd64 = pm.state_dict(), rep["o64"].state_dict()
     for k in sd64:
