@@ -37,6 +37,8 @@ def times(d):
 
 
 fe, wr, tm = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE"), times(fetch_dir)
+if steps <= 0:  # every train step ends in 6 sgd_multi_kernel launches (two param groups of R101: 64 tensors per launch), eager or replayed
+    steps = max(1.0, fe.get("sgd_multi_kernel", [6, 0.0])[0] / 6.0)
 print("counter units: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in kB; reads x2 (gfx950 correction); %g steps in the run (warm-up included)" % steps)
 print("| kernel | launches/step | read MB/step (x2) | write MB/step | ms/step (under PMC) | TB/s |\n|---|---|---|---|---|---|")
 rows = []
@@ -64,7 +66,7 @@ if json_out:
     import json
     per = {}
     for tot, k, n, rd, ww, t in rows:
-        if n > 0:
+        if n > 0 and not k.startswith("at::") and not k.startswith("__amd"):
             per[k.replace(", ", ",")] = round(tot * 1e6 / n, 1)
     old = {}
     if os.path.exists(json_out):

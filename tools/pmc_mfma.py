@@ -15,6 +15,8 @@ for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=T
         acc[name][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
             cnt[name] += 1
+if steps <= 0:
+    steps = max(1.0, cnt.get("sgd_multi_kernel", 6) / 6.0)
 print("| kernel | launches/step | MFMA-busy | MFMA instructions/step (M) | GUI_ACTIVE/8 per launch (k cycles) |\n|---|---|---|---|---|")
 rows = []
 for k, c in acc.items():

@@ -16,10 +16,10 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -- python3 bench.py --steps 2 --warmup 2 $FLAGS > "$OUT/pmc_$C.json" 2> "$OUT/pmc_$C.err"
   echo "pmc $C done"
 done
-python3 tools/pmc_bytes.py "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" 4 "$OUT/pmc_dominant.json" f16x3 > "$OUT/pmc_bytes.txt"
+python3 tools/pmc_bytes.py "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" 0 "$OUT/pmc_dominant.json" f16x3 > "$OUT/pmc_bytes.txt"
 #   3. matrix-pipe occupancy per kernel of the step: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$OUT/pmc_MFMA" -- python3 bench.py --steps 2 --warmup 2 $FLAGS > "$OUT/pmc_MFMA.json" 2> "$OUT/pmc_MFMA.err"
-python3 tools/pmc_mfma.py "$OUT/pmc_MFMA" 4 > "$OUT/pmc_mfma.txt"
+python3 tools/pmc_mfma.py "$OUT/pmc_MFMA" 0 > "$OUT/pmc_mfma.txt"
 echo "pmc MFMA done"
 # keep the merge-back small: the raw csv / db files stay on the box
 find "$OUT" -name "*.db" -size +20M -delete; find "$OUT" -name "*kernel_trace.csv" -size +20M -delete
