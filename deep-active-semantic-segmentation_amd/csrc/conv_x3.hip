@@ -1183,7 +1183,10 @@ template <int BM, int BN, int WARPS_M, int WARPS_N, int NSTAGE, int NP = 3> int 
     g_last_pick = (BM << 16) | (BN << 4) | ((has_simple && simple) ? 2 : 0) | (stream ? 1 : 0);
     if constexpr (has_simple) {
         if (simple) {
-            DASS_LAUNCH((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE, true, NP, true>), dim3(p.sk_wgs), dim3(64 * WARPS_M * WARPS_N), 0, st, p);
+            // (DASS_X3_LDS_PAD: bytes of dynamic LDS added to a whole-tile launch -- an occupancy experiment: the dispatcher then places fewer
+            //  workgroups per CU and has to spread a grid of ~2 tiles per CU more evenly; 0 = off)
+            static const int lds_pad = getenv("DASS_X3_LDS_PAD") ? atoi(getenv("DASS_X3_LDS_PAD")) : 0;
+            DASS_LAUNCH((conv_x3_kernel<BM, BN, WARPS_M, WARPS_N, NSTAGE, true, NP, true>), dim3(p.sk_wgs), dim3(64 * WARPS_M * WARPS_N), lds_pad, st, p);
             DASS_LAUNCH_CHECK();
             return DASS_OK;
         }

@@ -310,8 +310,8 @@ def test_fullsize_f16x3_values_vs_f64_dot_products(shape, tile):
 
 def test_config_b_r101_769_logits_vs_oracle():
     """BASELINE config B (R101 os16, 769 x 769) against the CPU oracle DIRECTLY (one image costs seconds on the box's
-    host cores, no need to argue it through properties): eval logits of one image within 1e-3 (relative to a logit scale of 50,
-    as in the 513 test), argmax identical outside near-ties.  Default engine (f16x3)."""
+    host cores, no need to argue it through properties): eval logits of one image within the contract's ABSOLUTE 1e-3 (measured
+    1.7e-4 on a logit scale of 60.6), argmax identical where the top-2 margin exceeds 1e-3.  Default engine (f16x3)."""
     pm, O = _r101(seed=7)
     om = O.ODeepLab("resnet101", 16, 19)
     O.fill_state_dict(om, seed=7)
@@ -325,7 +325,7 @@ def test_config_b_r101_769_logits_vs_oracle():
     scale = ref.abs().max().item()
     err = (got - ref).abs().max().item()
     top = ref.topk(2, dim=1)[0]
-    margin = 1e-3 * max(1.0, scale / 50)
+    margin = 1e-3
     safe = (top[:, 0] - top[:, 1]) > margin
     flips = int((got.argmax(1) != ref.argmax(1)).sum())
     print("config B 769^2 vs oracle: max |dlogit| %.2e on a logit scale of %.1f, argmax flips %d, near-ties %d" % (err, scale, flips, int((~safe).sum())))
