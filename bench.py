@@ -224,7 +224,13 @@ def work_model(backbone, size, classes, T=10):
         for cnt, n, h, w, c, k, ks, st, pad, dil in r101_conv_layers(1, size, 6 if backbone == "resnet" else 23):
             oh = _out(h, ks, st, pad, dil)
             fwd += cnt * oh * oh * k * ks * ks * c / 1e9
-    return {"forward_gflop": 2 * fwd, "train_gflop": 6 * fwd, "mc_gflop": 2 * ((fwd - tail) + T * tail), "coreset_gflop": 2 * (fwd - tail)}
+    # what the MC-dropout tail EXECUTES (DASS_MC_SPARSE, the default): of last_conv.0's 304 input channels the 256 that come from the ASPP carry
+    # the Dropout2d(0.5) mask of aspp.py:70; the surviving ones are packed to the front and the slab loop stops behind them -- Binomial(256, 0.5)
+    # + 48 channels = 6 of 10 32-channel slabs in 95 % of the draws (5 in 3 %, 7 in 2 %)
+    conv0 = s4 * s4 * 304 * 256 * 9 / 1e9
+    tail_exec = tail - 0.4 * conv0
+    return {"forward_gflop": 2 * fwd, "train_gflop": 6 * fwd, "mc_gflop": 2 * ((fwd - tail) + T * tail), "coreset_gflop": 2 * (fwd - tail),
+            "mc_executed_gflop": 2 * ((fwd - tail) + T * tail_exec)}
 
 
 def mixed_roofline(args, peak_tflops):
@@ -621,6 +627,10 @@ def run_mode(args, env, dtype_name, steps, warmup, mma="bf16x6"):
                                   "so one GPU scores the whole 2975-image pool in 2975 / value seconds",
                      "scoring_batch": b, "seconds": round(dts, 4), "selected": len(selected),
                      "frac_of_mfma_peak": round(pool_ips * wm["mc_gflop"] / 1e3 / (MFMA_PEAK_TFLOPS[engine] * world), 4),
+                     "gflop_per_image": {"algorithmic": round(wm["mc_gflop"], 1), "executed": round(wm["mc_executed_gflop"], 1),
+                                         "note": "algorithmic = prefix once + T x last_conv (SURVEY 8d); executed = the same with the channel slabs Dropout2d "
+                                                 "zeroed skipped in last_conv.0 (6 of 10 slabs on average): work avoided, not matrix-pipe utilisation"},
+                     "executed_frac_of_mfma_peak": round(pool_ips * wm["mc_executed_gflop"] / 1e3 / (MFMA_PEAK_TFLOPS[engine] * world), 4),
                      "sharding": "contiguous key shards per rank + RCCL all_gather of per-image scores" if world > 1 else "single rank"}
 
         # -------------------------------------------------------------- config E: core-set features + k-center greedy
@@ -1002,7 +1012,7 @@ def compact_line(full):
                                      "vs_baseline", "dtype", "data")}
     line["config"] = _pick(full.get("config") or {}, "workload", "global_batch", "parallelism", "bn", "f32_mma", "hip_graph", "final_loss", "replicas_identical", "ddp")
     mc = full.get("mc_dropout")
-    line["mc_dropout"] = _pick(mc, "value", "unit", "T", "pool_images", "scoring_batch", "frac_of_mfma_peak") if mc else None
+    line["mc_dropout"] = _pick(mc, "value", "unit", "T", "pool_images", "scoring_batch", "frac_of_mfma_peak", "executed_frac_of_mfma_peak") if mc else None
     cs = full.get("core_set")
     if cs:
         line["core_set"] = _pick(cs, "value", "unit", "frac_of_mfma_peak")
