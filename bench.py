@@ -1114,10 +1114,14 @@ def main():
     torch.cuda.set_device(local_rank)
     env.dev = torch.device("cuda", local_rank)
     env.dist = None
-    if env.world > 1:
+    # (DASS_DIST_FORCE=1 with one rank: the multi-process step -- graph A, RCCL all-reduce, graph B -- rehearsed on a one-GPU box with the real backend)
+    if env.world > 1 or os.environ.get("DASS_DIST_FORCE") == "1":
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend=os.environ.get("DASS_BENCH_BACKEND", "nccl"))  # nccl = RCCL on ROCm
         env.dist = dist
 

@@ -71,19 +71,24 @@ class GraphedStep(object):
             raise RuntimeError("dass_graph_capture_open failed (pinned staging tables)")
         _capture_hooks = self.hooks
         ok = False
+        # with a process group alive, its watchdog thread polls events while this thread captures: "thread_local" keeps another thread's
+        # harmless runtime calls from invalidating the capture (the launches of autograd's backward thread are captured in either mode)
+        import torch.distributed as dist
+
+        mode = {"capture_error_mode": "thread_local"} if (dist.is_available() and dist.is_initialized()) else {}
         try:
             if before is not None:
                 before()
             self.graph = torch.cuda.CUDAGraph()
             ops.graph_capture_begin()
             try:
-                with torch.cuda.graph(self.graph):
+                with torch.cuda.graph(self.graph, **mode):
                     self.out = fn()
             finally:
                 ops.graph_capture_end()
             if finish is not None:
                 self.graph_b = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph_b, pool=self.graph.pool()):
+                with torch.cuda.graph(self.graph_b, pool=self.graph.pool(), **mode):
                     finish()
                 ops.weights_changed()
             ok = True

@@ -22,7 +22,7 @@ explicit opt-in here -- SegmentationLosses(..., global_batch=True) -- because it
 import torch
 
 from dass_hip import ops
-from dass_hip.dist import global_batch_mean, sum_over_ranks, world_size
+from dass_hip.dist import collectives_on, global_batch_mean, sum_over_ranks
 
 
 class SegmentationLosses(object):
@@ -45,7 +45,7 @@ class SegmentationLosses(object):
 
     def _global(self):
         """does this call exchange its numerator / counts with the other ranks?"""
-        return bool(self.global_batch) and world_size() > 1 and (torch.is_grad_enabled() or self.global_batch_in_eval)
+        return bool(self.global_batch) and collectives_on() and (torch.is_grad_enabled() or self.global_batch_in_eval)
 
     def build_loss(self, mode='ce'):
         if mode == 'ce':
