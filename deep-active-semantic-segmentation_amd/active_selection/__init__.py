@@ -7,18 +7,23 @@ from active_selection.max_subset import ActiveSelectionMaxSubset
 from active_selection.mc_dropout import ActiveSelectionMCDropout
 from active_selection.mc_noise import ActiveSelectionMCNoise
 
+# --active-selection-mode -> (selector class, does its constructor take the class count first?)   (active_train.py:445-514)
+_SELECTORS = {}
+for _cls, _with_classes, _modes in (
+        (ActiveSelectionCoreSet, False, ('coreset',)),
+        (ActiveSelectionCEAL, True, ('ceal_confidence', 'ceal_margin', 'ceal_entropy', 'ceal_fusion', 'ceal_entropy_weakly_labeled')),
+        (ActiveSelectionMCNoise, True, ('noise_image', 'noise_feature', 'noise_variance')),
+        (ActiveSelectionMCDropout, True, ('variance', 'variance_representative', 'random'))):
+    for _m in _modes:
+        _SELECTORS[_m] = (_cls, _with_classes)
+
 
 def get_active_selection_class(active_selection_method, dataset_num_classes, dataset_lmdb_env, crop_size, dataloader_batch_size):
-    if active_selection_method == 'coreset':
-        return ActiveSelectionCoreSet(dataset_lmdb_env, crop_size, dataloader_batch_size)
-    elif active_selection_method in ('ceal_confidence', 'ceal_margin', 'ceal_entropy', 'ceal_fusion', 'ceal_entropy_weakly_labeled'):
-        return ActiveSelectionCEAL(dataset_num_classes, dataset_lmdb_env, crop_size, dataloader_batch_size)
-    elif active_selection_method in ('noise_image', 'noise_feature', 'noise_variance'):
-        return ActiveSelectionMCNoise(dataset_num_classes, dataset_lmdb_env, crop_size, dataloader_batch_size)
-    elif active_selection_method in ('variance', 'variance_representative', 'random'):
-        return ActiveSelectionMCDropout(dataset_num_classes, dataset_lmdb_env, crop_size, dataloader_batch_size)
-    else:
+    if active_selection_method not in _SELECTORS:   # (incl. 'accuracy_labels' / 'accuracy_eval': the predictor network is out of scope)
         raise NotImplementedError
+    cls, with_classes = _SELECTORS[active_selection_method]
+    args = (dataset_lmdb_env, crop_size, dataloader_batch_size)
+    return cls(dataset_num_classes, *args) if with_classes else cls(*args)
 
 
 def get_max_subset_active_selector(dataset_lmdb_env, crop_size, dataloader_batch_size):

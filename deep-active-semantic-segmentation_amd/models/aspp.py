@@ -30,31 +30,23 @@ class ASPPModule(nn.Module):
 
 class ASPP(nn.Module):
 
+    INPLANES = {'resnet': 2048, 'resnet101': 2048, 'mobilenet': 320}
+    RATES = {16: (1, 6, 12, 18), 8: (1, 12, 24, 36)}
+
     def __init__(self, backbone, output_stride, batchnorm):
         super(ASPP, self).__init__()
-        if backbone in ('resnet', 'resnet101'):
-            inplanes = 2048
-        elif backbone == 'mobilenet':
-            inplanes = 320
-        else:
+        if backbone not in self.INPLANES:
             raise Exception('Unknown backbone')
-
-        if output_stride == 16:
-            dilations = [1, 6, 12, 18]
-        elif output_stride == 8:
-            dilations = [1, 12, 24, 36]
-        else:
+        if output_stride not in self.RATES:
             raise NotImplementedError
-
-        self.aspp1 = ASPPModule(inplanes, 256, 1, padding=0, dilation=dilations[0], batchnorm=batchnorm)
-        self.aspp2 = ASPPModule(inplanes, 256, 3, padding=dilations[1], dilation=dilations[1], batchnorm=batchnorm)
-        self.aspp3 = ASPPModule(inplanes, 256, 3, padding=dilations[2], dilation=dilations[2], batchnorm=batchnorm)
-        self.aspp4 = ASPPModule(inplanes, 256, 3, padding=dilations[3], dilation=dilations[3], batchnorm=batchnorm)
-        self.global_average_pool = nn.Sequential(nn.AdaptiveAvgPool2d((1, 1)),
-                                                 nn.Conv2d(inplanes, 256, 1, stride=1, bias=False),
-                                                 nn.ReLU())
+        inplanes = self.INPLANES[backbone]
+        # aspp1: the 1x1 branch; aspp2-4: 3x3 at the three larger rates, padding = rate (aspp.py:46-59)
+        for i, rate in enumerate(self.RATES[output_stride], start=1):
+            k = 1 if i == 1 else 3
+            setattr(self, "aspp%d" % i, ASPPModule(inplanes, 256, k, padding=rate * (k // 2), dilation=rate, batchnorm=batchnorm))
+        self.global_average_pool = nn.Sequential(nn.AdaptiveAvgPool2d((1, 1)), nn.Conv2d(inplanes, 256, 1, stride=1, bias=False), nn.ReLU())
         self.bn_global_average_pool = batchnorm(256)
-        self.conv1 = nn.Conv2d(1280, 256, 1, bias=False)
+        self.conv1 = nn.Conv2d(5 * 256, 256, 1, bias=False)
         self.bn1 = batchnorm(256)
         self.relu = nn.ReLU()
         self.dropout = nn.Dropout2d(0.5)

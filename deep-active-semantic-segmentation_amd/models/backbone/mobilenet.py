@@ -16,24 +16,25 @@ def conv_bn(inplanes, outplanes, stride, batchnorm):
     return nn.Sequential(nn.Conv2d(inplanes, outplanes, 3, stride, 1, bias=False), batchnorm(outplanes), nn.ReLU6(inplace=True))
 
 
+def _conv_bn_act(cin, cout, k, stride, dilation, groups, batchnorm, act):
+    """[conv, BN(, ReLU6)] -- the unit every entry of an inverted-residual block's `conv` Sequential is made of"""
+    unit = [nn.Conv2d(cin, cout, k, stride, 0, dilation, groups=groups, bias=False), batchnorm(cout)]
+    return unit + [nn.ReLU6(inplace=True)] if act else unit
+
+
 class InvertedResidual(nn.Module):
 
     def __init__(self, inplanes, outplanes, stride, dilation, expand_ratio, batchnorm):
         super(InvertedResidual, self).__init__()
-        self.stride = stride
-        assert stride in [1, 2]
-        hidden_dim = round(inplanes * expand_ratio)
-        self.use_res_connect = self.stride == 1 and inplanes == outplanes
-        self.kernel_size = 3
-        self.dilation = dilation
+        assert stride in (1, 2)
+        hidden = round(inplanes * expand_ratio)
+        self.stride, self.dilation, self.kernel_size = stride, dilation, 3
         self.expand = expand_ratio != 1
-        layers = []
-        if self.expand:
-            layers += [nn.Conv2d(inplanes, hidden_dim, 1, 1, 0, 1, bias=False), batchnorm(hidden_dim), nn.ReLU6(inplace=True)]
-        layers += [nn.Conv2d(hidden_dim, hidden_dim, 3, stride, 0, dilation, groups=hidden_dim, bias=False),
-                   batchnorm(hidden_dim), nn.ReLU6(inplace=True),
-                   nn.Conv2d(hidden_dim, outplanes, 1, 1, 0, 1, bias=False), batchnorm(outplanes)]
-        self.conv = nn.Sequential(*layers)
+        self.use_res_connect = stride == 1 and inplanes == outplanes
+        # (mobilenet.py:33-66) pointwise expand (absent at ratio 1) -> depthwise 3x3, pad 0 (the block pads its own input) -> linear pointwise
+        units = ([(inplanes, hidden, 1, 1, 1, 1, True)] if self.expand else []) + [(hidden, hidden, 3, stride, dilation, hidden, True),
+                                                                                   (hidden, outplanes, 1, 1, 1, 1, False)]
+        self.conv = nn.Sequential(*[m for cin, cout, k, st, dil, g, act in units for m in _conv_bn_act(cin, cout, k, st, dil, g, batchnorm, act)])
 
     def forward(self, x):
         d = self.dilation  # fixed_padding for k=3: d on every side
@@ -51,36 +52,22 @@ class InvertedResidual(nn.Module):
 
 class MobileNetV2(nn.Module):
 
+    # (expansion t, channels c, blocks n, stride s) of the seven stages (mobilenet.py:92-101)
+    STAGES = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1))
+
     def __init__(self, input_channels=3, output_stride=8, batchnorm=None, width_mult=1., pretrained=True, mc_dropout=False):
         super(MobileNetV2, self).__init__()
-        block = InvertedResidual
-        input_channel = 32
-        current_stride = 1
-        rate = 1
-        inverted_residual_setting = [
-            # t, c, n, s
-            [1, 16, 1, 1],
-            [6, 24, 2, 2],
-            [6, 32, 3, 2],
-            [6, 64, 4, 2],
-            [6, 96, 3, 1],
-            [6, 160, 3, 2],
-            [6, 320, 1, 1],
-        ]
-        input_channel = int(input_channel * width_mult)
-        features = [conv_bn(input_channels, input_channel, 2, batchnorm)]
-        current_stride *= 2
-        for t, c, n, s in inverted_residual_setting:
-            if current_stride == output_stride:
-                stride, dilation = 1, rate
-                rate *= s
+        width = int(32 * width_mult)
+        features = [conv_bn(input_channels, width, 2, batchnorm)]
+        reached, rate = 2, 1          # stride reached so far; dilation that replaces further striding once output_stride is reached
+        for t, c, n, s in self.STAGES:
+            if reached == output_stride:
+                stride, dilation, rate = 1, rate, rate * s
             else:
-                stride, dilation = s, 1
-                current_stride *= s
-            output_channel = int(c * width_mult)
+                stride, dilation, reached = s, 1, reached * s
             for i in range(n):
-                features.append(block(input_channel, output_channel, stride if i == 0 else 1, dilation, t, batchnorm))
-                input_channel = output_channel
+                features.append(InvertedResidual(width, int(c * width_mult), stride if i == 0 else 1, dilation, t, batchnorm))
+                width = int(c * width_mult)
         if mc_dropout:
             features.append(nn.Dropout2d(p=constants.MC_DROPOUT_RATE))
         self.features = nn.Sequential(*features)

@@ -15,16 +15,15 @@ class Bottleneck(nn.Module):
 
     def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, batchnorm=None):
         super(Bottleneck, self).__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
-        self.bn1 = batchnorm(planes)
-        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, dilation=dilation, padding=dilation, bias=False)
-        self.bn2 = batchnorm(planes)
-        self.conv3 = nn.Conv2d(planes, planes * self.expansion, kernel_size=1, bias=False)
-        self.bn3 = batchnorm(planes * self.expansion)
+        # the block's three conv + BN pairs as data (resnet.py:9-20): (in, out, kernel, stride, dilation); registration order = the
+        # reference's state_dict order conv1, bn1, conv2, bn2, conv3, bn3
+        plan = ((inplanes, planes, 1, 1, 1), (planes, planes, 3, stride, dilation), (planes, planes * self.expansion, 1, 1, 1))
+        for i, (cin, cout, k, st, dil) in enumerate(plan, start=1):
+            setattr(self, "conv%d" % i, nn.Conv2d(cin, cout, kernel_size=k, stride=st, dilation=dil, padding=dil * (k // 2), bias=False))
+            setattr(self, "bn%d" % i, batchnorm(cout))
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
-        self.stride = stride
-        self.dilation = dilation
+        self.stride, self.dilation = stride, dilation
 
     def forward(self, x):
         if self.downsample:
@@ -41,30 +40,27 @@ class Bottleneck(nn.Module):
         return ops.conv_bn_act(out, self.conv3, self.bn3, ops.ACT_RELU, residual=residual)
 
 
+# (stride, dilation) of the four stages per output stride (resnet.py:50-57) and the multi-grid rates of the last one (resnet.py:48)
+_STAGE_GEOMETRY = {16: ((1, 1), (2, 1), (2, 1), (1, 2)), 8: ((1, 1), (2, 1), (1, 2), (1, 4))}
+_MULTI_GRID = (1, 2, 4)
+_STAGE_PLANES = (64, 128, 256, 512)
+
+
 class ResNet(nn.Module):
 
     def __init__(self, block, layers, output_stride, batchnorm, pretrained=True):
-        self.inplanes = 64
         super(ResNet, self).__init__()
-        blocks = [1, 2, 4]
-        if output_stride == 16:
-            strides = [1, 2, 2, 1]
-            dilations = [1, 1, 1, 2]
-        elif output_stride == 8:
-            strides = [1, 2, 1, 1]
-            dilations = [1, 1, 2, 4]
-        else:
+        if output_stride not in _STAGE_GEOMETRY:
             raise NotImplementedError
-
-        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
-        self.bn1 = batchnorm(64)
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, self.inplanes, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = batchnorm(self.inplanes)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
-
-        self.layer1 = self._make_layer(block, 64, layers[0], stride=strides[0], dilation=dilations[0], batchnorm=batchnorm)
-        self.layer2 = self._make_layer(block, 128, layers[1], stride=strides[1], dilation=dilations[1], batchnorm=batchnorm)
-        self.layer3 = self._make_layer(block, 256, layers[2], stride=strides[2], dilation=dilations[2], batchnorm=batchnorm)
-        self.layer4 = self._make_MG_unit(block, 512, blocks=blocks, stride=strides[3], dilation=dilations[3], batchnorm=batchnorm)
+        for i, ((stride, dilation), planes) in enumerate(zip(_STAGE_GEOMETRY[output_stride], _STAGE_PLANES)):
+            # stages 1-3: layers[i] blocks at one rate; stage 4: the multi-grid unit, one block per rate whatever layers[3] says
+            rates = [dilation] * layers[i] if i < 3 else [m * dilation for m in _MULTI_GRID]
+            setattr(self, "layer%d" % (i + 1), self._stage(block, planes, stride, rates, batchnorm))
         self._layers = layers
         self._init_weight()
         if pretrained:
@@ -82,28 +78,18 @@ class ResNet(nn.Module):
         x = self.layer4(x)
         return x, low_level_feat
 
-    def _downsample(self, planes, block, stride, batchnorm):
-        if stride != 1 or self.inplanes != planes * block.expansion:
-            return nn.Sequential(
-                nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
-                batchnorm(planes * block.expansion))
-        return None
-
-    def _make_layer(self, block, planes, blocks, stride=1, dilation=1, batchnorm=None):
-        downsample = self._downsample(planes, block, stride, batchnorm)
-        layers = [block(self.inplanes, planes, stride, dilation, downsample, batchnorm)]
-        self.inplanes = planes * block.expansion
-        for _ in range(1, blocks):
-            layers.append(block(self.inplanes, planes, dilation=dilation, batchnorm=batchnorm))
-        return nn.Sequential(*layers)
-
-    def _make_MG_unit(self, block, planes, blocks, stride=1, dilation=1, batchnorm=None):
-        downsample = self._downsample(planes, block, stride, batchnorm)
-        layers = [block(self.inplanes, planes, stride, dilation=blocks[0] * dilation, downsample=downsample, batchnorm=batchnorm)]
-        self.inplanes = planes * block.expansion
-        for i in range(1, len(blocks)):
-            layers.append(block(self.inplanes, planes, dilation=blocks[i] * dilation, batchnorm=batchnorm))
-        return nn.Sequential(*layers)
+    def _stage(self, block, planes, stride, rates, batchnorm):
+        """one residual stage: the first block carries the stride and -- when the shape changes -- the 1x1 projection of the skip path
+        (`downsample.0` / `.1` in the state_dict), the others keep stride 1; block j runs at dilation rates[j]"""
+        out_planes = planes * block.expansion
+        project = None
+        if stride != 1 or self.inplanes != out_planes:
+            project = nn.Sequential(nn.Conv2d(self.inplanes, out_planes, kernel_size=1, stride=stride, bias=False), batchnorm(out_planes))
+        blocks = []
+        for j, rate in enumerate(rates):
+            blocks.append(block(self.inplanes, planes, stride if j == 0 else 1, rate, project if j == 0 else None, batchnorm))
+            self.inplanes = out_planes
+        return nn.Sequential(*blocks)
 
     def _init_weight(self):
         init_weights(self)
