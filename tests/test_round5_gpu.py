@@ -170,3 +170,27 @@ def test_two_rank_graphed_ddp_step_keeps_replicas_identical(tmp_path):
     assert e["config"]["hip_graph"] is False and e["config"]["replicas_identical"] is True
     print("graphed", g["config"]["final_loss"], "eager", e["config"]["final_loss"])
     assert abs(g["config"]["final_loss"] - e["config"]["final_loss"]) <= 2e-5 * abs(e["config"]["final_loss"]) + 1e-5   # (the line rounds to 5 digits)
+
+
+def test_graphed_step_beside_a_live_rccl_group(tmp_path):
+    """The multi-process step with the REAL backend, as far as one GPU allows: `DASS_DIST_FORCE=1` keeps an RCCL process group of ONE rank alive and
+    runs every collective of the step over it (the exchange of the loss's denominators ahead of graph A, the in-place all-reduce of the weight-
+    gradient arena between the graphs) while its watchdog thread polls beside the captures.  The line must report the graphed multi-process form,
+    and its loss must equal the single-process graphed step's (a one-rank all-reduce changes no value; deterministic mode on both sides)."""
+    def run(force):
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        env.update(DASS_DETERMINISTIC="1", MASTER_PORT="29583")
+        if force:
+            env["DASS_DIST_FORCE"] = "1"
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--size", "129", "--batch", "2", "--backbone", "resnet",
+               "--graph", "on", "--no-mc", "--no-roofline", "--no-second-dtype", "--no-cpu-baseline", "--no-pool-reader"]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    f = run(True)
+    assert f["config"]["hip_graph"] is True and "graph A" in f["config"]["ddp"] and f["config"]["replicas_identical"] is True, f["config"]
+    s = run(False)
+    assert s["config"]["hip_graph"] is True and s["config"].get("ddp") is None
+    print("one rank over RCCL", f["config"]["final_loss"], "single process", s["config"]["final_loss"])
+    assert abs(f["config"]["final_loss"] - s["config"]["final_loss"]) <= 2e-5 * abs(s["config"]["final_loss"]) + 1e-5
