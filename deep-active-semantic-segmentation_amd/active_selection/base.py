@@ -114,16 +114,24 @@ def _cat_samples(samples):
     return torch.cat(list(samples), dim=0)
 
 
-def score_merge(batch_size=None):
-    """loader batches per scoring forward.  DASS_SCORE_MERGE when set (1 = the loader's own batches); otherwise 2 while the merged
-    forward stays at or below 16 images -- the size up to which the encoder's 33 x 33 layers gain from it -- and 1 above: a user who
-    sized `dataloader_batch_size` to the memory of a 769^2 crop or a large T is not handed twice that behind their back."""
+def score_merge(batch_size=None, most=2):
+    """loader batches per scoring forward.  DASS_SCORE_MERGE when set (1 = the loader's own batches); otherwise the largest factor <= `most` that
+    keeps the merged forward at or below 8 x most images, 1 above: a user who sized `dataloader_batch_size` to the memory of a 769^2 crop or a large
+    T is not handed a multiple of it behind their back.  Measured on R101 with the driver's batch of 8 (tools/score_merge_sweep.sh), 1 / 2 / 3 / 4
+    batches per forward: core-set features 1274 / 1448 / 1564-1581 / 1441 pool images/s -> the feature pass asks for most = 3; MC-dropout 565 / 631 /
+    637-644 / 626 at 513^2 but 298 -> 285 at 769^2 with three -> the T-pass selectors stay at most = 2 (the encoder's 33 x 33 layers fill the chip
+    from ~16 images on; beyond 24 the tile counts quantise worse again)."""
     import os
 
     env = os.environ.get("DASS_SCORE_MERGE")
     if env is not None:
         return max(1, int(env))
-    return 2 if batch_size is None or 2 * int(batch_size) <= 16 else 1
+    if batch_size is None:
+        return 2
+    for m in range(int(most), 1, -1):
+        if m * int(batch_size) <= 8 * int(most):
+            return m
+    return 1
 
 
 class ActiveSelectionBase:

@@ -59,7 +59,7 @@ class ActiveSelectionCoreSet(ActiveSelectionBase):
         main = torch.cuda.current_stream(dev)
         used_side = False
         with torch.no_grad():
-            for i, sample in enumerate(merged_batches(self.make_loader(local, False), score_merge(self.dataloader_batch_size))):
+            for i, sample in enumerate(merged_batches(self.make_loader(local, False), score_merge(self.dataloader_batch_size, most=3))):
                 batch = (sample['image'] if isinstance(sample, dict) else sample).to(dev)
                 side = lanes[i % len(lanes)] if i > 0 else None
                 if side is not None:

@@ -740,7 +740,7 @@ def test_merged_batches_tolerate_non_tensor_keys_and_ragged_shapes():
     assert [t.shape[0] for t in bare] == [4, 2]
     keep = os.environ.pop("DASS_SCORE_MERGE", None)
     try:
-        assert score_merge(8) == 2 and score_merge(16) == 1 and score_merge(None) == 2
+        assert score_merge(8) == 2 and score_merge(16) == 1 and score_merge(None) == 2 and score_merge(8, most=3) == 3 and score_merge(12, most=3) == 2
         os.environ["DASS_SCORE_MERGE"] = "3"
         assert score_merge(64) == 3
     finally:
