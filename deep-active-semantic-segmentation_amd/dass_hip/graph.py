@@ -83,7 +83,12 @@ class GraphedStep(object):
             ops.graph_capture_begin()
             try:
                 with torch.cuda.graph(self.graph, **mode):
-                    self.out = fn()
+                    out = fn()
+                # the static result WITHOUT its autograd history: holding the captured loss itself would keep the step's graph nodes -- and
+                # the parameters' AccumulateGrad nodes, bound to the capture stream -- alive for as long as this object lives, and a later
+                # eager step or capture of the same model would find them on the wrong stream
+                self.out = out.detach() if torch.is_tensor(out) else out
+                del out
             finally:
                 ops.graph_capture_end()
             if finish is not None:
@@ -106,6 +111,7 @@ class GraphedStep(object):
             lib.dass_graph_release(self.token)
             self.token = 0
         self.graph = self.graph_b = None
+        self.out = None
 
     def __del__(self):
         try:
