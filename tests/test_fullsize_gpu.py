@@ -409,3 +409,30 @@ def test_config_c_mobilenet_voc_batch16_train_steps():
         losses.append(loss.item())
     assert abs(losses[0] - ref_loss) <= 2e-4 * abs(ref_loss), (losses[0], ref_loss)
     assert losses[3] < losses[0], losses
+
+
+def test_config_c_full_size_gradients_under_the_hip_gates():
+    """BASELINE config C at its size (MobileNetV2, 21 classes, 513 x 513; batch 4 keeps the f64 oracle passes at seconds): every parameter gradient
+    of one train-mode step against the f64 oracle UNDER THE HIP FORWARD'S OWN GATES (ReLU6: both kinks), bounded by the f16x3 multiples of stock f32
+    PyTorch under the same gates, gate flips against the f64 forward counted (tests/gate_replay.py) -- the strip depthwise kernels, the BN sums that
+    ride in them and the expand / project 1x1 layers at 257^2 ... 33^2, none of which a 65^2 test reaches at these tile counts."""
+    from dass_hip import ops
+    from gate_replay import ENGINE_MULT, assert_gated_step, gated_step_report
+    from models.deeplab import DeepLab
+    from oracle import deeplab_cpu as O
+    from oracle import selection_cpu as S
+    from utils.loss import SegmentationLosses
+
+    ncls, n, hw = 21, 4, 513
+    assert ops.f32_mma() == "f16x3"
+    om = O.ODeepLab("mobilenet", 16, ncls)
+    O.fill_state_dict(om, seed=43, randomize_bn_stats=False)
+    pm = DeepLab(backbone="mobilenet", output_stride=16, num_classes=ncls, sync_bn=False, pretrained=False)
+    pm.load_state_dict(om.state_dict())
+    pm = pm.cuda().train()
+    x, lab = O.synthetic_batch(n, hw, hw, ncls, first_index=77)
+    m1, m2 = O.dropout_masks(n, 1, seed=44)
+    rep = gated_step_report(ops, O, S, pm, om.state_dict(), "mobilenet", ncls, x, lab, (m1[0], m2[0]), SegmentationLosses(cuda=True).build_loss("ce"))
+    print("config C train step 4 x 513^2: loss %.6f (f64 oracle %.6f)" % (rep["loss"], rep["loss64"]))
+    assert abs(rep["loss"] - rep["loss64"]) <= 2e-4 * abs(rep["loss64"]), (rep["loss"], rep["loss64"])
+    assert_gated_step(rep, "config C", mult=ENGINE_MULT["f16x3"])
