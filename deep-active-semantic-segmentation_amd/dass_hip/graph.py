@@ -23,6 +23,7 @@ from . import ops
 from ._lib import lib
 
 _capture_hooks = None   # the list replay hooks register into while a GraphedStep captures
+_TRACE = __import__("os").environ.get("DASS_GRAPH_TRACE") == "1"
 
 
 def register_replay_hook(fn):
@@ -122,6 +123,8 @@ class GraphedStep(object):
     def __call__(self):
         if self.graph is None:
             raise RuntimeError("GraphedStep: released (or its capture failed)")
+        if _TRACE:
+            return self._traced_call()
         for h in self.hooks:
             h()
         if self.before is not None:
@@ -132,4 +135,32 @@ class GraphedStep(object):
         if self.graph_b is not None:
             self.graph_b.replay()
         ops.weights_changed()   # (the replay stepped the optimizer: cached weight operands of eager code are stale)
+        return self.out
+
+    def _traced_call(self):
+        """DASS_GRAPH_TRACE=1: the same step with a device synchronisation and a wall-clock stamp behind every phase (diagnostic)"""
+        import sys
+        import time
+
+        t = [time.perf_counter()]
+
+        def mark():
+            torch.cuda.synchronize()
+            t.append(time.perf_counter())
+
+        for h in self.hooks:
+            h()
+        if self.before is not None:
+            self.before()
+        mark()
+        self.graph.replay()
+        mark()
+        if self.reduce is not None:
+            self.reduce()
+        mark()
+        if self.graph_b is not None:
+            self.graph_b.replay()
+        mark()
+        ops.weights_changed()
+        print("GraphedStep: before %.1f ms, graph A %.1f, reduce %.1f, graph B %.1f" % tuple(1e3 * (b - a) for a, b in zip(t, t[1:])), file=sys.stderr, flush=True)
         return self.out
