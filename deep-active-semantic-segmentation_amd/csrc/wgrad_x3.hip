@@ -606,7 +606,11 @@ int launch_group(GroupItem *it, int n, char *scratch, hipStream_t st) {
         if (hipEventRecord(sl.done, st) != hipSuccess) return DASS_ERR_LAUNCH;
         sl.used = true;
     }
-    DASS_LAUNCH((wgrad_x3_group_kernel<BMK, BNC, WARPS_M, WARPS_N, NSTAGE, NP>), dim3((unsigned)total), dim3(64 * WARPS_M * WARPS_N), 0, st, dev_p, dev_b, n);
+    // (DASS_WX3_GROUP_LDS_PAD: bytes of dynamic LDS added to the grouped launch.  The weight gradients share the chip with backward's chain of input-
+    //  gradient launches: two resident workgroups of 64 KB leave no room for a conv workgroup (33 KB) on that CU; padded beyond 80 KB only ONE fits and two
+    //  conv workgroups keep running beside it)
+    static const int lds_pad = getenv("DASS_WX3_GROUP_LDS_PAD") ? atoi(getenv("DASS_WX3_GROUP_LDS_PAD")) : 0;
+    DASS_LAUNCH((wgrad_x3_group_kernel<BMK, BNC, WARPS_M, WARPS_N, NSTAGE, NP>), dim3((unsigned)total), dim3(64 * WARPS_M * WARPS_N), lds_pad, st, dev_p, dev_b, n);
     DASS_LAUNCH_CHECK();
     return DASS_OK;
 }
